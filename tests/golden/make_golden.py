@@ -1,0 +1,273 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the REFERENCE's own code.
+
+Runs only in the build container (it reads /root/reference); the GPU box and the
+test-suite only ever see the .npz files this script writes.  Usage:
+
+    python tests/golden/make_golden.py
+
+How the reference is imported: `metayolo/__init__.py` imports cv2 and
+star-imports every sub-package, so the package object is pre-seeded with the three
+names the hot-path modules take from it (LOGGER, check_version, load_cfg) and the
+reference's own `metayolo/models/*.py` files are then imported unmodified from
+/root/reference.  torchvision / torch_scatter are not installed; they are only
+imported (never called) on the det-only path, except torchvision.ops.nms and
+remove_small_boxes inside nms_per_image, for which the build's documented restatement
+(oracle/nms_ref.py) is plugged in.  Consequently:
+
+  * conv / BN / SiLU / C3 / SPPF / FPN stage outputs, det logits, decode, matcher,
+    DetLoss and every gradient in these files are computed by the reference's code;
+  * kept-box order in the `outputs_*` entries is computed by the reference's
+    compute_outputs() on top of the oracle's NMS (torchvision boundary: unpinned).
+"""
+import importlib
+import logging
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+sys.path.insert(0, ROOT)
+
+from hd_yolo_amd import synth  # noqa: E402
+from oracle import nms_ref     # noqa: E402
+
+
+def install_shims():
+    pkg = types.ModuleType('metayolo')
+    pkg.__path__ = [os.path.join(REF, 'metayolo')]
+    pkg.LOGGER = logging.getLogger('yolov5-ref')
+    pkg.LOGGER.setLevel(logging.WARNING)
+
+    def check_version(current='0.0.0', minimum='0.0.0', *a, **k):
+        def t(v):
+            return tuple(int(''.join(c for c in p if c.isdigit()) or 0) for p in v.split('+')[0].split('.')[:3])
+        return t(current) >= t(minimum)
+
+    def load_cfg(cfg):
+        if isinstance(cfg, dict):
+            return cfg
+        import yaml
+        with open(cfg) as f:
+            return yaml.safe_load(f)
+
+    pkg.check_version, pkg.load_cfg = check_version, load_cfg
+    sys.modules['metayolo'] = pkg
+
+    tv = types.ModuleType('torchvision')
+    ops = types.ModuleType('torchvision.ops')
+    misc = types.ModuleType('torchvision.ops.misc')
+
+    def nms(boxes, scores, iou_threshold):
+        keep = nms_ref.nms_numpy(boxes.detach().cpu().numpy().astype(np.float32),
+                                 scores.detach().cpu().numpy().astype(np.float32), float(iou_threshold))
+        return torch.from_numpy(keep).to(boxes.device)
+
+    def remove_small_boxes(boxes, min_size):
+        ws, hs = boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]
+        return torch.where((ws >= min_size) & (hs >= min_size))[0]
+
+    def _absent(*a, **k):
+        raise RuntimeError('mask branch is out of scope for the goldens')
+
+    class FrozenBatchNorm2d(nn.Module):
+        pass
+
+    ops.nms, ops.remove_small_boxes, ops.roi_align = nms, remove_small_boxes, _absent
+    ops.FrozenBatchNorm2d = misc.FrozenBatchNorm2d = FrozenBatchNorm2d
+    ops.misc = misc
+    tv.ops = ops
+    models = types.ModuleType('torchvision.models')
+    det = types.ModuleType('torchvision.models.detection')
+    mr = types.ModuleType('torchvision.models.detection.mask_rcnn')
+    mr.MaskRCNNHeads = mr.MaskRCNNPredictor = _absent
+    tv.models, models.detection, det.mask_rcnn = models, det, mr
+    for name, m in [('torchvision', tv), ('torchvision.ops', ops), ('torchvision.ops.misc', misc),
+                    ('torchvision.models', models), ('torchvision.models.detection', det),
+                    ('torchvision.models.detection.mask_rcnn', mr)]:
+        sys.modules[name] = m
+    ts = types.ModuleType('torch_scatter')
+    ts.scatter_max = _absent
+    sys.modules['torch_scatter'] = ts
+
+
+def ref_model(variant, nc, hyp):
+    yolo = importlib.import_module('metayolo.models.yolo')
+    model = yolo.Model(synth.make_cfg(variant, nc), hyp)
+    sd = synth.synth_state_dict(synth.shapes_of(model), seed=0)
+    missing = model.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys
+    return model
+
+
+def npf(t):
+    return t.detach().cpu().numpy()
+
+
+def gen_stages(tag, variant, nc, batch, size, full=True):
+    """Eval-mode per-stage activations, det logits, decoded preds, final outputs."""
+    hyp = synth.make_hyp(conf_thres=0.05)
+    model = ref_model(variant, nc, hyp).eval()
+    x = synth.synth_images(batch, size, seed=7)
+    out = {'meta': np.array([batch, size, nc]), 'conf_thres': np.array(0.05)}
+    with torch.no_grad():
+        feats = model.backbone(x)
+        for k, v in feats.items():
+            out[f'backbone_{k}'] = npf(v)
+        # stage-by-stage backbone (every layer, for localisation of a mismatch)
+        h = x
+        for i, m in enumerate(model.backbone):
+            h = m(h)
+            if full:
+                out[f'stage_{i}'] = npf(h)
+        neck = model.neck(dict(feats))
+        for k, v in neck.items():
+            out[f'neck_{k}'] = npf(v)
+        head = model.headers['det']
+        xs = [neck[j] for j in head.f]
+        dets = []
+        for i, conv in enumerate(head.m):
+            f = conv(xs[i])
+            bs, _, ny, nx = f.shape
+            dets.append(f.view(bs, head.na, head.no, ny, nx).permute(0, 1, 3, 4, 2).contiguous())
+            out[f'det_{i}'] = npf(dets[-1])
+        preds = head.compute_proposals(dets)
+        for i, p in enumerate(preds):
+            out[f'pred_{i}'] = npf(p)
+        _, outputs = model(x)
+        for b, o in enumerate(outputs):
+            out[f'out_{b}_boxes'] = npf(o['det']['boxes'])
+            out[f'out_{b}_scores'] = npf(o['det']['scores'])
+            out[f'out_{b}_labels'] = npf(o['det']['labels'])
+        # fuse() equivalence: eval outputs after conv+bn folding
+        if full:
+            model.fuse()
+            feats = model.neck(model.backbone(x))
+            for k, v in feats.items():
+                out[f'fused_neck_{k}'] = npf(v)
+    np.savez_compressed(os.path.join(HERE, f'stages_{tag}.npz'), **out)
+    print('wrote', f'stages_{tag}.npz', {k: v.shape for k, v in list(out.items())[:4]})
+
+
+GRAD_KEYS = ['backbone.0.conv.weight', 'backbone.1.conv.weight', 'backbone.2.m.0.cv2.conv.weight',
+             'backbone.2.cv3.conv.weight', 'backbone.2.cv1.bn.weight', 'backbone.2.cv1.bn.bias',
+             'backbone.9.cv2.conv.weight', 'neck.3.cv3.conv.weight', 'neck.8.conv.weight',
+             'headers.det.m.0.weight', 'headers.det.m.0.bias', 'headers.det.m.2.weight']
+STAT_KEYS = ['backbone.0.bn.running_mean', 'backbone.0.bn.running_var',
+             'backbone.4.m.1.cv2.bn.running_mean', 'backbone.4.m.1.cv2.bn.running_var',
+             'neck.13.cv3.bn.running_mean', 'neck.13.cv3.bn.running_var']
+
+
+def gen_train(tag, variant, nc, batch, size, nmin, nmax):
+    """Train-mode: loss dict, BN running stats after one forward, gradients."""
+    hyp = synth.make_hyp()
+    model = ref_model(variant, nc, hyp).train()
+    x = synth.synth_images(batch, size, seed=11)
+    targets = synth.synth_targets(batch, size, nc, nmin=nmin, nmax=nmax, seed=5)
+    losses, _ = model(x, targets, compute_masks=True)
+    loss = losses['det']['det_loss'] + losses['det']['mask_loss']
+    loss.backward()
+    out = {'meta': np.array([batch, size, nc, nmin, nmax]),
+           'loss': npf(losses['det']['det_loss'])}
+    for k, v in losses['det']['loss_items'].items():
+        out[f'loss_{k}'] = npf(v)
+    sd = model.state_dict()
+    for k in STAT_KEYS:
+        out['stat:' + k] = npf(sd[k])
+    params = dict(model.named_parameters())
+    for k in GRAD_KEYS:
+        if params[k].numel() <= 40000:      # keep fixtures small; gradsum below covers the rest
+            out['grad:' + k] = npf(params[k].grad)
+    # one (sum, abs-sum, l2) triple per parameter: catches a wrong gradient anywhere
+    names, sums = [], []
+    for k, p in params.items():
+        g = p.grad
+        if g is None:
+            continue
+        names.append(k)
+        g64 = g.double()
+        sums.append([g64.sum().item(), g64.abs().sum().item(), g64.pow(2).sum().sqrt().item()])
+    out['gradsum_names'] = np.array(names)
+    out['gradsum'] = np.array(sums, dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, f'train_{tag}.npz'), **out)
+    print('wrote', f'train_{tag}.npz', 'loss', out['loss'], {k: float(out[k].reshape(-1)[0]) for k in out if k.startswith('loss_')})
+
+
+def gen_decode():
+    """Decode-only vectors: default grid sizes and a non-default one (forces _make_grid)."""
+    hyp = synth.make_hyp()
+    model = ref_model('n', 2, hyp).eval()
+    head = model.headers['det']
+    g = torch.Generator().manual_seed(99)
+    out = {}
+    for tag, sizes in [('default', [(80, 80), (40, 40), (20, 20)]), ('odd', [(12, 20), (6, 10), (3, 5)])]:
+        dets = [torch.randn((2, head.na, ny, nx, head.no), generator=g) * 2.0 for ny, nx in sizes]
+        with torch.no_grad():
+            preds = head.compute_proposals(dets)
+        for i, (d, p) in enumerate(zip(dets, preds)):
+            if tag == 'default':     # keep the fixture small: one image, a strip of rows
+                d, p = d[:1, :, :4], p[:1, :, :4]
+            out[f'{tag}_det_{i}'] = npf(d)
+            out[f'{tag}_pred_{i}'] = npf(p)
+    np.savez_compressed(os.path.join(HERE, 'decode.npz'), **out)
+    print('wrote decode.npz')
+
+
+def gen_outputs():
+    """compute_outputs(): score/label logic incl. the -100 label and multi_label=True.
+    NMS inside is the oracle's (see module docstring)."""
+    out = {}
+    for tag, ml in [('single', False), ('multi', True)]:
+        hyp = synth.make_hyp(conf_thres=0.15, multi_label=ml)
+        model = ref_model('n', 3, hyp).eval()
+        head = model.headers['det']
+        g = torch.Generator().manual_seed(123)
+        # logits centred so that a good share of candidates pass obj > conf and overlap
+        dets = [torch.randn((2, head.na, ny, nx, head.no), generator=g) * 1.5 for ny, nx in [(8, 8), (4, 4), (2, 2)]]
+        with torch.no_grad():
+            preds = head.compute_proposals([d.clone() for d in dets])
+            res = head.compute_outputs(preds, [], compute_masks=False)
+        for i, d in enumerate(dets):
+            out[f'{tag}_det_{i}'] = npf(d)
+        for b, r in enumerate(res):
+            out[f'{tag}_out_{b}_boxes'] = npf(r['boxes'])
+            out[f'{tag}_out_{b}_scores'] = npf(r['scores'])
+            out[f'{tag}_out_{b}_labels'] = npf(r['labels'])
+    np.savez_compressed(os.path.join(HERE, 'outputs.npz'), **out)
+    print('wrote outputs.npz')
+
+
+def gen_keys():
+    """state_dict key list + shapes for the four variants (drop-in surface)."""
+    out = {}
+    for v, nc in [('n', 2), ('s', 8), ('m', 8), ('l', 8)]:
+        model = ref_model(v, nc, synth.make_hyp())
+        sd = model.state_dict()
+        out[f'{v}_keys'] = np.array(list(sd.keys()))
+        out[f'{v}_shapes'] = np.array([','.join(map(str, t.shape)) for t in sd.values()])
+        out[f'{v}_nparams'] = np.array(sum(p.numel() for p in model.parameters()))
+    np.savez_compressed(os.path.join(HERE, 'keys.npz'), **out)
+    print('wrote keys.npz', {k: int(v) for k, v in out.items() if k.endswith('nparams')})
+
+
+def main():
+    assert os.path.isdir(REF), 'the reference is only mounted in the build container'
+    torch.set_num_threads(8)
+    install_shims()
+    gen_keys()
+    gen_decode()
+    gen_outputs()
+    gen_stages('n_64', 'n', 2, 2, 64)
+    gen_stages('s_128', 's', 8, 1, 128, full=False)
+    gen_train('n_64', 'n', 2, 2, 64, 3, 8)
+    gen_train('s_128', 's', 8, 2, 128, 10, 30)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,143 @@
+"""The CPU oracle (oracle/ref_net.py) against golden vectors produced by the reference's own code
+(tests/golden/make_golden.py).  This is what pins the oracle; GPU parity tests then compare the
+HIP path with the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from hd_yolo_amd import synth
+from oracle.ref_net import RefNet, fold_bn
+
+RTOL, ATOL = 1e-5, 1e-6      # fp32 CPU vs fp32 CPU; differences are summation-order only
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def close(a, b, rtol=RTOL, atol=ATOL):
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize('v,nc', [('n', 2), ('s', 8), ('m', 8), ('l', 8)])
+def test_state_dict_surface(golden_dir, v, nc):
+    g = load(golden_dir, 'keys.npz')
+    net = RefNet(synth.make_cfg(v, nc), synth.make_hyp())
+    ref = {k: s for k, s in zip(g[f'{v}_keys'], g[f'{v}_shapes'])}
+    for k, (shape, _) in net.shapes.items():
+        assert k in ref, k
+        assert ','.join(map(str, shape)) == ref[k], k
+    # everything the oracle does not carry is a non-learned buffer of the reference
+    extra = [k for k in ref if k not in net.shapes]
+    assert all(('num_batches_tracked' in k) or ('.anchors.' in k) or ('mask_indices' in k) or ('det_loss' in k)
+               for k in extra), extra
+
+
+@pytest.mark.parametrize('tag,v', [('n_64', 'n'), ('s_128', 's')])
+def test_eval_stages(golden_dir, tag, v):
+    g = load(golden_dir, f'stages_{tag}.npz')
+    batch, size, nc = (int(t) for t in g['meta'])
+    net = RefNet(synth.make_cfg(v, nc), synth.make_hyp(conf_thres=float(g['conf_thres'])))
+    sd = net.init_state()
+    x = synth.synth_images(batch, size, seed=7)
+    with torch.no_grad():
+        feats, dets, preds, outs = net.eval_forward(sd, x)
+    for k in g.files:
+        if k.startswith('stage_'):
+            close(feats[int(k[6:])], g[k], rtol=1e-4, atol=1e-5)
+        elif k.startswith('neck_'):
+            close(feats[int(k[5:])], g[k], rtol=1e-4, atol=1e-5)
+    for i in range(3):
+        close(dets[i], g[f'det_{i}'], rtol=1e-4, atol=1e-5)
+        close(preds[i], g[f'pred_{i}'], rtol=1e-4, atol=1e-4)
+    for b in range(batch):
+        assert outs[b]['boxes'].shape == g[f'out_{b}_boxes'].shape
+        close(outs[b]['boxes'], g[f'out_{b}_boxes'], rtol=1e-4, atol=1e-3)
+        close(outs[b]['scores'], g[f'out_{b}_scores'], rtol=1e-4, atol=1e-6)
+        assert np.array_equal(outs[b]['labels'].numpy(), g[f'out_{b}_labels'])
+    assert sum(len(o['boxes']) for o in outs) > 0
+
+
+def test_fold_bn_matches_fused_reference(golden_dir):
+    g = load(golden_dir, 'stages_n_64.npz')
+    batch, size, nc = (int(t) for t in g['meta'])
+    net = RefNet(synth.make_cfg('n', nc), synth.make_hyp())
+    sd = net.init_state()
+    # fold every conv, replace BN by identity statistics, and re-run
+    sd2 = dict(sd)
+    for k in list(sd):
+        if k.endswith('.conv.weight'):
+            p = k[:-len('.conv.weight')]
+            w, b = fold_bn(sd, p)
+            sd2[k] = w
+            c = w.shape[0]
+            sd2[p + '.bn.weight'] = torch.full((c,), float(np.sqrt(1 + 1e-3)))
+            sd2[p + '.bn.running_var'] = torch.ones(c)
+            sd2[p + '.bn.running_mean'] = torch.zeros(c)
+            sd2[p + '.bn.bias'] = b
+    with torch.no_grad():
+        feats = net.features(sd2, synth.synth_images(batch, size, seed=7))
+    for k in g.files:
+        if k.startswith('fused_neck_'):
+            close(feats[int(k[11:])], g[k], rtol=1e-3, atol=1e-4)
+
+
+def test_decode(golden_dir):
+    g = load(golden_dir, 'decode.npz')
+    net = RefNet(synth.make_cfg('n', 2), synth.make_hyp())
+    for tag in ('default', 'odd'):
+        dets = [torch.from_numpy(g[f'{tag}_det_{i}']) for i in range(3)]
+        preds = net.decode(dets)
+        for i in range(3):
+            close(preds[i], g[f'{tag}_pred_{i}'], rtol=1e-6, atol=1e-5)
+
+
+@pytest.mark.parametrize('tag,ml', [('single', False), ('multi', True)])
+def test_outputs_logic(golden_dir, tag, ml):
+    g = load(golden_dir, 'outputs.npz')
+    net = RefNet(synth.make_cfg('n', 3), synth.make_hyp(conf_thres=0.15, multi_label=ml))
+    dets = [torch.from_numpy(g[f'{tag}_det_{i}']) for i in range(3)]
+    outs = net.outputs(net.decode(dets))
+    seen_unclassified = False
+    for b, o in enumerate(outs):
+        close(o['boxes'], g[f'{tag}_out_{b}_boxes'], rtol=1e-6, atol=1e-4)
+        close(o['scores'], g[f'{tag}_out_{b}_scores'], rtol=1e-6, atol=1e-7)
+        assert np.array_equal(o['labels'].numpy(), g[f'{tag}_out_{b}_labels'])
+        if not ml:
+            seen_unclassified |= bool((o['labels'] == -100).any())
+    if not ml:
+        assert seen_unclassified, 'fixture must exercise the -100 label branch'
+
+
+@pytest.mark.parametrize('tag,v', [('n_64', 'n'), ('s_128', 's')])
+def test_train_loss_and_grads(golden_dir, tag, v):
+    g = load(golden_dir, f'train_{tag}.npz')
+    batch, size, nc, nmin, nmax = (int(t) for t in g['meta'])
+    net = RefNet(synth.make_cfg(v, nc), synth.make_hyp())
+    sd = net.init_state()
+    for k, t in sd.items():
+        if 'running' not in k:
+            t.requires_grad_(True)
+    x = synth.synth_images(batch, size, seed=11)
+    targets = synth.synth_targets(batch, size, nc, nmin=nmin, nmax=nmax, seed=5)
+    loss, items, _ = net.train_forward(sd, x, targets)
+    loss.backward()
+    close(loss, g['loss'], rtol=1e-5)
+    for k in ('box', 'obj', 'cls'):
+        close(items[k], g[f'loss_{k}'], rtol=1e-5)
+    for k in g.files:
+        if k.startswith('stat:'):
+            close(sd[k[5:]], g[k], rtol=1e-4, atol=1e-6)
+        elif k.startswith('grad:'):
+            ref = g[k]
+            got = sd[k[5:]].grad.numpy()
+            scale = np.abs(ref).max() + 1e-12
+            assert np.abs(got - ref).max() / scale < 2e-4, k
+    names = list(g['gradsum_names'])
+    for name, (s, a, l2) in zip(names, g['gradsum']):
+        gr = sd[name].grad.double()
+        assert abs(gr.abs().sum().item() - a) <= 2e-4 * a + 1e-9, name
+        assert abs(gr.pow(2).sum().sqrt().item() - l2) <= 2e-4 * l2 + 1e-9, name
