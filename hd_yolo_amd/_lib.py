@@ -1,0 +1,78 @@
+"""ctypes binding of libhdyolo_hip.so (include/hdyolo.h).
+
+The product path has no CPU fallback: if the library is missing or a call fails this module raises.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'build', 'libhdyolo_hip.so')
+
+F32, BF16 = 0, 1
+PACK_FWD, PACK_DGRAD, PACK_STEM = 0, 1, 2
+ACT_NONE, ACT_SILU = 0, 1
+
+_P, _I, _L, _F, _Z = c_void_p, c_int, c_longlong, c_float, c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/hdyolo.h declares (tests check this)
+SIGNATURES = {
+    'hdy_last_error': (c_char_p, []),
+    'hdy_version': (_I, []),
+    'hdy_conv_out_dim': (_I, [_I, _I, _I, _I]),
+    'hdy_conv_mtiles': (_I, [_L]),
+    'hdy_conv_pack_elems': (_Z, [_I, _I, _I, _I, _I, _I, _I, _I]),
+    'hdy_conv_pack': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    'hdy_conv_fwd': (_I, [_P, _I, _P, _P, _P, _P, _I, _P] + [_I] * 14 + [_P]),
+    'hdy_conv_dgrad': (_I, [_P, _I, _P, _P, _I] + [_I] * 11 + [_P]),
+    'hdy_conv_wgrad_workspace_bytes': (_Z, [_I] * 11),
+    'hdy_conv_wgrad': (_I, [_P, _I, _P, _I] + [_I] * 9 + [_P, _I, _P, _I, _I, _P, _Z, _I, _I, _P]),
+    'hdy_bn_finalize': (_I, [_P, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
+    'hdy_bn_eval_coeffs': (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
+    'hdy_bn_act_fwd': (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _L, _I, _I, _I, _P]),
+    'hdy_bn_bwd_blocks': (_I, [_L]),
+    'hdy_bn_act_bwd': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _L, _I, _I, _I, _P, _P]),
+    'hdy_add_inplace': (_I, [_P, _I, _P, _I, _L, _I, _I, _P]),
+    'hdy_sppf_pool_fwd': (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    'hdy_sppf_pool_bwd': (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    'hdy_upsample2x_fwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
+    'hdy_upsample2x_bwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'hdy_stem_prep': (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    'hdy_nchw_to_nhwc': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    'hdy_decode': (_I, [_P, _L, _L, _L, _L, _P, _F, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'hdy_nms_workspace_bytes': (_Z, [_I, _I]),
+    'hdy_nms_batched': (_I, [_P, _I, _I, _I, _I, _F, _F, _I, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+}
+
+_lib = None
+
+
+class HdyError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once).  Raises HdyError with build instructions if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HdyError(f'{LIB_PATH} is missing: run `python -m hd_yolo_amd.build` (hipcc, gfx950). '
+                           'hd_yolo_amd has no CPU fallback.')
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def call(name, *args):
+    """Call an int-returning entry point; raise HdyError(hdy_last_error()) on a non-zero status."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise HdyError(f'{name} failed (status {rc}): {lib.hdy_last_error().decode()}')
+
+
+def query(name, *args):
+    return getattr(load(), name)(*args)

@@ -1,0 +1,233 @@
+// C-ABI entry points for the convolution family (see include/hdyolo.h).  Everything here is host code that
+// validates shapes, derives the tap-window geometry and launches the kernels in conv_igemm.hip / conv_wgrad.hip
+// on the caller's stream.  No allocation, no synchronisation, no global state besides the thread-local error text.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "common.h"
+#include "hdyolo_internal.h"
+
+int hdy_wgrad_reduce_launch(const float* partial, int splits, size_t slab_stride, int K, int Q, int mode, int C, int R, int S, float* grad,
+                            int accumulate, hipStream_t st);
+int hdy_pack_weight_launch(const float* w, void* out, int K, int C, int R, int S, int transpose, int TH, int TW, int rbase, int rstep,
+                           int sbase, int sstep, int stem, int rows_valid, int rows_total, int Kdp, int dtype, hipStream_t st);
+
+static thread_local char g_err[512] = "";
+
+void hdy_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+namespace {
+
+enum { KIND_FWD = 0, KIND_DGRAD = 1, KIND_STEM = 2 };
+
+inline int velems(int dtype) { return dtype == HDY_BF16 ? 8 : 4; }
+inline int bke(int dtype) { return 8 * velems(dtype); }
+inline size_t esize(int dtype) { return dtype == HDY_BF16 ? 2 : 4; }
+
+// One spatial axis of a stride-2 dgrad parity class: output positions h = 2*i + a take the kernel taps
+// r = rmax, rmax-2, ... (same parity as a + pad), reading dy row i + d0 + t for the t-th of them.
+struct Axis { int taps, d0, rmax; };
+inline Axis class_axis(int R, int pad, int a) {
+    Axis ax = {0, 0, -1};
+    for (int r = R - 1; r >= 0; --r)
+        if (((a + pad - r) & 1) == 0) {
+            if (ax.rmax < 0) { ax.rmax = r; ax.d0 = (a + pad - r) / 2; }
+            ++ax.taps;
+        }
+    return ax;
+}
+
+// rows (padded to the N-tile) x pitch of one packed block
+inline size_t block_elems(int rows, int kd, int dtype) {
+    const int bn = hdy_conv_bn_tile(rows);
+    return (size_t)round_up(rows, bn) * round_up(kd, bke(dtype));
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* hdy_last_error(void) { return g_err; }
+
+int hdy_version(void) { return 1; }
+
+int hdy_conv_out_dim(int in, int k, int stride, int pad) { return (in + 2 * pad - k) / stride + 1; }
+
+int hdy_conv_mtiles(long long M) { return (int)((M + 127) / 128); }
+
+size_t hdy_conv_pack_elems(int K, int C, int R, int S, int stride, int pad, int kind, int dtype) {
+    if (kind == KIND_FWD) return block_elems(K, R * S * C, dtype);
+    if (kind == KIND_STEM) return block_elems(K, R * S * 4, dtype);
+    if (stride == 1) return block_elems(C, R * S * K, dtype);
+    size_t n = 0;
+    for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b) {
+            const Axis ah = class_axis(R, pad, a), aw = class_axis(S, pad, b);
+            if (ah.taps && aw.taps) n += block_elems(C, ah.taps * aw.taps * K, dtype);
+        }
+    return n;
+}
+
+// w_a [K_a][C][R][S] (+ optional w_b [K_b][C][R][S] stacked below it along K) -> packed operand for `kind`.
+int hdy_conv_pack(const float* w_a, int K_a, const float* w_b, int K_b, int C, int R, int S, int stride, int pad, int kind, int dtype,
+                  void* out, void* stream) {
+    HDY_ARG(w_a && out && K_a > 0 && K_b >= 0 && C > 0 && R > 0 && S > 0, "conv_pack: bad args");
+    HDY_ARG((K_b == 0) == (w_b == nullptr), "conv_pack: w_b / K_b mismatch");
+    HDY_ARG(stride == 1 || stride == 2, "conv_pack: stride %d unsupported", stride);
+    hipStream_t st = (hipStream_t)stream;
+    const int K = K_a + K_b;
+    // the pack kernel reads one source tensor; stacked sources are handled as two row (fwd) / column (dgrad) ranges
+    if (kind == KIND_FWD || kind == KIND_STEM) {
+        const int stem = kind == KIND_STEM;
+        HDY_ARG(!stem || (C == 3 && K_b == 0), "conv_pack: stem expects C == 3 and a single weight");
+        const int kd = stem ? R * S * 4 : R * S * C;
+        const int Kdp = round_up(kd, bke(dtype));
+        const int rows_total = round_up(K, hdy_conv_bn_tile(K));
+        const int TH = stem ? R : R, TW = stem ? 1 : S;
+        int rc = hdy_pack_weight_launch(w_a, out, K_a, C, R, S, 0, TH, TW, 0, 1, 0, 1, stem, K_a, K_b ? K_a : rows_total, Kdp, dtype, st);
+        if (rc) return rc;
+        if (K_b)
+            rc = hdy_pack_weight_launch(w_b, (char*)out + (size_t)K_a * Kdp * esize(dtype), K_b, C, R, S, 0, TH, TW, 0, 1, 0, 1, 0, K_b,
+                                        rows_total - K_a, Kdp, dtype, st);
+        return rc;
+    }
+    HDY_ARG(kind == KIND_DGRAD, "conv_pack: unknown kind %d", kind);
+    HDY_ARG(K_b == 0, "conv_pack: dgrad packing of stacked weights: pack the stacked fp32 tensor instead");
+    const int rows_total = round_up(C, hdy_conv_bn_tile(C));
+    if (stride == 1) {
+        const int Kdp = round_up(R * S * K, bke(dtype));
+        return hdy_pack_weight_launch(w_a, out, K, C, R, S, 1, R, S, R - 1, -1, S - 1, -1, 0, C, rows_total, Kdp, dtype, st);
+    }
+    size_t off = 0;
+    for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b) {
+            const Axis ah = class_axis(R, pad, a), aw = class_axis(S, pad, b);
+            if (!ah.taps || !aw.taps) continue;
+            const int Kdp = round_up(ah.taps * aw.taps * K, bke(dtype));
+            int rc = hdy_pack_weight_launch(w_a, (char*)out + off * esize(dtype), K, C, R, S, 1, ah.taps, aw.taps, ah.rmax, -2, aw.rmax, -2, 0,
+                                            C, rows_total, Kdp, dtype, st);
+            if (rc) return rc;
+            off += (size_t)rows_total * Kdp;
+        }
+    return HDY_OK;
+}
+
+// y = act(scale * conv(x, w) + shift) [+= y]; NHWC with pixel pitches; optional BatchNorm slabs in `stats`.
+// stem != 0: x is the hdy_stem_prep() buffer [N][H+2*pad][W+2*pad][4] and (C,R,S,stride,pad) must be (3,6,6,2,2).
+int hdy_conv_fwd(const void* x, int ldx, const void* w_packed, const float* scale, const float* shift, void* y, int ldy, float* stats,
+                 int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int act, int accumulate, int dtype, int out_f32,
+                 int stem, void* stream) {
+    HDY_ARG(stride >= 1 && R >= 1 && S >= 1 && pad >= 0, "conv_fwd: bad window");
+    HDY_ARG(dtype == HDY_BF16 || dtype == HDY_F32, "conv_fwd: unknown dtype %d", dtype);
+    ConvArgs a = {};
+    a.x = x; a.w = w_packed; a.y = y; a.scale = scale; a.shift = shift; a.stats = stats;
+    a.N = N;
+    a.Ho = hdy_conv_out_dim(H, R, stride, pad);
+    a.Wo = hdy_conv_out_dim(W, S, stride, pad);
+    HDY_ARG(a.Ho > 0 && a.Wo > 0, "conv_fwd: empty output");
+    a.K = K; a.ldy = ldy;
+    a.Hout = a.Ho; a.Wout = a.Wo; a.oh_mul = a.ow_mul = 1; a.oh_off = a.ow_off = 0; a.dense_out = 1;
+    a.act = act; a.accumulate = accumulate;
+    if (stem) {
+        HDY_ARG(C == 3 && R == 6 && S == 6 && stride == 2 && pad == 2 && ldx == 4, "conv_fwd: stem expects C=3 k=6 s=2 p=2 on a 4-channel padded image");
+        a.Hin = H + 2 * pad; a.Win = W + 2 * pad; a.C = 24; a.ldx = 4; a.span_pixels = 1;
+        a.ih_mul = 2; a.iw_mul = 2; a.dh0 = 0; a.dw0 = 0; a.TH = 6; a.TW = 1;
+        a.Kdp = round_up(6 * 24, bke(dtype));
+        return hdy_conv_igemm_launch(a, dtype, out_f32, (hipStream_t)stream);
+    }
+    a.Hin = H; a.Win = W; a.C = C; a.ldx = ldx;
+    a.ih_mul = stride; a.iw_mul = stride; a.dh0 = -pad; a.dw0 = -pad; a.TH = R; a.TW = S;
+    a.Kdp = round_up(R * S * C, bke(dtype));
+    return hdy_conv_igemm_launch(a, dtype, out_f32, (hipStream_t)stream);
+}
+
+// dx (+)= conv_transpose(dy, w): dx is [N][H][W][lddx] (C channels), dy is [N][Ho][Wo][lddy] (K channels).
+int hdy_conv_dgrad(const void* dy, int lddy, const void* w_packed_dgrad, void* dx, int lddx, int N, int H, int W, int C, int K, int R,
+                   int S, int stride, int pad, int accumulate, int dtype, void* stream) {
+    HDY_ARG(stride == 1 || stride == 2, "conv_dgrad: stride %d unsupported", stride);
+    HDY_ARG(dtype == HDY_BF16 || dtype == HDY_F32, "conv_dgrad: unknown dtype %d", dtype);
+    const int Ho = hdy_conv_out_dim(H, R, stride, pad), Wo = hdy_conv_out_dim(W, S, stride, pad);
+    HDY_ARG(Ho > 0 && Wo > 0, "conv_dgrad: empty dy");
+    ConvArgs a = {};
+    a.x = dy; a.y = dx; a.N = N; a.Hin = Ho; a.Win = Wo; a.C = K; a.ldx = lddy;
+    a.K = C; a.ldy = lddx; a.Hout = H; a.Wout = W;
+    a.ih_mul = a.iw_mul = 1; a.accumulate = accumulate;
+    if (stride == 1) {
+        a.w = w_packed_dgrad;
+        a.Ho = H; a.Wo = W; a.oh_mul = a.ow_mul = 1; a.dense_out = 1;
+        a.dh0 = pad - (R - 1); a.dw0 = pad - (S - 1); a.TH = R; a.TW = S;
+        a.Kdp = round_up(R * S * K, bke(dtype));
+        return hdy_conv_igemm_launch(a, dtype, 0, (hipStream_t)stream);
+    }
+    const int rows_total = round_up(C, hdy_conv_bn_tile(C));
+    size_t off = 0;
+    for (int ca = 0; ca < 2; ++ca)
+        for (int cb = 0; cb < 2; ++cb) {
+            const Axis ah = class_axis(R, pad, ca), aw = class_axis(S, pad, cb);
+            ConvArgs c = a;
+            c.Ho = (H - ca + 1) / 2; c.Wo = (W - cb + 1) / 2;
+            c.oh_mul = c.ow_mul = 2; c.oh_off = ca; c.ow_off = cb; c.dense_out = 0;
+            if (!ah.taps || !aw.taps) {
+                HDY_ARG(false, "conv_dgrad: kernel %dx%d pad %d leaves a parity class without taps (unsupported)", R, S, pad);
+            }
+            if (c.Ho <= 0 || c.Wo <= 0) continue;
+            c.dh0 = ah.d0; c.dw0 = aw.d0; c.TH = ah.taps; c.TW = aw.taps;
+            c.Kdp = round_up(ah.taps * aw.taps * K, bke(dtype));
+            c.w = (const char*)w_packed_dgrad + off * esize(dtype);
+            off += (size_t)rows_total * c.Kdp;
+            const int rc = hdy_conv_igemm_launch(c, dtype, 0, (hipStream_t)stream);
+            if (rc) return rc;
+        }
+    return HDY_OK;
+}
+
+size_t hdy_conv_wgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dtype, int stem) {
+    const int Ho = hdy_conv_out_dim(H, R, stride, pad), Wo = hdy_conv_out_dim(W, S, stride, pad);
+    const int Q = stem ? R * S * 4 : R * S * C;
+    int splits = 1, pps = 64;
+    hdy_wgrad_plan(K, Q, (long long)N * Ho * Wo, dtype, &splits, &pps);
+    return (size_t)splits * K * Q * sizeof(float);
+}
+
+// grad_a [K_a][C][R][S] (and optionally grad_b [K_b][C][R][S], the lower rows of a stacked weight) (+)= dW.
+int hdy_conv_wgrad(const void* x, int ldx, const void* dy, int lddy, int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
+                   float* grad_a, int K_a, float* grad_b, int K_b, int accumulate, void* workspace, size_t ws_bytes, int dtype, int stem,
+                   void* stream) {
+    HDY_ARG(grad_a && K_a > 0 && K_a + K_b <= K && K_b >= 0 && (K_b == 0) == (grad_b == nullptr), "conv_wgrad: bad gradient split");
+    HDY_ARG(dtype == HDY_BF16 || dtype == HDY_F32, "conv_wgrad: unknown dtype %d", dtype);
+    HDY_ARG(workspace && ws_bytes >= hdy_conv_wgrad_workspace_bytes(N, H, W, C, K, R, S, stride, pad, dtype, stem), "conv_wgrad: workspace too small");
+    WgradArgs a = {};
+    a.x = x; a.dy = dy; a.partial = (float*)workspace;
+    a.N = N; a.K = K; a.lddy = lddy;
+    a.Ho = hdy_conv_out_dim(H, R, stride, pad);
+    a.Wo = hdy_conv_out_dim(W, S, stride, pad);
+    HDY_ARG(a.Ho > 0 && a.Wo > 0, "conv_wgrad: empty dy");
+    if (stem) {
+        HDY_ARG(C == 3 && R == 6 && S == 6 && stride == 2 && pad == 2 && ldx == 4, "conv_wgrad: stem expects C=3 k=6 s=2 p=2 on a 4-channel padded image");
+        a.Hin = H + 2 * pad; a.Win = W + 2 * pad; a.C = 24; a.ldx = 4; a.span_pixels = 1;
+        a.ih_mul = a.iw_mul = 2; a.dh0 = a.dw0 = 0; a.TH = 6; a.TW = 1;
+    } else {
+        a.Hin = H; a.Win = W; a.C = C; a.ldx = ldx;
+        a.ih_mul = a.iw_mul = stride; a.dh0 = a.dw0 = -pad; a.TH = R; a.TW = S;
+    }
+    const int Q = a.TH * a.TW * a.C;
+    hdy_wgrad_plan(K, Q, (long long)N * a.Ho * a.Wo, dtype, &a.splits, &a.pix_per_split);
+    int rc = hdy_wgrad_launch(a, dtype, (hipStream_t)stream);
+    if (rc) return rc;
+    const int mode = stem ? 1 : 0;
+    rc = hdy_wgrad_reduce_launch(a.partial, a.splits, (size_t)K * Q, K_a, Q, mode, C, R, S, grad_a, accumulate, (hipStream_t)stream);
+    if (rc) return rc;
+    if (K_b) {
+        // rows K_a.. of every slab belong to the second tensor
+        rc = hdy_wgrad_reduce_launch(a.partial + (size_t)K_a * Q, a.splits, (size_t)K * Q, K_b, Q, mode, C, R, S, grad_b, accumulate,
+                                     (hipStream_t)stream);
+    }
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,362 @@
+// BatchNorm (train / eval) + SiLU (+ residual) forward and backward around the conv kernels, gfx950.
+//
+// All of these are HBM-bound streaming kernels over NHWC tensors with explicit pixel pitches: one 16-byte
+// vector (8 bf16 / 4 f32 channels) per lane per access, fp32 math, per-channel coefficients kept in registers.
+//
+//   forward (train):  conv writes raw y and per-tile (sum, sumsq) slabs  ->  bn_finalize (deterministic slab
+//                     reduction in fp64, running-stat update, scale/shift)  ->  bn_act_fwd: z = silu(y*scale+shift) [+ res]
+//   backward:         bn_act_bwd_reduce: per-channel partial sums of du = dz*silu'(u) and du*xhat
+//                     ->  bn_bwd_finalize: dgamma, dbeta, c1 = dbeta/M, c2 = dgamma/M
+//                     ->  bn_act_bwd_apply: dy = scale*(du - c1 - xhat*c2)        (recomputes du, xhat from dz, y)
+//
+// Reference semantics replaced: nn.BatchNorm2d (eps 1e-3, momentum 0.03: metayolo/models/utils_torch.py:47-49)
+// and nn.SiLU inside Conv.forward (metayolo/models/layers.py:37-38), the Bottleneck residual add (:97),
+// and their autograd backward.
+#include "common.h"
+
+namespace {
+
+template <typename T> struct VT;
+template <> struct VT<float> { static constexpr int VE = 4; };
+template <> struct VT<bf16_t> { static constexpr int VE = 8; };
+
+template <typename T> __device__ __forceinline__ void unpack(const i32x4& v, float* f);
+template <> __device__ __forceinline__ void unpack<float>(const i32x4& v, float* f) {
+    V16 u; u.i = v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = u.f[i];
+}
+template <> __device__ __forceinline__ void unpack<bf16_t>(const i32x4& v, float* f) {
+    V16 u; u.i = v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (float)u.h[i];
+}
+template <typename T> __device__ __forceinline__ i32x4 pack(const float* f);
+template <> __device__ __forceinline__ i32x4 pack<float>(const float* f) {
+    V16 u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) u.f[i] = f[i];
+    return u.i;
+}
+template <> __device__ __forceinline__ i32x4 pack<bf16_t>(const float* f) {
+    V16 u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) u.h[i] = (bf16_t)f[i];
+    return u.i;
+}
+
+// ---------------------------------------------------------------- finalize (forward)
+// grid = ceil(K/32), block = 32 channels x 32 tile-lanes
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ stats, int mtiles, int K, double count,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ rmean, float* __restrict__ rvar, float eps, float momentum,
+                                                           float* __restrict__ scale, float* __restrict__ shift,
+                                                           float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+    __shared__ double red[2][32][33];
+    const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
+    const int k = blockIdx.x * 32 + cl;
+    double s = 0.0, ss = 0.0;
+    if (k < K) {
+        for (int t = tl; t < mtiles; t += 32) {
+            s += (double)stats[((size_t)t * 2 + 0) * K + k];
+            ss += (double)stats[((size_t)t * 2 + 1) * K + k];
+        }
+    }
+    red[0][tl][cl] = s;
+    red[1][tl][cl] = ss;
+    __syncthreads();
+    if (tl == 0 && k < K) {
+        s = 0.0; ss = 0.0;
+        for (int t = 0; t < 32; ++t) { s += red[0][t][cl]; ss += red[1][t][cl]; }
+        const double mean = s / count;
+        double var = ss / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[k] * invstd;
+        scale[k] = sc;
+        shift[k] = beta[k] - (float)mean * sc;
+        save_mean[k] = (float)mean;
+        save_invstd[k] = invstd;
+        if (rmean) {
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            rmean[k] = (1.0f - momentum) * rmean[k] + momentum * (float)mean;
+            rvar[k] = (1.0f - momentum) * rvar[k] + momentum * (float)unbiased;
+        }
+    }
+}
+
+__global__ void bn_eval_coeffs_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ rmean,
+                                      const float* __restrict__ rvar, float eps, int K, float* __restrict__ scale, float* __restrict__ shift) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const float sc = gamma[k] / sqrtf(rvar[k] + eps);
+    scale[k] = sc;
+    shift[k] = beta[k] - rmean[k] * sc;
+}
+
+// ---------------------------------------------------------------- forward apply
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, const T* __restrict__ res, int ldr,
+                                                         T* __restrict__ z, int ldz, long long M, int K, int act) {
+    constexpr int VE = VT<T>::VE;
+    const int VC = K / VE;
+    const long long total = M * VC;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const long long m = idx / VC;
+        const int c = (int)(idx - m * VC) * VE;
+        float v[VE], r[VE];
+        unpack<T>(*(const i32x4*)(y + m * ldy + c), v);
+        if (res) unpack<T>(*(const i32x4*)(res + m * ldr + c), r);
+#pragma unroll
+        for (int i = 0; i < VE; ++i) {
+            float u = v[i] * scale[c + i] + shift[c + i];
+            if (act == 1) u = silu_f(u);
+            if (res) u += r[i];
+            v[i] = u;
+        }
+        *(i32x4*)(z + m * ldz + c) = pack<T>(v);
+    }
+}
+
+// ---------------------------------------------------------------- backward
+__device__ __forceinline__ float dsilu_f(float u) {
+    const float s = sigmoid_f(u);
+    return s * (1.0f + u * (1.0f - s));
+}
+
+// partial[block][2][K]: sum(du), sum(du*xhat) over this block's rows.  grid.x = row blocks, grid.y = column groups.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restrict__ dz, int lddz, const T* __restrict__ y, int ldy,
+                                                                const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                long long M, int K, int act, int rows_per_block, float* __restrict__ partial) {
+    constexpr int VE = VT<T>::VE;
+    __shared__ float red[2][256 * VE];
+    const int VCt = K / VE;
+    const int vc0 = blockIdx.y * 256;
+    const int VC = min(256, VCt - vc0);
+    const int RL = 256 / VC;
+    const int vc = threadIdx.x % VC, rl = threadIdx.x / VC;
+    const int c = (vc0 + vc) * VE;
+    float a1[VE], a2[VE], sc[VE], sh[VE], mu[VE], is[VE];
+#pragma unroll
+    for (int i = 0; i < VE; ++i) {
+        a1[i] = 0.f; a2[i] = 0.f;
+        sc[i] = scale[c + i]; sh[i] = shift[c + i]; mu[i] = mean[c + i]; is[i] = invstd[c + i];
+    }
+    const long long mbeg = (long long)blockIdx.x * rows_per_block;
+    const long long mend = min(mbeg + rows_per_block, M);
+    if (rl < RL) {
+        for (long long m = mbeg + rl; m < mend; m += RL) {
+            float g[VE], v[VE];
+            unpack<T>(*(const i32x4*)(dz + m * lddz + c), g);
+            unpack<T>(*(const i32x4*)(y + m * ldy + c), v);
+#pragma unroll
+            for (int i = 0; i < VE; ++i) {
+                float du = g[i];
+                if (act == 1) du *= dsilu_f(v[i] * sc[i] + sh[i]);
+                a1[i] += du;
+                a2[i] += du * ((v[i] - mu[i]) * is[i]);
+            }
+        }
+    }
+    // reduce over row lanes: thread (rl, vc) -> red[q][rl*VC*VE + vc*VE + i]
+    if (rl < RL) {
+#pragma unroll
+        for (int i = 0; i < VE; ++i) {
+            red[0][(rl * VC + vc) * VE + i] = a1[i];
+            red[1][(rl * VC + vc) * VE + i] = a2[i];
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < VC * VE; j += 256) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int r = 0; r < RL; ++r) {
+            s1 += red[0][r * VC * VE + j];
+            s2 += red[1][r * VC * VE + j];
+        }
+        partial[((size_t)blockIdx.x * 2 + 0) * K + vc0 * VE + j] = s1;
+        partial[((size_t)blockIdx.x * 2 + 1) * K + vc0 * VE + j] = s2;
+    }
+}
+
+// dbeta/dgamma (+)=, c1 = dbeta/M, c2 = dgamma/M
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblocks, int K, double count,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
+                                                               float* __restrict__ c1, float* __restrict__ c2) {
+    __shared__ double red[2][32][33];
+    const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
+    const int k = blockIdx.x * 32 + cl;
+    double s1 = 0.0, s2 = 0.0;
+    if (k < K) {
+        for (int t = tl; t < nblocks; t += 32) {
+            s1 += (double)partial[((size_t)t * 2 + 0) * K + k];
+            s2 += (double)partial[((size_t)t * 2 + 1) * K + k];
+        }
+    }
+    red[0][tl][cl] = s1;
+    red[1][tl][cl] = s2;
+    __syncthreads();
+    if (tl == 0 && k < K) {
+        s1 = 0.0; s2 = 0.0;
+        for (int t = 0; t < 32; ++t) { s1 += red[0][t][cl]; s2 += red[1][t][cl]; }
+        if (dbeta) dbeta[k] = accumulate ? dbeta[k] + (float)s1 : (float)s1;
+        if (dgamma) dgamma[k] = accumulate ? dgamma[k] + (float)s2 : (float)s2;
+        if (c1) c1[k] = (float)(s1 / count);
+        if (c2) c2[k] = (float)(s2 / count);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restrict__ dz, int lddz, const T* __restrict__ y, int ldy,
+                                                               const float* __restrict__ scale, const float* __restrict__ shift,
+                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                               const float* __restrict__ c1, const float* __restrict__ c2,
+                                                               T* __restrict__ dy, int lddy, long long M, int K, int act) {
+    constexpr int VE = VT<T>::VE;
+    const int VC = K / VE;
+    const long long total = M * VC;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const long long m = idx / VC;
+        const int c = (int)(idx - m * VC) * VE;
+        float g[VE], v[VE];
+        unpack<T>(*(const i32x4*)(dz + m * lddz + c), g);
+        unpack<T>(*(const i32x4*)(y + m * ldy + c), v);
+#pragma unroll
+        for (int i = 0; i < VE; ++i) {
+            const float sc = scale[c + i];
+            float du = g[i];
+            if (act == 1) du *= dsilu_f(v[i] * sc + shift[c + i]);
+            const float xh = (v[i] - mean[c + i]) * invstd[c + i];
+            g[i] = sc * (du - c1[c + i] - xh * c2[c + i]);
+        }
+        *(i32x4*)(dy + m * lddy + c) = pack<T>(g);
+    }
+}
+
+// out[m][c] (+)= a[m][c]  -- gradient accumulation between pitched NHWC views
+template <typename T>
+__global__ __launch_bounds__(256) void add_inplace_kernel(T* __restrict__ out, int ldo, const T* __restrict__ a, int lda, long long M, int K) {
+    constexpr int VE = VT<T>::VE;
+    const int VC = K / VE;
+    const long long total = M * VC;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const long long m = idx / VC;
+        const int c = (int)(idx - m * VC) * VE;
+        float o[VE], v[VE];
+        unpack<T>(*(const i32x4*)(out + m * ldo + c), o);
+        unpack<T>(*(const i32x4*)(a + m * lda + c), v);
+#pragma unroll
+        for (int i = 0; i < VE; ++i) o[i] += v[i];
+        *(i32x4*)(out + m * ldo + c) = pack<T>(o);
+    }
+}
+
+inline int stream_grid(long long total_vec) {
+    long long g = (total_vec + 255) / 256;
+    if (g > 256 * 16) g = 256 * 16;      // <= 16 workgroups per CU, grid-stride the rest
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+#define VEC_OK(ptr, ld, VE) ((((uintptr_t)(ptr)) & 15) == 0 && (ld) % (VE) == 0)
+
+extern "C" {
+
+int hdy_bn_finalize(const float* stats, int mtiles, int K, long long count, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, float eps, float momentum, float* scale, float* shift, float* save_mean, float* save_invstd,
+                    void* stream) {
+    HDY_ARG(stats && gamma && beta && scale && shift && save_mean && save_invstd, "bn_finalize: null pointer");
+    HDY_ARG(mtiles > 0 && K > 0 && count > 0, "bn_finalize: bad sizes");
+    HDY_ARG((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running_mean/var must both be given or both null");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(K, 32)), dim3(1024), 0, (hipStream_t)stream, stats, mtiles, K, (double)count, gamma,
+                       beta, running_mean, running_var, eps, momentum, scale, shift, save_mean, save_invstd);
+    HDY_LAUNCH_CHECK("bn_finalize");
+    return HDY_OK;
+}
+
+int hdy_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, int K,
+                       float* scale, float* shift, void* stream) {
+    HDY_ARG(gamma && beta && running_mean && running_var && scale && shift && K > 0, "bn_eval_coeffs: bad args");
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(cdiv(K, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta, running_mean,
+                       running_var, eps, K, scale, shift);
+    HDY_LAUNCH_CHECK("bn_eval_coeffs");
+    return HDY_OK;
+}
+
+int hdy_bn_act_fwd(const void* y, int ldy, const float* scale, const float* shift, const void* res, int ldr, void* z, int ldz,
+                   long long M, int K, int act, int dtype, void* stream) {
+    const int VE = dtype == HDY_BF16 ? 8 : 4;
+    HDY_ARG(y && z && scale && shift && M > 0 && K > 0, "bn_act_fwd: bad args");
+    HDY_ARG(K % VE == 0 && VEC_OK(y, ldy, VE) && VEC_OK(z, ldz, VE) && (!res || VEC_OK(res, ldr, VE)), "bn_act_fwd: K/pitch/alignment must be multiples of one 16-byte vector");
+    const int grid = stream_grid(M * (K / VE));
+    if (dtype == HDY_BF16)
+        hipLaunchKernelGGL(bn_act_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y, ldy, scale, shift,
+                           (const bf16_t*)res, ldr, (bf16_t*)z, ldz, M, K, act);
+    else
+        hipLaunchKernelGGL(bn_act_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)y, ldy, scale, shift,
+                           (const float*)res, ldr, (float*)z, ldz, M, K, act);
+    HDY_LAUNCH_CHECK("bn_act_fwd");
+    return HDY_OK;
+}
+
+// number of row blocks hdy_bn_act_bwd uses (size of the partial slab = blocks*2*K floats)
+int hdy_bn_bwd_blocks(long long M) {
+    long long b = (M + 255) / 256;
+    if (b > 1024) b = 1024;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// Full backward of z = act(BN_train(y)) [+ res]:  dy, and dgamma/dbeta (+)=.
+// workspace: (hdy_bn_bwd_blocks(M)*2*K + 2*K) floats.
+int hdy_bn_act_bwd(const void* dz, int lddz, const void* y, int ldy, const float* scale, const float* shift, const float* mean,
+                   const float* invstd, void* dy, int lddy, float* dgamma, float* dbeta, int accumulate, long long M, int K, int act,
+                   int dtype, float* workspace, void* stream) {
+    const int VE = dtype == HDY_BF16 ? 8 : 4;
+    HDY_ARG(dz && y && dy && scale && shift && mean && invstd && workspace && M > 0 && K > 0, "bn_act_bwd: bad args");
+    HDY_ARG(K % VE == 0 && VEC_OK(dz, lddz, VE) && VEC_OK(y, ldy, VE) && VEC_OK(dy, lddy, VE), "bn_act_bwd: K/pitch/alignment must be multiples of one 16-byte vector");
+    const int nb = hdy_bn_bwd_blocks(M);
+    const int rows = (int)((M + nb - 1) / nb);
+    float* partial = workspace;
+    float* c1 = workspace + (size_t)nb * 2 * K;
+    float* c2 = c1 + K;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(nb, cdiv(K / VE, 256));
+    if (dtype == HDY_BF16)
+        hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dz, lddz, (const bf16_t*)y, ldy, scale,
+                           shift, mean, invstd, M, K, act, rows, partial);
+    else
+        hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<float>, grid, dim3(256), 0, st, (const float*)dz, lddz, (const float*)y, ldy, scale,
+                           shift, mean, invstd, M, K, act, rows, partial);
+    HDY_LAUNCH_CHECK("bn_act_bwd_reduce");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(K, 32)), dim3(1024), 0, st, partial, nb, K, (double)M, dgamma, dbeta, accumulate, c1,
+                       c2);
+    HDY_LAUNCH_CHECK("bn_bwd_finalize");
+    const int g2 = stream_grid(M * (K / VE));
+    if (dtype == HDY_BF16)
+        hipLaunchKernelGGL(bn_act_bwd_apply_kernel<bf16_t>, dim3(g2), dim3(256), 0, st, (const bf16_t*)dz, lddz, (const bf16_t*)y, ldy, scale,
+                           shift, mean, invstd, c1, c2, (bf16_t*)dy, lddy, M, K, act);
+    else
+        hipLaunchKernelGGL(bn_act_bwd_apply_kernel<float>, dim3(g2), dim3(256), 0, st, (const float*)dz, lddz, (const float*)y, ldy, scale,
+                           shift, mean, invstd, c1, c2, (float*)dy, lddy, M, K, act);
+    HDY_LAUNCH_CHECK("bn_act_bwd_apply");
+    return HDY_OK;
+}
+
+int hdy_add_inplace(void* out, int ldo, const void* a, int lda, long long M, int K, int dtype, void* stream) {
+    const int VE = dtype == HDY_BF16 ? 8 : 4;
+    HDY_ARG(out && a && M > 0 && K > 0 && K % VE == 0 && VEC_OK(out, ldo, VE) && VEC_OK(a, lda, VE), "add_inplace: bad args");
+    const int grid = stream_grid(M * (K / VE));
+    if (dtype == HDY_BF16)
+        hipLaunchKernelGGL(add_inplace_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (bf16_t*)out, ldo, (const bf16_t*)a, lda, M, K);
+    else
+        hipLaunchKernelGGL(add_inplace_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (float*)out, ldo, (const float*)a, lda, M, K);
+    HDY_LAUNCH_CHECK("add_inplace");
+    return HDY_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,67 @@
+// hd_yolo_amd — shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#define HDY_OK 0
+#define HDY_EINVAL (-1)
+#define HDY_EUNSUPPORTED (-2)
+
+enum { HDY_F32 = 0, HDY_BF16 = 1 };
+
+// thread-local error text, returned by hdy_last_error()
+void hdy_set_error(const char* fmt, ...);
+
+#define HDY_ARG(cond, ...)                 \
+    do {                                   \
+        if (!(cond)) {                     \
+            hdy_set_error(__VA_ARGS__);    \
+            return HDY_EINVAL;             \
+        }                                  \
+    } while (0)
+
+#define HDY_LAUNCH_CHECK(what)                                                       \
+    do {                                                                             \
+        hipError_t e__ = hipGetLastError();                                          \
+        if (e__ != hipSuccess) {                                                     \
+            hdy_set_error("%s: launch failed: %s", what, hipGetErrorString(e__));    \
+            return (int)e__;                                                         \
+        }                                                                            \
+    } while (0)
+
+typedef __bf16 bf16_t;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+#ifdef __HIPCC__
+// 16-byte vector <-> 8 bf16 / 4 f32 views
+union V16 {
+    i32x4 i;
+    f32x4 f;
+    bf16x8 h;
+};
+
+__device__ __forceinline__ float silu_f(float u) { return u / (1.0f + __expf(-u)); }
+__device__ __forceinline__ float sigmoid_f(float u) { return 1.0f / (1.0f + __expf(-u)); }
+
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+// Bijective XCD-aware remap of a 1-D grid (cdna_hip_programming.md §5.5 T1): blocks that the
+// dispatcher deals to one XCD (same id % 8) get a contiguous range of logical tile ids, so
+// neighbouring tiles share that XCD's L2.  Speed only; any mapping is correct.
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+    const int q = n >> 3, r = n & 7, x = id & 7, s = id >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + s;
+}
+#endif

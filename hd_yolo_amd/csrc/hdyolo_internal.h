@@ -1,0 +1,38 @@
+// Internal (not part of the C ABI): argument blocks shared between api.hip and the kernel files.
+#pragma once
+#include "common.h"
+
+struct ConvArgs {
+    const void* x;        // [N][Hin][Win][ldx]
+    const void* w;        // packed [Kpad][Kdp]
+    void* y;              // [N][Hout][Wout][ldy]
+    const float* scale;   // per-channel epilogue scale (or null = 1)
+    const float* shift;   // per-channel epilogue shift / bias (or null = 0)
+    float* stats;         // [mtiles][2][K] BatchNorm partial sums (or null)
+    int N, Hin, Win, C, ldx;
+    int Ho, Wo, K, ldy;
+    int Hout, Wout, oh_mul, oh_off, ow_mul, ow_off;
+    int ih_mul, iw_mul, dh0, dw0, TH, TW;
+    int Kd, Kdp, M;
+    int act, accumulate, dense_out;
+    int mtiles, ntiles, bn;
+    int span_pixels;      // 1: the C-wide read deliberately spans several ldx-pitched pixels (stem)
+};
+
+struct WgradArgs {
+    const void* x;        // [N][Hin][Win][ldx]
+    const void* dy;       // [N][Ho][Wo][lddy]
+    float* partial;       // [splits][K][Q]   Q = TH*TW*C
+    int N, Hin, Win, C, ldx;
+    int Ho, Wo, K, lddy;
+    int ih_mul, iw_mul, dh0, dw0, TH, TW;
+    int Q, P;             // Q = taps*C, P = N*Ho*Wo pixels
+    int splits, pix_per_split;
+    int ktiles, qtiles;
+    int span_pixels;
+};
+
+int hdy_conv_bn_tile(int K);
+int hdy_conv_igemm_launch(ConvArgs a, int dtype, int out_f32, hipStream_t st);
+int hdy_wgrad_launch(WgradArgs a, int dtype, hipStream_t st);
+int hdy_wgrad_plan(int K, int Q, long long P, int dtype, int* splits, int* pix_per_split);

@@ -1,0 +1,314 @@
+// SPPF triple max-pool (forward with argmax, backward), 2x nearest upsample (forward/backward) and the
+// layout kernels at the framework boundary (NCHW fp32 images -> NHWC tiles), gfx950.  All HBM/LDS-bound; no MFMA.
+//
+// Reference semantics replaced: nn.MaxPool2d(5,1,2) x3 + torch.cat in SPPF.forward
+// (metayolo/models/layers.py:181-189), nn.Upsample(None, 2, 'nearest') (hub yaml `fpn` rows), and the
+// host-side `torch.stack(imgs).to(device)` hand-off (train.py:432).
+#include "common.h"
+
+namespace {
+
+constexpr int CG = 8;   // channels per workgroup in the SPPF kernels
+
+// One workgroup owns the whole H x W plane of CG channels of one image in LDS and produces the three chained
+// 5x5/s1/p2 max-pools (= 5x5, 9x9, 13x13 windows) in one launch.  Ties resolve to the first maximum in
+// row-major window order, as ATen's max_pool2d does; idx stores that window position (0..24) for backward.
+template <typename T>
+__global__ __launch_bounds__(256) void sppf_pool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y1, T* __restrict__ y2, T* __restrict__ y3,
+                                                            int ld, unsigned char* __restrict__ i1, unsigned char* __restrict__ i2,
+                                                            unsigned char* __restrict__ i3, int H, int W, int C) {
+    extern __shared__ float pl[];          // [2][H*W][CG]
+    const int HW = H * W;
+    float* a = pl;
+    float* b = pl + HW * CG;
+    const int cgs = C / CG;
+    const int n = blockIdx.x / cgs, c0 = (blockIdx.x - n * cgs) * CG;
+    const size_t base = (size_t)n * HW;
+    for (int e = threadIdx.x; e < HW * CG; e += blockDim.x) {
+        const int pix = e / CG, ch = e - pix * CG;
+        a[e] = to_f32<T>(x[(base + pix) * ld + c0 + ch]);
+    }
+    __syncthreads();
+    T* outs[3] = {y1, y2, y3};
+    unsigned char* idxs[3] = {i1, i2, i3};
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass) {
+        for (int e = threadIdx.x; e < HW * CG; e += blockDim.x) {
+            const int pix = e / CG, ch = e - pix * CG;
+            const int h = pix / W, w = pix - h * W;
+            float best = -INFINITY;
+            int bi = 0;
+            for (int dy = 0; dy < 5; ++dy) {
+                const int hh = h + dy - 2;
+                if (hh < 0 || hh >= H) continue;
+                for (int dx = 0; dx < 5; ++dx) {
+                    const int ww = w + dx - 2;
+                    if (ww < 0 || ww >= W) continue;
+                    const float v = a[(hh * W + ww) * CG + ch];
+                    if (v > best || v != v) { best = v; bi = dy * 5 + dx; }
+                }
+            }
+            b[e] = best;
+            outs[pass][(base + pix) * ld + c0 + ch] = from_f32<T>(best);
+            if (idxs[pass]) idxs[pass][(base + pix) * C + c0 + ch] = (unsigned char)bi;
+        }
+        __syncthreads();
+        float* t = a; a = b; b = t;
+    }
+}
+
+// dx = g0 + P1^T( g1 + P2^T( g2 + P3^T g3 ) ), P^T = scatter-to-argmax written as a gather (deterministic).
+template <typename T>
+__global__ __launch_bounds__(256) void sppf_pool_bwd_kernel(const T* __restrict__ g0, const T* __restrict__ g1, const T* __restrict__ g2,
+                                                            const T* __restrict__ g3, int ldg, const unsigned char* __restrict__ i1,
+                                                            const unsigned char* __restrict__ i2, const unsigned char* __restrict__ i3,
+                                                            T* __restrict__ dx, int lddx, int H, int W, int C) {
+    extern __shared__ float pl[];          // [2][H*W][CG] floats + [H*W][CG] bytes
+    const int HW = H * W;
+    float* a = pl;
+    float* b = pl + HW * CG;
+    unsigned char* ix = (unsigned char*)(pl + 2 * HW * CG);
+    const int cgs = C / CG;
+    const int n = blockIdx.x / cgs, c0 = (blockIdx.x - n * cgs) * CG;
+    const size_t base = (size_t)n * HW;
+    const T* gs[3] = {g2, g1, g0};
+    const unsigned char* idxs[3] = {i3, i2, i1};
+    for (int e = threadIdx.x; e < HW * CG; e += blockDim.x) {
+        const int pix = e / CG, ch = e - pix * CG;
+        a[e] = to_f32<T>(g3[(base + pix) * ldg + c0 + ch]);
+    }
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass) {
+        for (int e = threadIdx.x; e < HW * CG; e += blockDim.x) {
+            const int pix = e / CG, ch = e - pix * CG;
+            ix[e] = idxs[pass][(base + pix) * C + c0 + ch];
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < HW * CG; e += blockDim.x) {
+            const int pix = e / CG, ch = e - pix * CG;
+            const int h = pix / W, w = pix - h * W;
+            float s = to_f32<T>(gs[pass][(base + pix) * ldg + c0 + ch]);
+            for (int ey = -2; ey <= 2; ++ey) {
+                const int qh = h - ey;
+                if (qh < 0 || qh >= H) continue;
+                for (int ex = -2; ex <= 2; ++ex) {
+                    const int qw = w - ex;
+                    if (qw < 0 || qw >= W) continue;
+                    const int q = (qh * W + qw) * CG + ch;
+                    if (ix[q] == (ey + 2) * 5 + (ex + 2)) s += a[q];
+                }
+            }
+            b[e] = s;
+        }
+        __syncthreads();
+        float* t = a; a = b; b = t;
+    }
+    for (int e = threadIdx.x; e < HW * CG; e += blockDim.x) {
+        const int pix = e / CG, ch = e - pix * CG;
+        dx[(base + pix) * lddx + c0 + ch] = from_f32<T>(a[e]);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int N, int H, int W,
+                                                             int C) {
+    constexpr int VE = 16 / sizeof(T);
+    const int VC = C / VE;
+    const long long total = (long long)N * 4 * H * W * VC;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const long long op = idx / VC;
+        const int c = (int)(idx - op * VC) * VE;
+        const int ow = (int)(op % (2 * W));
+        const long long t = op / (2 * W);
+        const int oh = (int)(t % (2 * H));
+        const int n = (int)(t / (2 * H));
+        const size_t ip = ((size_t)n * H + (oh >> 1)) * W + (ow >> 1);
+        *(i32x4*)(y + (size_t)op * ldy + c) = *(const i32x4*)(x + ip * ldx + c);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* __restrict__ dy, int lddy, T* __restrict__ dx, int lddx, int N, int H,
+                                                             int W, int C, int accumulate) {
+    constexpr int VE = 16 / sizeof(T);
+    const int VC = C / VE;
+    const long long total = (long long)N * H * W * VC;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const long long ip = idx / VC;
+        const int c = (int)(idx - ip * VC) * VE;
+        const int w = (int)(ip % W);
+        const long long t = ip / W;
+        const int h = (int)(t % H);
+        const int n = (int)(t / H);
+        float s[VE];
+#pragma unroll
+        for (int i = 0; i < VE; ++i) s[i] = 0.f;
+        if (accumulate) {
+            V16 u; u.i = *(const i32x4*)(dx + (size_t)ip * lddx + c);
+#pragma unroll
+            for (int i = 0; i < VE; ++i) s[i] = sizeof(T) == 2 ? (float)u.h[i] : u.f[i & 3];
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const size_t op = ((size_t)n * 2 * H + 2 * h + a) * 2 * W + 2 * w + b;
+                V16 u; u.i = *(const i32x4*)(dy + op * lddy + c);
+#pragma unroll
+                for (int i = 0; i < VE; ++i) s[i] += sizeof(T) == 2 ? (float)u.h[i] : u.f[i & 3];
+            }
+        V16 o;
+#pragma unroll
+        for (int i = 0; i < VE; ++i) {
+            if (sizeof(T) == 2) o.h[i] = (bf16_t)s[i];
+            else o.f[i & 3] = s[i];
+        }
+        *(i32x4*)(dx + (size_t)ip * lddx + c) = o.i;
+    }
+}
+
+// images [B][3][H][W] fp32 (NCHW) -> [B][H+2*pad][W+2*pad][4] of T, zero border and zero 4th channel: the
+// layout the stem's 6-row-tap conv reads (24 contiguous pseudo-channels = 6 pixels x 4).
+template <typename T>
+__global__ __launch_bounds__(256) void stem_prep_kernel(const float* __restrict__ img, T* __restrict__ out, int B, int H, int W, int pad) {
+    const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+    const long long total = (long long)B * Hp * Wp;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int wp = (int)(idx % Wp);
+        const long long t = idx / Wp;
+        const int hp = (int)(t % Hp);
+        const int b = (int)(t / Hp);
+        const int h = hp - pad, w = wp - pad;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (h >= 0 && h < H && w >= 0 && w < W) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[c] = img[(((size_t)b * 3 + c) * H + h) * W + w];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) out[(size_t)idx * 4 + c] = from_f32<T>(v[c]);
+    }
+}
+
+// generic NCHW fp32 -> NHWC T (pitched); tiled through LDS so both sides are coalesced
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int ldd, int C, int HW) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, p = p0 + tx;
+        tile[i][tx] = (c < C && p < HW) ? src[((size_t)n * C + c) * HW + p] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int p = p0 + i, c = c0 + tx;
+        if (p < HW && c < C) dst[((size_t)n * HW + p) * ldd + c] = from_f32<T>(tile[tx][i]);
+    }
+}
+
+inline int sgrid(long long total) {
+    long long g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hdy_sppf_pool_fwd(const void* x, void* y1, void* y2, void* y3, int ld, unsigned char* idx1, unsigned char* idx2, unsigned char* idx3,
+                      int N, int H, int W, int C, int dtype, void* stream) {
+    HDY_ARG(x && y1 && y2 && y3 && N > 0 && H > 0 && W > 0 && C > 0, "sppf_pool_fwd: bad args");
+    HDY_ARG(C % CG == 0 && ld >= C, "sppf_pool_fwd: C=%d must be a multiple of %d and ld >= C", C, CG);
+    HDY_ARG((idx1 == nullptr) == (idx2 == nullptr) && (idx1 == nullptr) == (idx3 == nullptr), "sppf_pool_fwd: idx buffers all or none");
+    const size_t smem = (size_t)2 * H * W * CG * sizeof(float);
+    HDY_ARG(smem <= 150 * 1024, "sppf_pool_fwd: plane %dx%d does not fit LDS", H, W);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == HDY_BF16) {
+        (void)hipFuncSetAttribute((const void*)sppf_pool_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        hipLaunchKernelGGL(sppf_pool_fwd_kernel<bf16_t>, dim3(N * (C / CG)), dim3(256), smem, st, (const bf16_t*)x, (bf16_t*)y1, (bf16_t*)y2,
+                           (bf16_t*)y3, ld, idx1, idx2, idx3, H, W, C);
+    } else {
+        (void)hipFuncSetAttribute((const void*)sppf_pool_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        hipLaunchKernelGGL(sppf_pool_fwd_kernel<float>, dim3(N * (C / CG)), dim3(256), smem, st, (const float*)x, (float*)y1, (float*)y2,
+                           (float*)y3, ld, idx1, idx2, idx3, H, W, C);
+    }
+    HDY_LAUNCH_CHECK("sppf_pool_fwd");
+    return HDY_OK;
+}
+
+int hdy_sppf_pool_bwd(const void* g0, const void* g1, const void* g2, const void* g3, int ldg, const unsigned char* idx1,
+                      const unsigned char* idx2, const unsigned char* idx3, void* dx, int lddx, int N, int H, int W, int C, int dtype,
+                      void* stream) {
+    HDY_ARG(g0 && g1 && g2 && g3 && idx1 && idx2 && idx3 && dx && N > 0 && H > 0 && W > 0, "sppf_pool_bwd: bad args");
+    HDY_ARG(C % CG == 0 && ldg >= C && lddx >= C, "sppf_pool_bwd: bad channel count / pitch");
+    const size_t smem = (size_t)2 * H * W * CG * sizeof(float) + (size_t)H * W * CG;
+    HDY_ARG(smem <= 150 * 1024, "sppf_pool_bwd: plane %dx%d does not fit LDS", H, W);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == HDY_BF16) {
+        (void)hipFuncSetAttribute((const void*)sppf_pool_bwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        hipLaunchKernelGGL(sppf_pool_bwd_kernel<bf16_t>, dim3(N * (C / CG)), dim3(256), smem, st, (const bf16_t*)g0, (const bf16_t*)g1,
+                           (const bf16_t*)g2, (const bf16_t*)g3, ldg, idx1, idx2, idx3, (bf16_t*)dx, lddx, H, W, C);
+    } else {
+        (void)hipFuncSetAttribute((const void*)sppf_pool_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        hipLaunchKernelGGL(sppf_pool_bwd_kernel<float>, dim3(N * (C / CG)), dim3(256), smem, st, (const float*)g0, (const float*)g1,
+                           (const float*)g2, (const float*)g3, ldg, idx1, idx2, idx3, (float*)dx, lddx, H, W, C);
+    }
+    HDY_LAUNCH_CHECK("sppf_pool_bwd");
+    return HDY_OK;
+}
+
+int hdy_upsample2x_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, int dtype, void* stream) {
+    const int VE = dtype == HDY_BF16 ? 8 : 4;
+    HDY_ARG(x && y && N > 0 && H > 0 && W > 0 && C > 0 && C % VE == 0 && ldx % VE == 0 && ldy % VE == 0 && ldx >= C && ldy >= C,
+            "upsample2x_fwd: bad args");
+    HDY_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, "upsample2x_fwd: 16-byte alignment");
+    const int grid = sgrid((long long)N * 4 * H * W * (C / VE));
+    if (dtype == HDY_BF16)
+        hipLaunchKernelGGL(upsample2x_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, N, H, W, C);
+    else
+        hipLaunchKernelGGL(upsample2x_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, (float*)y, ldy, N, H, W, C);
+    HDY_LAUNCH_CHECK("upsample2x_fwd");
+    return HDY_OK;
+}
+
+int hdy_upsample2x_bwd(const void* dy, int lddy, void* dx, int lddx, int N, int H, int W, int C, int accumulate, int dtype, void* stream) {
+    const int VE = dtype == HDY_BF16 ? 8 : 4;
+    HDY_ARG(dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && C % VE == 0 && lddx % VE == 0 && lddy % VE == 0 && lddx >= C && lddy >= C,
+            "upsample2x_bwd: bad args");
+    HDY_ARG(((uintptr_t)dx & 15) == 0 && ((uintptr_t)dy & 15) == 0, "upsample2x_bwd: 16-byte alignment");
+    const int grid = sgrid((long long)N * H * W * (C / VE));
+    if (dtype == HDY_BF16)
+        hipLaunchKernelGGL(upsample2x_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, N, H, W, C, accumulate);
+    else
+        hipLaunchKernelGGL(upsample2x_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)dy, lddy, (float*)dx, lddx, N, H, W, C, accumulate);
+    HDY_LAUNCH_CHECK("upsample2x_bwd");
+    return HDY_OK;
+}
+
+int hdy_stem_prep(const float* img, void* out, int B, int H, int W, int pad, int dtype, void* stream) {
+    HDY_ARG(img && out && B > 0 && H > 0 && W > 0 && pad >= 0, "stem_prep: bad args");
+    const int grid = sgrid((long long)B * (H + 2 * pad) * (W + 2 * pad));
+    if (dtype == HDY_BF16)
+        hipLaunchKernelGGL(stem_prep_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, img, (bf16_t*)out, B, H, W, pad);
+    else
+        hipLaunchKernelGGL(stem_prep_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, img, (float*)out, B, H, W, pad);
+    HDY_LAUNCH_CHECK("stem_prep");
+    return HDY_OK;
+}
+
+int hdy_nchw_to_nhwc(const float* src, void* dst, int ldd, int N, int C, int H, int W, int dtype, void* stream) {
+    HDY_ARG(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && ldd >= C, "nchw_to_nhwc: bad args");
+    const int HW = H * W;
+    dim3 grid(cdiv(HW, 32), cdiv(C, 32), N);
+    HDY_ARG(grid.y <= 65535 && grid.z <= 65535, "nchw_to_nhwc: grid too large");
+    if (dtype == HDY_BF16)
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, ldd, C, HW);
+    else
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, src, (float*)dst, ldd, C, HW);
+    HDY_LAUNCH_CHECK("nchw_to_nhwc");
+    return HDY_OK;
+}
+
+}  // extern "C"

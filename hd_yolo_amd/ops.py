@@ -1,0 +1,252 @@
+"""Tensor-level wrappers over the C ABI (include/hdyolo.h).
+
+torch is used here for device memory and streams only: every function takes NHWC device tensors
+(shape [N, H, W, C], possibly a channel-slice view of a wider buffer), checks that they are laid out the
+way the kernels assume, and builds a *launch record* `(symbol, args)` whose pointer arguments are raw
+device addresses.  Records are either executed at once (`run`) or stored in a static plan
+(hd_yolo_amd/plan.py) and replayed every step with no further Python-side work.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ACT_NONE, ACT_SILU, BF16, F32, PACK_DGRAD, PACK_FWD, PACK_STEM  # noqa: F401
+
+BN_EPS, BN_MOMENTUM = 1e-3, 0.03     # metayolo/models/utils_torch.py:47-49
+
+
+def _rec(scope, name, args):
+    """launch record = (symbol, args, tensors kept alive while the record exists)"""
+    return (name, args, tuple(v for v in scope.values() if isinstance(v, torch.Tensor)) +
+            tuple(t for v in scope.values() if isinstance(v, (list, tuple)) for t in v if isinstance(t, torch.Tensor)))
+
+
+def dcode(dtype):
+    if dtype == torch.float32:
+        return F32
+    if dtype == torch.bfloat16:
+        return BF16
+    raise _lib.HdyError(f'unsupported arithmetic type {dtype}: use torch.float32 or torch.bfloat16')
+
+
+def require_gpu(t):
+    if not t.is_cuda:
+        raise _lib.HdyError('hd_yolo_amd runs on MI355X only: tensor is on CPU and there is no CPU fallback '
+                            '(the CPU oracle under oracle/ is test infrastructure)')
+
+
+def nhwc(t):
+    """(ptr, N, H, W, C, pitch) of an NHWC tensor or channel-slice view."""
+    require_gpu(t)
+    assert t.dim() == 4 and (t.shape[3] == 1 or t.stride(3) == 1), f'not NHWC-contiguous in C: {t.shape} {t.stride()}'
+    n, h, w, c = t.shape
+    ld = t.stride(2)
+    assert ld >= c and (h == 1 or t.stride(1) == w * ld) and (n == 1 or t.stride(0) == h * w * ld), \
+        f'pixel pitch is not uniform: {t.shape} {t.stride()}'
+    return t.data_ptr(), n, h, w, c, ld
+
+
+def ptr(t):
+    if t is None:
+        return None
+    require_gpu(t)
+    return t.data_ptr()
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def run(records, stream=None):
+    """Execute launch records on `stream` (default: torch's current HIP stream)."""
+    lib = _lib.load()
+    s = stream_ptr() if stream is None else stream
+    for rec in records:
+        name, args = rec[0], rec[1]
+        rc = getattr(lib, name)(*args, s)
+        if rc != 0:
+            raise _lib.HdyError(f'{name} failed (status {rc}): {lib.hdy_last_error().decode()}')
+
+
+# ------------------------------------------------------------------------------------------ convolution
+def out_dim(n, k, s, p):
+    return (n + 2 * p - k) // s + 1
+
+
+def pack_alloc(K, C, R, S, stride, pad, kind, dtype, device):
+    n = _lib.query('hdy_conv_pack_elems', K, C, R, S, stride, pad, kind, dcode(dtype))
+    return torch.empty(n, dtype=dtype, device=device)
+
+
+def rec_pack(w_a, w_b, stride, pad, kind, out):
+    """Pack framework weights [K,C,R,S] fp32 (optionally two stacked along K) into `out`."""
+    K_a, C, R, S = w_a.shape
+    K_b = 0 if w_b is None else w_b.shape[0]
+    assert w_a.is_contiguous() and w_a.dtype == torch.float32 and (w_b is None or (w_b.is_contiguous() and w_b.shape[1:] == w_a.shape[1:]))
+    return _rec(locals(), 'hdy_conv_pack', (ptr(w_a), K_a, ptr(w_b), K_b, C, R, S, stride, pad, kind, dcode(out.dtype), ptr(out)))
+
+
+def rec_conv_fwd(x, wp, y, K, R, S, stride, pad, scale=None, shift=None, stats=None, act=ACT_NONE, accumulate=False,
+                 stem_hw=None):
+    """y = act(scale*conv(x)+shift).  For the stem, x is the hdy_stem_prep buffer and stem_hw = (H, W) of the image."""
+    xp, N, H, W, C, ldx = nhwc(x)
+    yp, _, Ho, Wo, Ky, ldy = nhwc(y)
+    stem = 0
+    if stem_hw is not None:
+        stem, (H, W), C = 1, stem_hw, 3
+    assert Ky == K and Ho == out_dim(H, R, stride, pad) and Wo == out_dim(W, S, stride, pad), (y.shape, K, Ho, Wo)
+    out_f32 = 1 if (y.dtype == torch.float32 and x.dtype == torch.bfloat16) else 0
+    assert y.dtype == x.dtype or out_f32
+    return _rec(locals(), 'hdy_conv_fwd', (xp, ldx, ptr(wp), ptr(scale), ptr(shift), yp, ldy, ptr(stats), N, H, W, C, K, R, S, stride, pad, act,
+                             int(accumulate), dcode(x.dtype), out_f32, stem))
+
+
+def rec_conv_dgrad(dy, wp_d, dx, R, S, stride, pad, accumulate=False):
+    dyp, N, Ho, Wo, K, lddy = nhwc(dy)
+    dxp, _, H, W, C, lddx = nhwc(dx)
+    assert Ho == out_dim(H, R, stride, pad) and Wo == out_dim(W, S, stride, pad) and dy.dtype == dx.dtype
+    return _rec(locals(), 'hdy_conv_dgrad', (dyp, lddy, ptr(wp_d), dxp, lddx, N, H, W, C, K, R, S, stride, pad, int(accumulate), dcode(dy.dtype)))
+
+
+def wgrad_ws_bytes(N, H, W, C, K, R, S, stride, pad, dtype, stem=False):
+    return _lib.query('hdy_conv_wgrad_workspace_bytes', N, H, W, C, K, R, S, stride, pad, dcode(dtype), int(stem))
+
+
+def rec_conv_wgrad(x, dy, grad_a, grad_b, R, S, stride, pad, ws, accumulate=False, stem_hw=None):
+    xp, N, H, W, C, ldx = nhwc(x)
+    dyp, _, Ho, Wo, K, lddy = nhwc(dy)
+    stem = 0
+    if stem_hw is not None:
+        stem, (H, W), C = 1, stem_hw, 3
+    K_a = grad_a.shape[0]
+    K_b = 0 if grad_b is None else grad_b.shape[0]
+    assert grad_a.is_contiguous() and grad_a.dtype == torch.float32 and tuple(grad_a.shape[1:]) == (C, R, S)
+    return _rec(locals(), 'hdy_conv_wgrad', (xp, ldx, dyp, lddy, N, H, W, C, K, R, S, stride, pad, ptr(grad_a), K_a, ptr(grad_b), K_b, int(accumulate),
+                               ptr(ws), ws.numel() * ws.element_size(), dcode(x.dtype), stem))
+
+
+# ------------------------------------------------------------------------------------------ BN / act
+def rec_bn_finalize(stats, mtiles, K, count, gamma, beta, rmean, rvar, scale, shift, save_mean, save_invstd,
+                    eps=BN_EPS, momentum=BN_MOMENTUM):
+    return _rec(locals(), 'hdy_bn_finalize', (ptr(stats), mtiles, K, count, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), eps, momentum, ptr(scale),
+                                ptr(shift), ptr(save_mean), ptr(save_invstd)))
+
+
+def rec_bn_eval_coeffs(gamma, beta, rmean, rvar, scale, shift, eps=BN_EPS):
+    return _rec(locals(), 'hdy_bn_eval_coeffs', (ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), eps, gamma.numel(), ptr(scale), ptr(shift)))
+
+
+def rec_bn_act_fwd(y, scale, shift, z, res=None, act=ACT_SILU):
+    yp, N, H, W, K, ldy = nhwc(y)
+    zp, _, _, _, Kz, ldz = nhwc(z)
+    assert Kz == K and z.shape == y.shape and z.dtype == y.dtype
+    rp, ldr = None, 0
+    if res is not None:
+        rp, _, _, _, Kr, ldr = nhwc(res)
+        assert Kr == K and res.dtype == y.dtype
+    return _rec(locals(), 'hdy_bn_act_fwd', (yp, ldy, ptr(scale), ptr(shift), rp, ldr, zp, ldz, N * H * W, K, act, dcode(y.dtype)))
+
+
+def bn_bwd_ws_floats(M, K):
+    return _lib.query('hdy_bn_bwd_blocks', M) * 2 * K + 2 * K
+
+
+def rec_bn_act_bwd(dz, y, scale, shift, mean, invstd, dy, dgamma, dbeta, ws, accumulate=False, act=ACT_SILU):
+    dzp, N, H, W, K, lddz = nhwc(dz)
+    yp, _, _, _, _, ldy = nhwc(y)
+    dyp, _, _, _, _, lddy = nhwc(dy)
+    assert dz.shape == y.shape == dy.shape and dz.dtype == y.dtype == dy.dtype and ws.numel() >= bn_bwd_ws_floats(N * H * W, K)
+    return _rec(locals(), 'hdy_bn_act_bwd', (dzp, lddz, yp, ldy, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), dyp, lddy, ptr(dgamma), ptr(dbeta),
+                               int(accumulate), N * H * W, K, act, dcode(dz.dtype), ptr(ws)))
+
+
+def rec_add_inplace(out, a):
+    op, N, H, W, K, ldo = nhwc(out)
+    ap, _, _, _, _, lda = nhwc(a)
+    assert out.shape == a.shape and out.dtype == a.dtype
+    return _rec(locals(), 'hdy_add_inplace', (op, ldo, ap, lda, N * H * W, K, dcode(out.dtype)))
+
+
+# ------------------------------------------------------------------------------------------ pool / upsample / layout
+def rec_sppf_pool_fwd(x, y1, y2, y3, idx=None):
+    xp, N, H, W, C, ld = nhwc(x)
+    for t in (y1, y2, y3):
+        assert nhwc(t)[5] == ld and t.shape == x.shape
+    i1, i2, i3 = (None, None, None) if idx is None else idx
+    return _rec(locals(), 'hdy_sppf_pool_fwd', (xp, ptr(y1), ptr(y2), ptr(y3), ld, ptr(i1), ptr(i2), ptr(i3), N, H, W, C, dcode(x.dtype)))
+
+
+def rec_sppf_pool_bwd(g0, g1, g2, g3, idx, dx):
+    gp, N, H, W, C, ldg = nhwc(g0)
+    for t in (g1, g2, g3):
+        assert nhwc(t)[5] == ldg and t.shape == g0.shape
+    dxp, _, _, _, _, lddx = nhwc(dx)
+    return _rec(locals(), 'hdy_sppf_pool_bwd', (gp, ptr(g1), ptr(g2), ptr(g3), ldg, ptr(idx[0]), ptr(idx[1]), ptr(idx[2]), dxp, lddx, N, H, W, C,
+                                  dcode(g0.dtype)))
+
+
+def rec_upsample_fwd(x, y):
+    xp, N, H, W, C, ldx = nhwc(x)
+    yp, _, H2, W2, _, ldy = nhwc(y)
+    assert H2 == 2 * H and W2 == 2 * W and y.shape[3] == C
+    return _rec(locals(), 'hdy_upsample2x_fwd', (xp, ldx, yp, ldy, N, H, W, C, dcode(x.dtype)))
+
+
+def rec_upsample_bwd(dy, dx, accumulate=False):
+    dxp, N, H, W, C, lddx = nhwc(dx)
+    dyp, _, H2, W2, _, lddy = nhwc(dy)
+    assert H2 == 2 * H and W2 == 2 * W
+    return _rec(locals(), 'hdy_upsample2x_bwd', (dyp, lddy, dxp, lddx, N, H, W, C, int(accumulate), dcode(dx.dtype)))
+
+
+def rec_stem_prep(img, out, pad=2):
+    require_gpu(img)
+    B, C, H, W = img.shape
+    assert C == 3 and img.dtype == torch.float32 and img.is_contiguous()
+    assert tuple(out.shape) == (B, H + 2 * pad, W + 2 * pad, 4) and out.is_contiguous()
+    return _rec(locals(), 'hdy_stem_prep', (img.data_ptr(), out.data_ptr(), B, H, W, pad, dcode(out.dtype)))
+
+
+def rec_nchw_to_nhwc(src, dst):
+    require_gpu(src)
+    N, C, H, W = src.shape
+    assert src.dtype == torch.float32 and src.is_contiguous()
+    dp, _, _, _, Cd, ldd = nhwc(dst)
+    assert Cd == C
+    return _rec(locals(), 'hdy_nchw_to_nhwc', (src.data_ptr(), dp, ldd, N, C, H, W, dcode(dst.dtype)))
+
+
+# ------------------------------------------------------------------------------------------ detection head
+def decode_level(det, anchor_px, stride, out, row_offset, level_id):
+    """det: fp32 logits viewed as (B, na, ny, nx, no) with o contiguous (any other strides)."""
+    require_gpu(det)
+    B, na, ny, nx, no = det.shape
+    assert det.dtype == torch.float32 and det.stride(4) == 1 and out.dtype == torch.float32 and out.is_contiguous()
+    assert out.shape[0] == B and out.shape[2] == no + 1
+    anc = (ctypes.c_float * (2 * na))(*[float(v) for v in anchor_px])
+    _lib.call('hdy_decode', det.data_ptr(), det.stride(0), det.stride(1), det.stride(2), det.stride(3),
+              ctypes.cast(anc, ctypes.c_void_p), float(stride), out.data_ptr(), row_offset, out.shape[1], level_id, B, na, ny, nx, no,
+              stream_ptr())
+
+
+def nms_batched(preds, nc, conf_thres, iou_thres, max_det, min_wh=2.0, class_aware=False):
+    """preds (B, N, 5+nc+extra) fp32 on the GPU -> dict of device tensors, everything padded to max_det."""
+    require_gpu(preds)
+    assert preds.dtype == torch.float32 and preds.is_contiguous() and preds.dim() == 3
+    B, N, row = preds.shape
+    dev = preds.device
+    nex = row - 5 - nc
+    keep = torch.empty((B, max_det), dtype=torch.int64, device=dev)
+    n_keep = torch.empty((B,), dtype=torch.int32, device=dev)
+    boxes = torch.empty((B, max_det, 4), dtype=torch.float32, device=dev)
+    scores = torch.empty((B, max_det, 1 + nc), dtype=torch.float32, device=dev)
+    extra = torch.empty((B, max_det, max(nex, 1)), dtype=torch.float32, device=dev)
+    conf = torch.empty((B, max_det), dtype=torch.float32, device=dev)
+    cls = torch.empty((B, max_det), dtype=torch.int32, device=dev)
+    wsb = _lib.query('hdy_nms_workspace_bytes', B, N)
+    ws = torch.empty((max(wsb, 8) // 8,), dtype=torch.int64, device=dev)
+    _lib.call('hdy_nms_batched', preds.data_ptr(), B, N, row, nc, float(conf_thres), float(iou_thres), int(max_det), float(min_wh),
+              int(class_aware), keep.data_ptr(), n_keep.data_ptr(), boxes.data_ptr(), scores.data_ptr(),
+              extra.data_ptr() if nex > 0 else None, conf.data_ptr(), cls.data_ptr(), ws.data_ptr(), ws.numel() * 8, stream_ptr())
+    return {'keep': keep, 'n_keep': n_keep, 'boxes': boxes, 'scores': scores, 'extra': extra[:, :, :nex], 'conf': conf, 'cls': cls}

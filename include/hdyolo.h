@@ -1,0 +1,128 @@
+/* hdyolo.h — C ABI of libhdyolo_hip.so: the MI355X (gfx950) kernels behind hd_yolo's metayolo detection hot path.
+ *
+ * The reference (impromptuRong/hd_yolo) is pure Python on PyTorch: it has no FFI / plugin registry.  The native
+ * boundary of its hot path is wherever ATen / torchvision are entered, so each entry point below names the
+ * reference call site whose native work it replaces (paths relative to the reference repo root).
+ * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - Plain pointers and sizes only; every buffer (inputs, outputs, workspaces) is owned by the caller.
+ *    The library allocates nothing, keeps no pointers after a call returns and never synchronises.
+ *  - All work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the null stream).
+ *  - Return value: 0 = ok; < 0 = invalid argument / unsupported shape; > 0 = a hipError_t from the launch.
+ *    hdy_last_error() returns a thread-local description of the last failure.  Re-entrant, no global state.
+ *  - Activations are NHWC ("channels last") with an explicit pixel pitch `ld*` in ELEMENTS, so a tensor may be
+ *    a channel slice of a wider buffer (this is how torch.cat along C costs nothing).  Framework weights stay
+ *    in the reference layout [K][C][R][S] fp32 and are re-packed by hdy_conv_pack.
+ *  - dtype: HDY_F32 (exact fp32 MFMA, parity mode) or HDY_BF16 (bf16 operands, fp32 accumulate).  Per-channel
+ *    vectors (scale/shift/statistics/gradients of them) are always fp32.
+ *  - Alignment: activation and packed-weight pointers 16 bytes; channel counts and pitches multiples of one
+ *    16-byte vector (8 bf16 / 4 f32) unless stated otherwise.
+ */
+#ifndef HDYOLO_H
+#define HDYOLO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HDY_F32 0
+#define HDY_BF16 1
+
+#define HDY_PACK_FWD 0   /* operand of hdy_conv_fwd / layout of hdy_conv_wgrad results */
+#define HDY_PACK_DGRAD 1 /* operand of hdy_conv_dgrad */
+#define HDY_PACK_STEM 2  /* operand of hdy_conv_fwd(stem=1) */
+
+#define HDY_ACT_NONE 0
+#define HDY_ACT_SILU 1
+
+const char* hdy_last_error(void);
+int hdy_version(void);
+
+/* ---- convolution family --------------------------------------------------------------------------------------
+ * Replaces nn.Conv2d forward/backward as used by metayolo/models/layers.py:31,37-41 (Conv), :92-97 (Bottleneck),
+ * :124-131 (C3), :179-189 (SPPF) and metayolo/models/yolo_head.py:112,142 (Detect's 1x1 conv with bias);
+ * backward is what train.py:472 `scaler.scale(loss).backward()` reaches through autograd. */
+int hdy_conv_out_dim(int in, int k, int stride, int pad);
+int hdy_conv_mtiles(long long M); /* number of BatchNorm statistic slabs hdy_conv_fwd writes for M output pixels */
+
+size_t hdy_conv_pack_elems(int K, int C, int R, int S, int stride, int pad, int kind, int dtype);
+int hdy_conv_pack(const float* w_a, int K_a, const float* w_b, int K_b, int C, int R, int S, int stride, int pad, int kind, int dtype,
+                  void* out, void* stream);
+
+/* y = act(scale[k] * conv(x, w)[.., k] + shift[k]) (+= y when accumulate).  scale/shift may be NULL (1 / 0).
+ * stats (optional, train-mode BN): [hdy_conv_mtiles(N*Ho*Wo)][2][K] floats, per-tile sum and sum of squares of
+ * the raw convolution (before scale/shift/act).  out_f32: write fp32 even when dtype is bf16 (detection logits).
+ * stem: x is the hdy_stem_prep buffer; requires C=3, R=S=6, stride=2, pad=2, ldx=4. */
+int hdy_conv_fwd(const void* x, int ldx, const void* w_packed, const float* scale, const float* shift, void* y, int ldy, float* stats,
+                 int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int act, int accumulate, int dtype, int out_f32,
+                 int stem, void* stream);
+
+/* dx[N][H][W][C] (+)= conv_transpose(dy[N][Ho][Wo][K], w); stride 1 or 2. */
+int hdy_conv_dgrad(const void* dy, int lddy, const void* w_packed_dgrad, void* dx, int lddx, int N, int H, int W, int C, int K, int R,
+                   int S, int stride, int pad, int accumulate, int dtype, void* stream);
+
+/* grad_a[K_a][C][R][S] (and grad_b[K_b][..] = the following K_b output channels, for two convs fused along K)
+ * (+)= dW, fp32, deterministic (slab reduction, no atomics). */
+size_t hdy_conv_wgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dtype, int stem);
+int hdy_conv_wgrad(const void* x, int ldx, const void* dy, int lddy, int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
+                   float* grad_a, int K_a, float* grad_b, int K_b, int accumulate, void* workspace, size_t ws_bytes, int dtype, int stem,
+                   void* stream);
+
+/* ---- BatchNorm + SiLU (+ residual) ---------------------------------------------------------------------------
+ * Replaces nn.BatchNorm2d (eps 1e-3, momentum 0.03: metayolo/models/utils_torch.py:47-49) and nn.SiLU in
+ * Conv.forward (metayolo/models/layers.py:37-38), the shortcut add of Bottleneck.forward (:97), their backward,
+ * and the eval-time folding of fuse_conv_and_bn (metayolo/models/utils_torch.py:79-99). */
+int hdy_bn_finalize(const float* stats, int mtiles, int K, long long count, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, float eps, float momentum, float* scale, float* shift, float* save_mean, float* save_invstd,
+                    void* stream);
+int hdy_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, int K,
+                       float* scale, float* shift, void* stream);
+int hdy_bn_act_fwd(const void* y, int ldy, const float* scale, const float* shift, const void* res, int ldr, void* z, int ldz,
+                   long long M, int K, int act, int dtype, void* stream);
+int hdy_bn_bwd_blocks(long long M);
+/* workspace: (hdy_bn_bwd_blocks(M) * 2 * K + 2 * K) floats */
+int hdy_bn_act_bwd(const void* dz, int lddz, const void* y, int ldy, const float* scale, const float* shift, const float* mean,
+                   const float* invstd, void* dy, int lddy, float* dgamma, float* dbeta, int accumulate, long long M, int K, int act,
+                   int dtype, float* workspace, void* stream);
+int hdy_add_inplace(void* out, int ldo, const void* a, int lda, long long M, int K, int dtype, void* stream);
+
+/* ---- SPPF pooling, upsample, layout --------------------------------------------------------------------------
+ * Replaces nn.MaxPool2d(5,1,2) x3 of SPPF.forward (metayolo/models/layers.py:181-189), nn.Upsample(None,2,'nearest')
+ * (hub yaml fpn rows) and the NCHW image hand-off (train.py:432, val_nuclei.py:135). */
+int hdy_sppf_pool_fwd(const void* x, void* y1, void* y2, void* y3, int ld, unsigned char* idx1, unsigned char* idx2, unsigned char* idx3,
+                      int N, int H, int W, int C, int dtype, void* stream);
+int hdy_sppf_pool_bwd(const void* g0, const void* g1, const void* g2, const void* g3, int ldg, const unsigned char* idx1,
+                      const unsigned char* idx2, const unsigned char* idx3, void* dx, int lddx, int N, int H, int W, int C, int dtype,
+                      void* stream);
+int hdy_upsample2x_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, int dtype, void* stream);
+int hdy_upsample2x_bwd(const void* dy, int lddy, void* dx, int lddx, int N, int H, int W, int C, int accumulate, int dtype, void* stream);
+int hdy_stem_prep(const float* img_nchw, void* out, int B, int H, int W, int pad, int dtype, void* stream);
+int hdy_nchw_to_nhwc(const float* src, void* dst, int ldd, int N, int C, int H, int W, int dtype, void* stream);
+
+/* ---- detection head ------------------------------------------------------------------------------------------
+ * hdy_decode replaces Detect.compute_proposals and the level-id pad + cat of compute_outputs
+ * (metayolo/models/yolo_head.py:185-213, :311-312, :419-429): logits (b,a,y,x,o) addressed through element strides
+ * (sb,sa,sy,sx; o contiguous) -> out[b][row_offset + (a*ny + y)*nx + x][0..no] = cx,cy,w,h (pixels), sigmoid(obj),
+ * sigmoid(cls..), level id.  anchor_px: na*2 HOST floats (anchor w,h in pixels).
+ *
+ * hdy_nms_batched replaces nms_per_image (metayolo/models/utils_general.py:299-356; class_aware=0, the path's
+ * default: class-agnostic, ranked by objectness, boxes with w or h < min_wh dropped, obj > conf strict) and
+ * non_max_suppression (:423-523; class_aware=1) including torchvision.ops.nms / remove_small_boxes.
+ * preds [B][N][row] fp32 with row = 5 + nc + extra.  Outputs per tile: keep[max_det] original row indices in
+ * descending-score order (stable: ties by lower row), -1 padded; n_keep; and the gathered rows.
+ * max_det <= 4096.  workspace: hdy_nms_workspace_bytes(B, N). */
+int hdy_decode(const float* det, long long sb, long long sa, long long sy, long long sx, const float* anchor_px, float stride, float* out,
+               int row_offset, int rows_per_image, int level_id, int B, int na, int ny, int nx, int no, void* stream);
+size_t hdy_nms_workspace_bytes(int B, int N);
+int hdy_nms_batched(const float* preds, int B, int N, int row, int nc, float conf, float iou, int max_det, float min_wh, int class_aware,
+                    long long* keep, int* n_keep, float* out_boxes, float* out_scores, float* out_extra, float* out_conf, int* out_cls,
+                    void* workspace, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HDYOLO_H */

@@ -17,3 +17,13 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN
+
+
+def pytest_collection_modifyitems(config, items):
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason='no GPU in this container (run with gpurun)')
+    for item in items:
+        if 'gpu' in item.keywords:
+            item.add_marker(skip)

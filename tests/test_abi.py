@@ -1,0 +1,52 @@
+"""CPU-side checks of the C-ABI boundary: the library builds for gfx950, loads, and exports every symbol
+include/hdyolo.h declares with a ctypes signature registered in hd_yolo_amd/_lib.py.  No compute calls."""
+import os
+import re
+
+import pytest
+
+from hd_yolo_amd import _lib, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    if not os.path.exists(_lib.LIB_PATH):
+        build.build(verbose=False)
+    return _lib.load()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'hdyolo.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(hdy_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_header_symbols_exported_and_bound(lib):
+    syms = declared_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(lib, s), f'{s} declared in include/hdyolo.h but not exported'
+        assert s in _lib.SIGNATURES, f'{s} has no ctypes signature'
+    assert sorted(_lib.SIGNATURES) == syms
+
+
+def test_pure_host_queries(lib):
+    assert lib.hdy_version() == 1
+    assert lib.hdy_conv_out_dim(640, 6, 2, 2) == 320 and lib.hdy_conv_out_dim(80, 3, 2, 1) == 40
+    assert lib.hdy_conv_mtiles(129) == 2
+    # packed sizes: rows padded to the N tile, K-extent padded to 128 bytes
+    assert lib.hdy_conv_pack_elems(39, 128, 1, 1, 1, 0, _lib.PACK_FWD, _lib.BF16) == 64 * 128
+    assert lib.hdy_conv_pack_elems(64, 64, 3, 3, 1, 1, _lib.PACK_FWD, _lib.F32) == 64 * 576
+    # stride-2 dgrad = four parity classes holding 1+2+2+4 = 9 taps in total
+    assert lib.hdy_conv_pack_elems(128, 64, 3, 3, 2, 1, _lib.PACK_DGRAD, _lib.BF16) == 64 * 128 * 9
+    assert lib.hdy_nms_workspace_bytes(2, 25200) == 2 * 32768 * 8
+    assert lib.hdy_bn_bwd_blocks(10) == 1 and lib.hdy_bn_bwd_blocks(10 ** 7) == 1024
+
+
+def test_invalid_arguments_return_status_not_crash(lib):
+    rc = lib.hdy_conv_fwd(None, 8, None, None, None, None, 8, None, 1, 4, 4, 8, 8, 1, 1, 1, 0, 0, 0, _lib.BF16, 0, 0, None)
+    assert rc < 0 and b'null' in lib.hdy_last_error()
+    rc = lib.hdy_nms_batched(None, 1, 4, 7, 1, 0.1, 2.0, 10, 2.0, 0, None, None, None, None, None, None, None, None, 0, None)
+    assert rc < 0
