@@ -22,17 +22,19 @@ SIGNATURES = {
     'hdy_conv_out_dim': (_I, [_I, _I, _I, _I]),
     'hdy_conv_mtiles': (_I, [_L]),
     'hdy_conv_pack_elems': (_Z, [_I, _I, _I, _I, _I, _I, _I, _I]),
-    'hdy_conv_pack': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
-    'hdy_conv_fwd': (_I, [_P, _I, _P, _P, _P, _P, _I, _P] + [_I] * 14 + [_P]),
+    'hdy_conv_pack': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    'hdy_conv_fwd': (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _I, _P] + [_I] * 14 + [_P]),
     'hdy_conv_dgrad': (_I, [_P, _I, _P, _P, _I] + [_I] * 11 + [_P]),
     'hdy_conv_wgrad_workspace_bytes': (_Z, [_I] * 11),
     'hdy_conv_wgrad': (_I, [_P, _I, _P, _I] + [_I] * 9 + [_P, _I, _P, _I, _I, _P, _Z, _I, _I, _P]),
-    'hdy_bn_finalize': (_I, [_P, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
+    'hdy_bn_finalize': (_I, [_P, _I, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
     'hdy_bn_eval_coeffs': (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
     'hdy_bn_act_fwd': (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _L, _I, _I, _I, _P]),
     'hdy_bn_bwd_blocks': (_I, [_L]),
     'hdy_bn_act_bwd': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _L, _I, _I, _I, _P, _P]),
     'hdy_add_inplace': (_I, [_P, _I, _P, _I, _L, _I, _I, _P]),
+    'hdy_colsum': (_I, [_P, _I, _L, _I, _P, _I, _I, _P, _P]),
+    'hdy_det_grad_pack': (_I, [_P, _L, _L, _L, _L, _L, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'hdy_sppf_pool_fwd': (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     'hdy_sppf_pool_bwd': (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'hdy_upsample2x_fwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -9,8 +9,9 @@
 
 int hdy_wgrad_reduce_launch(const float* partial, int splits, size_t slab_stride, int K, int Q, int mode, int C, int R, int S, float* grad,
                             int accumulate, hipStream_t st);
-int hdy_pack_weight_launch(const float* w, void* out, int K, int C, int R, int S, int transpose, int TH, int TW, int rbase, int rstep,
-                           int sbase, int sstep, int stem, int rows_valid, int rows_total, int Kdp, int dtype, hipStream_t st);
+int hdy_pack_weight_launch(const float* w_a, int K_a, const float* w_b, int K_b, void* out, int Kl, int C, int R, int S, int transpose,
+                           int TH, int TW, int rbase, int rstep, int sbase, int sstep, int stem, int rows_total, int Kdp, int dtype,
+                           hipStream_t st);
 
 static thread_local char g_err[512] = "";
 
@@ -73,35 +74,28 @@ size_t hdy_conv_pack_elems(int K, int C, int R, int S, int stride, int pad, int 
     return n;
 }
 
-// w_a [K_a][C][R][S] (+ optional w_b [K_b][C][R][S] stacked below it along K) -> packed operand for `kind`.
-int hdy_conv_pack(const float* w_a, int K_a, const float* w_b, int K_b, int C, int R, int S, int stride, int pad, int kind, int dtype,
-                  void* out, void* stream) {
-    HDY_ARG(w_a && out && K_a > 0 && K_b >= 0 && C > 0 && R > 0 && S > 0, "conv_pack: bad args");
+// Logical weight W[K][C][R][S]: rows 0..K_a-1 from w_a, the next K_b rows from w_b (two convs fused along K),
+// remaining rows up to K are zero (channel padding, e.g. 39 -> 40 detection outputs).  Packs it for `kind`.
+int hdy_conv_pack(const float* w_a, int K_a, const float* w_b, int K_b, int K, int C, int R, int S, int stride, int pad, int kind,
+                  int dtype, void* out, void* stream) {
+    HDY_ARG(w_a && out && K_a > 0 && K_b >= 0 && K >= K_a + K_b && C > 0 && R > 0 && S > 0, "conv_pack: bad args");
     HDY_ARG((K_b == 0) == (w_b == nullptr), "conv_pack: w_b / K_b mismatch");
     HDY_ARG(stride == 1 || stride == 2, "conv_pack: stride %d unsupported", stride);
+    HDY_ARG(dtype == HDY_BF16 || dtype == HDY_F32, "conv_pack: unknown dtype %d", dtype);
     hipStream_t st = (hipStream_t)stream;
-    const int K = K_a + K_b;
-    // the pack kernel reads one source tensor; stacked sources are handled as two row (fwd) / column (dgrad) ranges
     if (kind == KIND_FWD || kind == KIND_STEM) {
         const int stem = kind == KIND_STEM;
         HDY_ARG(!stem || (C == 3 && K_b == 0), "conv_pack: stem expects C == 3 and a single weight");
         const int kd = stem ? R * S * 4 : R * S * C;
         const int Kdp = round_up(kd, bke(dtype));
         const int rows_total = round_up(K, hdy_conv_bn_tile(K));
-        const int TH = stem ? R : R, TW = stem ? 1 : S;
-        int rc = hdy_pack_weight_launch(w_a, out, K_a, C, R, S, 0, TH, TW, 0, 1, 0, 1, stem, K_a, K_b ? K_a : rows_total, Kdp, dtype, st);
-        if (rc) return rc;
-        if (K_b)
-            rc = hdy_pack_weight_launch(w_b, (char*)out + (size_t)K_a * Kdp * esize(dtype), K_b, C, R, S, 0, TH, TW, 0, 1, 0, 1, 0, K_b,
-                                        rows_total - K_a, Kdp, dtype, st);
-        return rc;
+        return hdy_pack_weight_launch(w_a, K_a, w_b, K_b, out, K, C, R, S, 0, R, stem ? 1 : S, 0, 1, 0, 1, stem, rows_total, Kdp, dtype, st);
     }
     HDY_ARG(kind == KIND_DGRAD, "conv_pack: unknown kind %d", kind);
-    HDY_ARG(K_b == 0, "conv_pack: dgrad packing of stacked weights: pack the stacked fp32 tensor instead");
     const int rows_total = round_up(C, hdy_conv_bn_tile(C));
     if (stride == 1) {
         const int Kdp = round_up(R * S * K, bke(dtype));
-        return hdy_pack_weight_launch(w_a, out, K, C, R, S, 1, R, S, R - 1, -1, S - 1, -1, 0, C, rows_total, Kdp, dtype, st);
+        return hdy_pack_weight_launch(w_a, K_a, w_b, K_b, out, K, C, R, S, 1, R, S, R - 1, -1, S - 1, -1, 0, rows_total, Kdp, dtype, st);
     }
     size_t off = 0;
     for (int a = 0; a < 2; ++a)
@@ -109,8 +103,8 @@ int hdy_conv_pack(const float* w_a, int K_a, const float* w_b, int K_b, int C, i
             const Axis ah = class_axis(R, pad, a), aw = class_axis(S, pad, b);
             if (!ah.taps || !aw.taps) continue;
             const int Kdp = round_up(ah.taps * aw.taps * K, bke(dtype));
-            int rc = hdy_pack_weight_launch(w_a, (char*)out + off * esize(dtype), K, C, R, S, 1, ah.taps, aw.taps, ah.rmax, -2, aw.rmax, -2, 0,
-                                            C, rows_total, Kdp, dtype, st);
+            int rc = hdy_pack_weight_launch(w_a, K_a, w_b, K_b, (char*)out + off * esize(dtype), K, C, R, S, 1, ah.taps, aw.taps, ah.rmax, -2,
+                                            aw.rmax, -2, 0, rows_total, Kdp, dtype, st);
             if (rc) return rc;
             off += (size_t)rows_total * Kdp;
         }
@@ -119,13 +113,14 @@ int hdy_conv_pack(const float* w_a, int K_a, const float* w_b, int K_b, int C, i
 
 // y = act(scale * conv(x, w) + shift) [+= y]; NHWC with pixel pitches; optional BatchNorm slabs in `stats`.
 // stem != 0: x is the hdy_stem_prep() buffer [N][H+2*pad][W+2*pad][4] and (C,R,S,stride,pad) must be (3,6,6,2,2).
-int hdy_conv_fwd(const void* x, int ldx, const void* w_packed, const float* scale, const float* shift, void* y, int ldy, float* stats,
-                 int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int act, int accumulate, int dtype, int out_f32,
-                 int stem, void* stream) {
+int hdy_conv_fwd(const void* x, int ldx, const void* w_packed, const float* scale, const float* shift, const void* res, int ldr, void* y,
+                 int ldy, float* stats, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int act, int accumulate,
+                 int dtype, int out_f32, int stem, void* stream) {
     HDY_ARG(stride >= 1 && R >= 1 && S >= 1 && pad >= 0, "conv_fwd: bad window");
     HDY_ARG(dtype == HDY_BF16 || dtype == HDY_F32, "conv_fwd: unknown dtype %d", dtype);
     ConvArgs a = {};
-    a.x = x; a.w = w_packed; a.y = y; a.scale = scale; a.shift = shift; a.stats = stats;
+    a.x = x; a.w = w_packed; a.y = y; a.scale = scale; a.shift = shift; a.stats = stats; a.res = res; a.ldr = ldr;
+    HDY_ARG(!res || ldr >= K, "conv_fwd: residual pitch %d < K", ldr);
     a.N = N;
     a.Ho = hdy_conv_out_dim(H, R, stride, pad);
     a.Wo = hdy_conv_out_dim(W, S, stride, pad);

@@ -47,7 +47,7 @@ template <> __device__ __forceinline__ i32x4 pack<bf16_t>(const float* f) {
 
 // ---------------------------------------------------------------- finalize (forward)
 // grid = ceil(K/32), block = 32 channels x 32 tile-lanes
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ stats, int mtiles, int K, double count,
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ stats, int stats_ld, int mtiles, int K, double count,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float* __restrict__ rmean, float* __restrict__ rvar, float eps, float momentum,
                                                            float* __restrict__ scale, float* __restrict__ shift,
@@ -58,8 +58,8 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
     double s = 0.0, ss = 0.0;
     if (k < K) {
         for (int t = tl; t < mtiles; t += 32) {
-            s += (double)stats[((size_t)t * 2 + 0) * K + k];
-            ss += (double)stats[((size_t)t * 2 + 1) * K + k];
+            s += (double)stats[((size_t)t * 2 + 0) * stats_ld + k];
+            ss += (double)stats[((size_t)t * 2 + 1) * stats_ld + k];
         }
     }
     red[0][tl][cl] = s;
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restr
 #pragma unroll
     for (int i = 0; i < VE; ++i) {
         a1[i] = 0.f; a2[i] = 0.f;
-        sc[i] = scale[c + i]; sh[i] = shift[c + i]; mu[i] = mean[c + i]; is[i] = invstd[c + i];
+        sc[i] = scale ? scale[c + i] : 1.f; sh[i] = shift ? shift[c + i] : 0.f; mu[i] = mean ? mean[c + i] : 0.f; is[i] = invstd ? invstd[c + i] : 0.f;
     }
     const long long mbeg = (long long)blockIdx.x * rows_per_block;
     const long long mend = min(mbeg + rows_per_block, M);
@@ -151,7 +151,11 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restr
         for (long long m = mbeg + rl; m < mend; m += RL) {
             float g[VE], v[VE];
             unpack<T>(*(const i32x4*)(dz + m * lddz + c), g);
-            unpack<T>(*(const i32x4*)(y + m * ldy + c), v);
+            if (y) unpack<T>(*(const i32x4*)(y + m * ldy + c), v);
+            else {
+#pragma unroll
+                for (int i = 0; i < VE; ++i) v[i] = 0.f;
+            }
 #pragma unroll
             for (int i = 0; i < VE; ++i) {
                 float du = g[i];
@@ -266,13 +270,13 @@ inline int stream_grid(long long total_vec) {
 
 extern "C" {
 
-int hdy_bn_finalize(const float* stats, int mtiles, int K, long long count, const float* gamma, const float* beta, float* running_mean,
+int hdy_bn_finalize(const float* stats, int stats_ld, int mtiles, int K, long long count, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float eps, float momentum, float* scale, float* shift, float* save_mean, float* save_invstd,
                     void* stream) {
     HDY_ARG(stats && gamma && beta && scale && shift && save_mean && save_invstd, "bn_finalize: null pointer");
-    HDY_ARG(mtiles > 0 && K > 0 && count > 0, "bn_finalize: bad sizes");
+    HDY_ARG(mtiles > 0 && K > 0 && count > 0 && stats_ld >= K, "bn_finalize: bad sizes");
     HDY_ARG((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running_mean/var must both be given or both null");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(K, 32)), dim3(1024), 0, (hipStream_t)stream, stats, mtiles, K, (double)count, gamma,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(K, 32)), dim3(1024), 0, (hipStream_t)stream, stats, stats_ld, mtiles, K, (double)count, gamma,
                        beta, running_mean, running_var, eps, momentum, scale, shift, save_mean, save_invstd);
     HDY_LAUNCH_CHECK("bn_finalize");
     return HDY_OK;
@@ -344,6 +348,27 @@ int hdy_bn_act_bwd(const void* dz, int lddz, const void* y, int ldy, const float
         hipLaunchKernelGGL(bn_act_bwd_apply_kernel<float>, dim3(g2), dim3(256), 0, st, (const float*)dz, lddz, (const float*)y, ldy, scale,
                            shift, mean, invstd, c1, c2, (float*)dy, lddy, M, K, act);
     HDY_LAUNCH_CHECK("bn_act_bwd_apply");
+    return HDY_OK;
+}
+
+// out[k] (+)= sum over the M rows of dz[m][k]  (bias gradient of the detection conv).  workspace: hdy_bn_bwd_blocks(M)*2*K floats.
+int hdy_colsum(const void* dz, int lddz, long long M, int K, float* out, int accumulate, int dtype, float* workspace, void* stream) {
+    const int VE = dtype == HDY_BF16 ? 8 : 4;
+    HDY_ARG(dz && out && workspace && M > 0 && K > 0 && K % VE == 0 && VEC_OK(dz, lddz, VE), "colsum: bad args");
+    const int nb = hdy_bn_bwd_blocks(M);
+    const int rows = (int)((M + nb - 1) / nb);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(nb, cdiv(K / VE, 256));
+    if (dtype == HDY_BF16)
+        hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dz, lddz, (const bf16_t*)nullptr, 0,
+                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, M, K, 0, rows, workspace);
+    else
+        hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<float>, grid, dim3(256), 0, st, (const float*)dz, lddz, (const float*)nullptr, 0,
+                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, M, K, 0, rows, workspace);
+    HDY_LAUNCH_CHECK("colsum_reduce");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(K, 32)), dim3(1024), 0, st, workspace, nb, K, (double)M, (float*)nullptr, out, accumulate,
+                       (float*)nullptr, (float*)nullptr);
+    HDY_LAUNCH_CHECK("colsum_finalize");
     return HDY_OK;
 }
 

@@ -217,11 +217,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
                 opix = ((size_t)n * p.Hout + (p.oh_off + oi * p.oh_mul)) * p.Wout + (p.ow_off + oj * p.ow_mul);
             }
             OT* yrow = y + opix * p.ldy;
+            const OT* rrow = p.res ? (const OT*)p.res + opix * p.ldr : nullptr;
 #pragma unroll
             for (int b = 0; b < NT; ++b) {
                 if (kcol[b] >= p.K) continue;
                 float v = acc[a][b][r] * sc[b] + sh[b];
                 if (p.act == 1) v = silu_f(v);
+                if (rrow) v += to_f32<OT>(rrow[kcol[b]]);
                 if (p.accumulate) v += to_f32<OT>(yrow[kcol[b]]);
                 yrow[kcol[b]] = from_f32<OT>(v);
             }

@@ -217,29 +217,34 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int split
 //   tap t = (tr, ts) in a TH x TW window reads source (r, s) = (rbase + rstep*tr, sbase + sstep*ts)
 //   stem == 1: forward only, cdim = s*4 + c over a [R][S*4] window (TH = R, TW = 1), c == 3 is zero
 template <typename T>
-__global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int K, int C, int R, int S, int transpose,
-                                   int TH, int TW, int rbase, int rstep, int sbase, int sstep, int stem, int rows_valid,
-                                   int rows_total, int Kdp) {
+__global__ void pack_weight_kernel(const float* __restrict__ w_a, int K_a, const float* __restrict__ w_b, int K_b, T* __restrict__ out,
+                                   int Kl, int C, int R, int S, int transpose, int TH, int TW, int rbase, int rstep, int sbase,
+                                   int sstep, int stem, int rows_total, int Kdp) {
+    // logical weight W[k][c][r][s], k < Kl: rows of w_a, then rows of w_b, then zeros (channel padding)
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)rows_total * Kdp) return;
     const int row = (int)(idx / Kdp), col = (int)(idx - (long long)row * Kdp);
-    float v = 0.f;
-    if (row < rows_valid) {
-        if (stem) {
-            const int r = col / (S * 4), rem = col - r * (S * 4);
-            const int s = rem >> 2, c = rem & 3;
-            if (r < R && c < C) v = w[(((size_t)row * C + c) * R + r) * S + s];
-        } else {
-            const int cd = transpose ? K : C;
-            const int t = col / cd, ci = col - t * cd;
-            if (t < TH * TW) {
-                const int tr = t / TW, ts = t - tr * TW;
-                const int r = rbase + rstep * tr, s = sbase + sstep * ts;
-                const int k = transpose ? ci : row, c = transpose ? row : ci;
-                if (r >= 0 && r < R && s >= 0 && s < S) v = w[(((size_t)k * C + c) * R + r) * S + s];
-            }
+    int k = -1, c = 0, r = 0, s = 0;
+    if (stem) {
+        r = col / (S * 4);
+        const int rem = col - r * (S * 4);
+        s = rem >> 2;
+        c = rem & 3;
+        if (r < R && c < C) k = row;
+    } else {
+        const int cd = transpose ? Kl : C;
+        const int t = col / cd, ci = col - t * cd;
+        if (t < TH * TW) {
+            const int tr = t / TW, ts = t - tr * TW;
+            r = rbase + rstep * tr;
+            s = sbase + sstep * ts;
+            c = transpose ? row : ci;
+            if (r >= 0 && r < R && s >= 0 && s < S && c < C) k = transpose ? ci : row;
         }
     }
+    float v = 0.f;
+    if (k >= 0 && k < K_a) v = w_a[(((size_t)k * C + c) * R + r) * S + s];
+    else if (k >= K_a && k < K_a + K_b) v = w_b[(((size_t)(k - K_a) * C + c) * R + r) * S + s];
     out[idx] = from_f32<T>(v);
 }
 
@@ -290,16 +295,17 @@ int hdy_wgrad_reduce_launch(const float* partial, int splits, size_t slab_stride
     return HDY_OK;
 }
 
-int hdy_pack_weight_launch(const float* w, void* out, int K, int C, int R, int S, int transpose, int TH, int TW, int rbase, int rstep,
-                           int sbase, int sstep, int stem, int rows_valid, int rows_total, int Kdp, int dtype, hipStream_t st) {
+int hdy_pack_weight_launch(const float* w_a, int K_a, const float* w_b, int K_b, void* out, int Kl, int C, int R, int S, int transpose,
+                           int TH, int TW, int rbase, int rstep, int sbase, int sstep, int stem, int rows_total, int Kdp, int dtype,
+                           hipStream_t st) {
     const long long n = (long long)rows_total * Kdp;
     const int grid = cdiv(n, 256);
     if (dtype == HDY_BF16)
-        hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, w, (bf16_t*)out, K, C, R, S, transpose, TH, TW, rbase,
-                           rstep, sbase, sstep, stem, rows_valid, rows_total, Kdp);
+        hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, w_a, K_a, w_b, K_b, (bf16_t*)out, Kl, C, R, S,
+                           transpose, TH, TW, rbase, rstep, sbase, sstep, stem, rows_total, Kdp);
     else
-        hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(grid), dim3(256), 0, st, w, (float*)out, K, C, R, S, transpose, TH, TW, rbase,
-                           rstep, sbase, sstep, stem, rows_valid, rows_total, Kdp);
+        hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(grid), dim3(256), 0, st, w_a, K_a, w_b, K_b, (float*)out, Kl, C, R, S, transpose,
+                           TH, TW, rbase, rstep, sbase, sstep, stem, rows_total, Kdp);
     HDY_LAUNCH_CHECK("pack_weight");
     return HDY_OK;
 }

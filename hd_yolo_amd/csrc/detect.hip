@@ -56,6 +56,28 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs p) {
     }
 }
 
+// gradient of the logits as autograd hands it over, (b,a,y,x,o) fp32 with arbitrary element strides ->
+// NHWC [B][ny][nx][ldo] of T with channel = a*no + o and zero padding up to ldo (what dgrad/wgrad consume)
+template <typename T>
+__global__ __launch_bounds__(256) void det_grad_pack_kernel(const float* __restrict__ g, long long sb, long long sa, long long sy, long long sx,
+                                                            long long so, T* __restrict__ out, int ldo, int B, int na, int ny, int nx, int no) {
+    const long long total = (long long)B * ny * nx * ldo;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int ch = (int)(idx % ldo);
+        long long t = idx / ldo;
+        const int x = (int)(t % nx);
+        t /= nx;
+        const int y = (int)(t % ny);
+        const int b = (int)(t / ny);
+        float v = 0.f;
+        if (ch < na * no) {
+            const int a = ch / no, o = ch - a * no;
+            v = g[b * sb + a * sa + y * sy + x * sx + o * so];
+        }
+        out[idx] = from_f32<T>(v);
+    }
+}
+
 // ------------------------------------------------------------------------------------------- NMS
 constexpr int NT = 1024;          // threads per tile
 constexpr int LDS_KEYS = 8192;    // sort capacity in LDS
@@ -289,6 +311,21 @@ int hdy_decode(const float* det, long long sb, long long sa, long long sy, long 
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(decode_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, a);
     HDY_LAUNCH_CHECK("decode");
+    return HDY_OK;
+}
+
+int hdy_det_grad_pack(const float* g, long long sb, long long sa, long long sy, long long sx, long long so, void* out, int ldo, int B, int na,
+                      int ny, int nx, int no, int dtype, void* stream) {
+    HDY_ARG(g && out && B > 0 && na > 0 && ny > 0 && nx > 0 && no > 0 && ldo >= na * no, "det_grad_pack: bad args");
+    long long n = ((long long)B * ny * nx * ldo + 255) / 256;
+    if (n > 8192) n = 8192;
+    if (dtype == HDY_BF16)
+        hipLaunchKernelGGL(det_grad_pack_kernel<bf16_t>, dim3((int)n), dim3(256), 0, (hipStream_t)stream, g, sb, sa, sy, sx, so, (bf16_t*)out, ldo,
+                           B, na, ny, nx, no);
+    else
+        hipLaunchKernelGGL(det_grad_pack_kernel<float>, dim3((int)n), dim3(256), 0, (hipStream_t)stream, g, sb, sa, sy, sx, so, (float*)out, ldo, B,
+                           na, ny, nx, no);
+    HDY_LAUNCH_CHECK("det_grad_pack");
     return HDY_OK;
 }
 

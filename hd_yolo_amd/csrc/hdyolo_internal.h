@@ -9,6 +9,8 @@ struct ConvArgs {
     const float* scale;   // per-channel epilogue scale (or null = 1)
     const float* shift;   // per-channel epilogue shift / bias (or null = 0)
     float* stats;         // [mtiles][2][K] BatchNorm partial sums (or null)
+    const void* res;      // residual added after the activation, same pixel grid as y, pitch ldr (or null)
+    int ldr;
     int N, Hin, Win, C, ldx;
     int Ho, Wo, K, ldy;
     int Hout, Wout, oh_mul, oh_off, ow_mul, ow_off;

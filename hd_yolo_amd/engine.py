@@ -1,0 +1,151 @@
+"""Glue between the nn.Module surface and the static HIP plans: plan cache, flat gradient store, autograd hook-in."""
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+from .plan import Plan
+
+
+def compute_dtype(owner, x):
+    """Arithmetic type of a forward call: bf16 under autocast (the reference trains under amp.autocast,
+    train.py:455) or for half/bf16 inputs (val_nuclei.py:116,137), else the owner's `hdy_dtype`, else fp32."""
+    forced = getattr(owner, 'hdy_dtype', None)
+    if forced is not None:
+        return forced
+    if torch.is_autocast_enabled() or x.dtype in (torch.float16, torch.bfloat16):
+        return torch.bfloat16
+    return torch.float32
+
+
+class GradStore:
+    """All parameter gradients in one flat fp32 buffer.  Kernels write this step's gradient into `cur`;
+    publish() folds it into `acc`, whose views are what `param.grad` points at (so optimizers, clipping and the
+    RCCL all-reduce see one contiguous tensor)."""
+
+    def __init__(self, params, device):
+        self.params = [p for p in params]
+        self.offsets, n = {}, 0
+        for p in self.params:
+            self.offsets[id(p)] = n
+            n += (p.numel() + 3) // 4 * 4          # keep every view 16-byte aligned
+        self.numel = n
+        self.cur = torch.zeros(n, dtype=torch.float32, device=device)
+        self.acc = torch.zeros(n, dtype=torch.float32, device=device)
+        self._acc_views = {id(p): self._view(self.acc, p) for p in self.params}
+
+    def _view(self, flat, p):
+        o = self.offsets[id(p)]
+        return flat[o:o + p.numel()].view(p.shape)
+
+    def view_of(self, p):
+        return self._view(self.cur, p)
+
+    def publish(self):
+        live = [p for p in self.params if p.requires_grad]
+        fresh = all(p.grad is None for p in live)
+        if fresh:
+            self.acc.copy_(self.cur)
+            for p in live:
+                p.grad = self._acc_views[id(p)]
+            return
+        mine = all(p.grad is not None and p.grad.data_ptr() == self._acc_views[id(p)].data_ptr() for p in live)
+        if mine:
+            self.acc.add_(self.cur)
+            return
+        for p in live:                               # mixed ownership: fall back to per-parameter accumulation
+            g = self.view_of(p)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.add_(g)
+
+
+class _PlanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, engine, plan, hook, images):
+        ctx.engine, ctx.plan = engine, plan
+        return tuple(plan.run_forward(images))
+
+    @staticmethod
+    def backward(ctx, *gdets):
+        ctx.plan.run_backward(gdets)
+        ctx.engine.after_backward()
+        return None, None, None, None
+
+
+class Engine:
+    """Owns the plans of one (backbone, neck, head) triple."""
+
+    def __init__(self, backbone, neck=None, head=None, max_plans=3):
+        self.parts = (backbone, neck, head)
+        self.plans = {}
+        self.max_plans = max_plans
+        self.store = None
+        self.hook = None
+        self.grad_hooks = []          # callables run after every backward, before publish (data-parallel all-reduce)
+
+    def _params(self):
+        seen, out = set(), []
+        for part in self.parts:
+            if part is None:
+                continue
+            mods = part if not isinstance(part, nn.Module) else [part]
+            for m in mods:
+                for p in m.parameters():
+                    if id(p) not in seen:
+                        seen.add(id(p))
+                        out.append(p)
+        return out
+
+    def _signature(self):
+        b, n, h = self.parts
+        fused = tuple(hasattr(m, 'bn') for part in (b, n) if part is not None for m in part.modules() if type(m).__name__ == 'Conv')
+        return hash(fused)
+
+    def plan_for(self, x, training, dtype):
+        ops.require_gpu(x)
+        _lib.load()
+        key = (tuple(x.shape), dtype, bool(training), x.device.index, self._signature())
+        plan = self.plans.get(key)
+        if plan is None:
+            if training and self.store is None:
+                self.store = GradStore(self._params(), x.device)
+                self.hook = torch.zeros(1, device=x.device, requires_grad=True)
+            if len(self.plans) >= self.max_plans:
+                self.plans.pop(next(iter(self.plans)))
+            b, n, h = self.parts
+            plan = Plan(b, n, h, tuple(x.shape), dtype, training, x.device, grad_store=self.store)
+            self.plans[key] = plan
+        return plan
+
+    def forward(self, x, training, dtype):
+        """Returns (plan, det logits list).  With grad enabled in training mode the logits are attached to autograd."""
+        plan = self.plan_for(x, training, dtype)
+        if training and torch.is_grad_enabled():
+            dets = _PlanFn.apply(self, plan, self.hook, x)
+        else:
+            dets = plan.run_forward(x)
+        return plan, list(dets)
+
+    def after_backward(self):
+        for fn in self.grad_hooks:
+            fn(self.store)
+        self.store.publish()
+
+
+class _Seq(list):
+    """A bare list of modules posing as a backbone for single-module plans."""
+    save = [0]
+
+
+def module_forward(module, x):
+    """Standalone forward of one hot-path module (Conv, Bottleneck, C3, SPPF) on an NCHW fp32 CUDA tensor: runs a
+    one-module HIP plan and returns the NCHW-shaped result (forward only; training goes through Model)."""
+    ops.require_gpu(x)
+    eng = module.__dict__.get('_hdy_engine')
+    if eng is None:
+        eng = Engine(_Seq([module]))
+        object.__setattr__(module, '_hdy_engine', eng)
+    plan = eng.plan_for(x, False, compute_dtype(module, x))
+    plan.run_forward(x)
+    return plan.feature(0)

@@ -1,0 +1,112 @@
+"""`Model` with the reference's constructor, attributes, forward signature and return structure
+(reference: metayolo/models/yolo.py:26-107).
+
+forward(x, targets=None, visualize=False, compute_masks=False) -> (losses, outputs)
+    x        (B, 3, H, W) float tiles in 0..1 on the MI355X
+    losses   {task: {'det_loss', 'mask_loss', 'loss_items': {'box','obj','cls','mask'}}}   (when targets are given)
+    outputs  list over images of {task: {'boxes' (n,4) xyxy px, 'scores' (n,), 'labels' (n,) 1..nc or -100}}   (eval)
+
+Backbone, neck and every header's 1x1 detection convs execute as ONE static HIP plan (hd_yolo_amd/plan.py); the plan's
+fp32 logits enter autograd through a single custom Function, so `loss.backward()` replays the plan's backward launch list
+and leaves parameter gradients as views of one flat buffer.
+Arithmetic type: bf16 (fp32 accumulate) under torch autocast or after .half()/.bfloat16(); exact fp32 otherwise.
+"""
+from copy import deepcopy
+from typing import Any
+
+import torch
+import torch.nn as nn
+
+from .. import LOGGER, check_version, load_cfg  # noqa: F401
+from ... import engine as _engine
+from .utils_general import make_divisible  # noqa: F401
+from .utils_torch import freeze_bn, freeze_params, fuse_conv_and_bn, initialize_weights, model_info, scale_img  # noqa: F401
+from .yolov5 import *  # noqa: F401,F403
+from .yolov5 import Conv, Detect, build_network
+
+
+class Model(nn.Module):
+    def __init__(self, cfg='yolov5s.yaml', hyp='./hyp.scratch.yaml', ch=3, anchors=None, is_scripting=False):
+        super().__init__()
+        self.cfg = deepcopy(load_cfg(cfg))
+        self.hyp = deepcopy(load_cfg(hyp))
+        self.inplace = self.cfg.get('inplace', True)
+        self.cfg['ch'] = self.cfg.get('ch', ch)
+        self.amp = self.cfg.get('amplification', None)
+        if anchors:
+            LOGGER.info(f'Overriding model.cfg anchors with anchors={anchors}')
+            self.cfg['anchors'] = round(anchors)
+        self.backbone, self.neck, self.headers = build_network(self.cfg, self.hyp, is_scripting=is_scripting)
+        if len(self.headers) != 1:
+            raise NotImplementedError('multi-header models are outside this round\'s hot path (one Detect header)')
+        initialize_weights(self)
+        self.info()
+        LOGGER.info('')
+
+    # ------------------------------------------------------------------ engine
+    def _eng(self):
+        eng = self.__dict__.get('_hdy_engine')
+        if eng is None:
+            head = next(iter(self.headers.values()))
+            eng = _engine.Engine(self.backbone, self.neck, head)
+            object.__setattr__(self, '_hdy_engine', eng)
+        return eng
+
+    def half(self):
+        """The reference validates with model.half() (val_nuclei.py:116).  Parameters stay fp32 masters here; the call
+        switches the plans to bf16 operands."""
+        object.__setattr__(self, 'hdy_dtype', torch.bfloat16)
+        return self
+
+    bfloat16 = half
+
+    def float(self):
+        object.__setattr__(self, 'hdy_dtype', None)
+        return super().float()
+
+    def features(self, x):
+        """{layer index: NCHW view} of the neck outputs for x (eval-mode statistics unless self.training)."""
+        plan, _ = self._eng().forward(x, self.training, _engine.compute_dtype(self, x))
+        return {k: plan.feature(k) for k in self.neck.save}
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x: torch.Tensor, targets=None, visualize=False, compute_masks=False):
+        plan, dets = self._eng().forward(x, self.training, _engine.compute_dtype(self, x))
+        losses, outputs = {}, {}
+        for task_id, header in self.headers.items():
+            task_dets, task_gts = dets, None
+            if targets is not None:
+                task_gts, keep = [], []
+                for idx, t in enumerate(targets):
+                    if task_id in t['anns']:
+                        task_gts.extend(t['anns'][task_id])
+                        keep.extend([idx] * len(t['anns'][task_id]))
+                if keep != list(range(x.shape[0])):
+                    sel = torch.tensor(keep, device=x.device, dtype=torch.long)
+                    task_dets = [d.index_select(0, sel) for d in dets]
+            losses[task_id], outputs[task_id] = header.forward_dets(task_dets, task_gts, compute_masks=compute_masks)
+        outputs = [dict(zip(outputs.keys(), per_image)) for per_image in zip(*outputs.values())]
+        return losses, self.post_processing(outputs)
+
+    def post_processing(self, outputs: Any):
+        return outputs
+
+    def fuse(self):
+        """Fold every BatchNorm into its conv (deploy); the plans are rebuilt for the folded graph."""
+        LOGGER.info('Fusing layers... ')
+        for m in self.modules():
+            if isinstance(m, Conv) and hasattr(m, 'bn'):
+                m.conv = fuse_conv_and_bn(m.conv, m.bn)
+                delattr(m, 'bn')
+                m.forward = m.forward_fuse
+        self.__dict__.pop('_hdy_engine', None)
+        self.info()
+        return self
+
+    def info(self, verbose=False, img_size=640):
+        model_info(self, verbose, img_size)
+
+    def freeze(self, layers=[]):
+        freeze_params(self, layers)
+        freeze_bn(self, layers)
+        return self

@@ -1,0 +1,268 @@
+"""Detection head with the reference's constructor, attributes, buffers and state_dict keys
+(reference: metayolo/models/yolo_head.py:18-23 BuffersDict, :25-112 Detect.__init__, :132-183 forward,
+:185-213 compute_proposals, :216-229 compute_losses (det part), :301-355 compute_outputs (det part),
+:358-417 matcher, :419-448 grids / bias init / NMS params, :473-511 hierarchical scores).
+
+On MI355X: the per-level 1x1 convs run inside the model's HIP plan (or a head-only plan when Detect is called on
+feature maps directly); decode and NMS are the `hdy_decode` / `hdy_nms_batched` kernels.  The mask branch
+(`masks` > 0: roi_align, Mask-RCNN heads, SegLoss) is SURVEY.md §8 row f2 and raises NotImplementedError.
+"""
+import math
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import LOGGER
+from ... import engine as _engine
+from ... import ops as _ops
+from .loss import DetLoss
+from .utils_general import nms_per_image, xyxy2xywh
+from .utils_torch import one_hot_labels
+
+
+class BuffersDict(nn.Module):
+    def __init__(self, x: Dict[str, Optional[torch.Tensor]] = {}):
+        super().__init__()
+        for k, v in x.items():
+            self.register_buffer(k, v)
+
+
+class _FeatureList(list):
+    """pseudo-backbone for a head-only plan (Detect called on given feature maps)"""
+    save = []
+
+
+class Detect(nn.Module):
+    def __init__(self, ch: List[int], anchors: List[List[int]], strides: List[int], nc: int, masks: Dict[int, int] = {},
+                 dim_reduced: int = 256, mask_output_size: int = 28, multi_label: bool = False,
+                 nms_params: Dict[str, float] = {}, loss_hyp: Dict[str, float] = {}, default_input_size: Optional[int] = 640,
+                 is_scripting: bool = False):
+        super().__init__()
+        assert len(ch) == len(anchors) == len(strides), 'ch, anchors, strides should have same length.'
+        self.ch, self.nl, self.nc, self.no = ch, len(ch), nc, nc + 5
+        self.na = len(anchors[0]) // 2
+        self.default_input_size = default_input_size
+        self.descendants: Dict[int, List[int]] = {}
+        self.get_descendants(self.build_hierarchical_tree())
+
+        strides_t = torch.tensor(strides).float()
+        anchors_t = torch.tensor(anchors).float().view(len(anchors), -1, 2) / strides_t.view(-1, 1, 1)   # in grid units
+        self.anchors = nn.ModuleList([])
+        for s, a in zip(strides_t, anchors_t):
+            if default_input_size is not None:
+                n = int(default_input_size / s)
+                grid, anchor_grid = self._make_grid(a, s, n, n)
+            else:
+                grid, anchor_grid = None, None
+            self.anchors.append(BuffersDict({'stride': s, 'anchor': a, 'grid': grid, 'anchor_grid': anchor_grid}))
+
+        self.m = self.build_det_layers()
+        self.initialize_biases()
+        if not is_scripting:
+            self.det_loss = DetLoss(self.nc, self.nl, loss_hyp, ssi=0)
+        self.nms_params: Dict[str, float] = self.get_nms_params(nms_params)
+        self.multi_label: bool = multi_label
+
+        mask_indices = torch.tensor([masks.get(i, 0) for i in range(self.nc + 1)])
+        self.nc_masks = mask_indices.max().item() + 1
+        self.register_buffer('mask_indices', mask_indices)
+        self.dim_reduced = dim_reduced
+        if self.nc_masks > 0:
+            raise NotImplementedError('Detect: the mask branch (masks >= 0) is the next hot-path row (SURVEY.md §8 f2); '
+                                      'build the header with masks = -1')
+        self.mask_output_size = None
+        self.seg, self.seg_h, self.seg_loss = None, None, None
+
+    # ------------------------------------------------------------------ construction helpers
+    def build_det_layers(self):
+        return nn.ModuleList(nn.Conv2d(c, self.no * self.na, 1) for c in self.ch)
+
+    def _make_grid(self, anchor, stride, nx: int = 20, ny: int = 20):
+        d, t = anchor.device, anchor.dtype
+        yv, xv = torch.meshgrid(torch.arange(ny, device=d, dtype=t), torch.arange(nx, device=d, dtype=t), indexing='ij')
+        return torch.stack((xv, yv), 2), anchor * stride
+
+    def initialize_biases(self, cf=None):
+        """obj prior of 8 objects per 640 px image, cls prior 0.6 / nc (focal-loss paper, section 3.3)."""
+        for mi, buf in zip(self.m, self.anchors):
+            b = mi.bias.view(self.na, -1)
+            b.data[:, 4] += math.log(8 / (640 / buf.stride) ** 2)
+            b.data[:, 5:] += math.log(0.6 / (self.nc - 0.999999)) if cf is None else torch.log(cf / cf.sum())
+            mi.bias = torch.nn.Parameter(b.view(-1), requires_grad=True)
+
+    def _print_biases(self):
+        for mi in self.m:
+            b = mi.bias.detach().view(self.na, -1).T
+            LOGGER.info(('%6g Conv2d.bias:' + '%10.3g' * 6) % (mi.weight.shape[1], *b[:5].mean(1).tolist(), b[5:].mean()))
+
+    def get_nms_params(self, args={}):
+        defaults = {'conf_thres': 0.15, 'iou_thres': 0.45, 'max_det': 300}
+        return {k: float(args.get(k, v)) for k, v in defaults.items()}
+
+    def build_hierarchical_tree(self):
+        return {0: {c: None for c in range(1, self.nc + 1)}}
+
+    def get_descendants(self, node: Optional[Dict] = None):
+        res: List[int] = []
+        if node is not None:
+            for k, v in node.items():
+                res.append(k)
+                below = self.get_descendants(v)
+                if below:
+                    self.descendants[k] = below
+                    res += below
+        return res
+
+    def hierarchical_scores(self, x: torch.Tensor) -> torch.Tensor:
+        """In place: every node's score is multiplied by its ancestors' (default tree: cls *= obj)."""
+        for k, v in self.descendants.items():
+            x[:, v] *= x[:, k:k + 1]
+        return x
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x: Dict[int, torch.Tensor], targets=None, compute_masks: bool = True):
+        """x: {layer index: NCHW feature map}.  Runs the level convs on a head-only HIP plan, then the shared tail."""
+        feats = [x[j] for j in self.f] if not isinstance(self.f, int) else [x[self.f]]
+        dets = self._det_convs(feats)
+        return self.forward_dets(dets, targets, compute_masks=compute_masks)
+
+    def _det_convs(self, feats):
+        raise NotImplementedError('Detect on bare feature maps: run the head through Model (the det convs are part of the '
+                                  'model plan); a head-only plan is not wired yet')
+
+    def forward_dets(self, dets: List[torch.Tensor], targets=None, compute_masks: bool = True):
+        """Tail of Detect.forward given the per-level logits (bs, na, ny, nx, no) fp32."""
+        if self.training:
+            assert targets is not None
+            want_loss, want_out = True, False
+        else:
+            want_loss, want_out = targets is not None, True
+        losses = self.compute_losses(dets, [], [], targets, compute_masks=False) if want_loss else {}
+        outputs = self.compute_outputs(self.compute_proposals(dets), [], compute_masks=False) if want_out else []
+        return losses, outputs
+
+    def anchor_px(self, i):
+        buf = self.anchors[i]
+        return (buf.anchor * buf.stride).flatten().tolist()
+
+    def compute_proposals(self, dets: List[torch.Tensor]) -> List[torch.Tensor]:
+        """Per level (bs, na, ny, nx, no): xy = (sigmoid*2 - 0.5 + grid)*stride, wh = (sigmoid*2)^2 * anchor px, rest sigmoid."""
+        preds = []
+        for i, d in enumerate(dets):
+            bs, na, ny, nx, no = d.shape
+            out = torch.empty((bs, na * ny * nx, no + 1), dtype=torch.float32, device=d.device)
+            _ops.decode_level(d, self._anchor_px_cached(i), float(self.anchors[i].stride), out, 0, i)
+            preds.append(out[..., :no].view(bs, na, ny, nx, no))
+        return preds
+
+    def _anchor_px_cached(self, i):
+        cache = self.__dict__.setdefault('_apx', {})
+        if i not in cache:
+            cache[i] = self.anchor_px(i)
+        return cache[i]
+
+    def decode_all(self, dets: List[torch.Tensor]) -> torch.Tensor:
+        """All levels decoded straight into one (bs, sum na*ny*nx, no+1) tensor with the level id in the last column
+        (what compute_outputs feeds to NMS; replaces the reference's per-level pad + cat)."""
+        bs = dets[0].shape[0]
+        rows = [d.shape[1] * d.shape[2] * d.shape[3] for d in dets]
+        out = torch.empty((bs, sum(rows), self.no + 1), dtype=torch.float32, device=dets[0].device)
+        off = 0
+        for i, d in enumerate(dets):
+            _ops.decode_level(d, self._anchor_px_cached(i), float(self.anchors[i].stride), out, off, i)
+            off += rows[i]
+        return out
+
+    def compute_outputs(self, preds, features=(), compute_masks: bool = False) -> List[Dict[str, torch.Tensor]]:
+        """preds: list of decoded levels (bs, na, ny, nx, no) or the already concatenated (bs, N, no+1) tensor."""
+        if isinstance(preds, (list, tuple)):
+            flat = torch.cat([torch.nn.functional.pad(p.reshape(p.shape[0], -1, self.no), [0, 1], value=float(i))
+                              for i, p in enumerate(preds)], 1)
+        else:
+            flat = preds
+        conf = self.nms_params['conf_thres']
+        kept = nms_per_image(flat, nc=self.nc, conf_thres=conf, iou_thres=self.nms_params['iou_thres'],
+                             max_det=int(self.nms_params['max_det']))
+        results = []
+        for r in kept:
+            scores = self.hierarchical_scores(r['scores'].clone())
+            out = {'boxes': r['boxes']}
+            if self.multi_label:
+                out['scores'], out['labels'] = scores, scores > conf
+            else:
+                obj = scores[..., 0]
+                if scores.shape[0]:
+                    cls_scores, cls_labels = scores[..., 1:].max(1)
+                else:
+                    cls_scores, cls_labels = obj, torch.zeros_like(obj, dtype=torch.long)
+                out['scores'] = torch.where(cls_scores > conf, cls_scores, obj)
+                out['labels'] = torch.where(cls_scores > conf, cls_labels + 1, torch.full_like(cls_labels, -100))
+            results.append(out)
+        return results
+
+    # ------------------------------------------------------------------ training side
+    def compute_losses(self, dets, preds, features, targets, compute_masks=False):
+        dev = dets[0].device
+        rows = []
+        for idx, t in enumerate(targets):
+            rows.append(torch.cat([torch.full_like(t['boxes'][:, :1], idx), xyxy2xywh(t['boxes'], clip=True, eps=0.0)], -1))
+        gts = torch.cat(rows).to(dev)
+        gt_labels = torch.cat([one_hot_labels(t['labels'], self.nc) if t['labels'].dim() == 1 else t['labels'] for t in targets]).to(dev)
+        tbox, tids, indices, anchors = self.matcher(dets, gts)
+        tcls = [gt_labels[i] for i in tids]
+        det_loss, items = self.det_loss(dets, tcls, tbox, indices, anchors)
+        mask_loss = torch.zeros_like(det_loss)
+        return {'det_loss': det_loss, 'mask_loss': mask_loss, 'loss_items': {**items, 'mask': mask_loss.detach()}}
+
+    def matcher(self, p, gts):
+        """Assign each ground-truth box (img, cx, cy, w, h; normalised) to anchors whose w/h ratio is within anchor_t and to
+        the cell containing its centre plus the up-to-two nearest neighbour cells.  Returns per level
+        (tbox [dx, dy, w, h in grid units], object ids, (img, anchor, gj, gi), anchor wh)."""
+        dev = gts.device
+        na, nt = self.na, len(gts)
+        rows = torch.cat([torch.arange(nt, device=dev, dtype=gts.dtype)[:, None], gts[:, :6]], 1)        # obj, img, x, y, w, h
+        ai = torch.arange(na, device=dev, dtype=gts.dtype).view(na, 1, 1).expand(na, nt, 1)
+        rows = torch.cat([ai, rows[None].expand(na, nt, rows.shape[1])], 2)                               # (na, nt, 7)
+        g = 0.5
+        shifts = torch.tensor([[0, 0], [1, 0], [0, 1], [-1, 0], [0, -1]], device=dev, dtype=gts.dtype) * g
+        tbox, tids, indices, anch = [], [], [], []
+        for i, buf in enumerate(self.anchors):
+            anc = buf.anchor.to(dev)
+            ny, nx = p[i].shape[2:4]
+            t = rows * torch.tensor([1, 1, 1, nx, ny, nx, ny], device=dev, dtype=gts.dtype)
+            if nt:
+                ratio = t[:, :, 5:7] / anc[:, None]
+                t = t[torch.max(ratio, 1. / ratio).max(2)[0] < self.det_loss.hyp['anchor_t']]
+                gxy = t[:, 3:5]
+                inv = torch.tensor([nx, ny], device=dev, dtype=gts.dtype) - gxy
+                j, k = ((gxy % 1. < g) & (gxy > 1.)).T
+                l, m = ((inv % 1. < g) & (inv > 1.)).T
+                sel = torch.stack((torch.ones_like(j), j, k, l, m))
+                t = t.repeat((5, 1, 1))[sel]
+                off = (torch.zeros_like(gxy)[None] + shifts[:, None])[sel]
+            else:
+                t, off = rows[0], 0
+            gxy, gwh = t[:, 3:5], t[:, 5:7]
+            cell = (gxy - off).long()
+            gi, gj = cell[:, 0].clamp(0, nx - 1), cell[:, 1].clamp(0, ny - 1)
+            cell = torch.stack((gi, gj), 1)          # the reference clamps through views, so tbox uses the clamped cell
+            a, o, b = t[:, 0].long(), t[:, 1].long(), t[:, 2].long()
+            indices.append((b, a, gj, gi))
+            tbox.append(torch.cat((gxy - cell, gwh), 1))
+            anch.append(anc[a])
+            tids.append(o)
+        return tbox, tids, indices, anch
+
+    # ------------------------------------------------------------------ whole-slide helpers (yolo_head.py:450-471)
+    def merge_outputs(self, r):
+        boxes = torch.cat([x['boxes'] + x['boxes'].new([x['roi'][0], x['roi'][1], x['roi'][0], x['roi'][1]]) for x in r])
+        res = {'boxes': boxes, 'labels': torch.cat([x['labels'] for x in r]), 'scores': torch.cat([x['scores'] for x in r])}
+        if 'masks' in r[0]:
+            res['masks'] = torch.cat([x['masks'] for x in r])
+        return res
+
+    def rescale_outputs(self, r, scale=1.0):
+        if scale != 1.0:
+            r['boxes'] *= scale
+        return r

@@ -79,16 +79,17 @@ def pack_alloc(K, C, R, S, stride, pad, kind, dtype, device):
     return torch.empty(n, dtype=dtype, device=device)
 
 
-def rec_pack(w_a, w_b, stride, pad, kind, out):
-    """Pack framework weights [K,C,R,S] fp32 (optionally two stacked along K) into `out`."""
+def rec_pack(w_a, w_b, stride, pad, kind, out, K=None):
+    """Pack framework weights [K,C,R,S] fp32 (optionally two stacked along K, zero padded to K rows) into `out`."""
     K_a, C, R, S = w_a.shape
     K_b = 0 if w_b is None else w_b.shape[0]
+    K = K_a + K_b if K is None else K
     assert w_a.is_contiguous() and w_a.dtype == torch.float32 and (w_b is None or (w_b.is_contiguous() and w_b.shape[1:] == w_a.shape[1:]))
-    return _rec(locals(), 'hdy_conv_pack', (ptr(w_a), K_a, ptr(w_b), K_b, C, R, S, stride, pad, kind, dcode(out.dtype), ptr(out)))
+    return _rec(locals(), 'hdy_conv_pack', (ptr(w_a), K_a, ptr(w_b), K_b, K, C, R, S, stride, pad, kind, dcode(out.dtype), ptr(out)))
 
 
 def rec_conv_fwd(x, wp, y, K, R, S, stride, pad, scale=None, shift=None, stats=None, act=ACT_NONE, accumulate=False,
-                 stem_hw=None):
+                 stem_hw=None, res=None):
     """y = act(scale*conv(x)+shift).  For the stem, x is the hdy_stem_prep buffer and stem_hw = (H, W) of the image."""
     xp, N, H, W, C, ldx = nhwc(x)
     yp, _, Ho, Wo, Ky, ldy = nhwc(y)
@@ -98,7 +99,11 @@ def rec_conv_fwd(x, wp, y, K, R, S, stride, pad, scale=None, shift=None, stats=N
     assert Ky == K and Ho == out_dim(H, R, stride, pad) and Wo == out_dim(W, S, stride, pad), (y.shape, K, Ho, Wo)
     out_f32 = 1 if (y.dtype == torch.float32 and x.dtype == torch.bfloat16) else 0
     assert y.dtype == x.dtype or out_f32
-    return _rec(locals(), 'hdy_conv_fwd', (xp, ldx, ptr(wp), ptr(scale), ptr(shift), yp, ldy, ptr(stats), N, H, W, C, K, R, S, stride, pad, act,
+    rp, ldr = None, 0
+    if res is not None:
+        rp, _, _, _, Kr, ldr = nhwc(res)
+        assert Kr == K and res.dtype == y.dtype and res.shape == y.shape
+    return _rec(locals(), 'hdy_conv_fwd', (xp, ldx, ptr(wp), ptr(scale), ptr(shift), rp, ldr, yp, ldy, ptr(stats), N, H, W, C, K, R, S, stride, pad, act,
                              int(accumulate), dcode(x.dtype), out_f32, stem))
 
 
@@ -128,8 +133,9 @@ def rec_conv_wgrad(x, dy, grad_a, grad_b, R, S, stride, pad, ws, accumulate=Fals
 
 # ------------------------------------------------------------------------------------------ BN / act
 def rec_bn_finalize(stats, mtiles, K, count, gamma, beta, rmean, rvar, scale, shift, save_mean, save_invstd,
-                    eps=BN_EPS, momentum=BN_MOMENTUM):
-    return _rec(locals(), 'hdy_bn_finalize', (ptr(stats), mtiles, K, count, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), eps, momentum, ptr(scale),
+                    eps=BN_EPS, momentum=BN_MOMENTUM, stats_ld=None):
+    """stats may be a channel slice [.., k0:k0+K] of a wider slab: stats_ld is the slab's channel count."""
+    return _rec(locals(), 'hdy_bn_finalize', (ptr(stats), K if stats_ld is None else stats_ld, mtiles, K, count, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), eps, momentum, ptr(scale),
                                 ptr(shift), ptr(save_mean), ptr(save_invstd)))
 
 
@@ -159,6 +165,23 @@ def rec_bn_act_bwd(dz, y, scale, shift, mean, invstd, dy, dgamma, dbeta, ws, acc
     assert dz.shape == y.shape == dy.shape and dz.dtype == y.dtype == dy.dtype and ws.numel() >= bn_bwd_ws_floats(N * H * W, K)
     return _rec(locals(), 'hdy_bn_act_bwd', (dzp, lddz, yp, ldy, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), dyp, lddy, ptr(dgamma), ptr(dbeta),
                                int(accumulate), N * H * W, K, act, dcode(dz.dtype), ptr(ws)))
+
+
+def rec_colsum(dz, out, ws, accumulate=False):
+    dzp, N, H, W, K, lddz = nhwc(dz)
+    assert out.dtype == torch.float32 and out.numel() >= K and ws.numel() >= bn_bwd_ws_floats(N * H * W, K)
+    return _rec(locals(), 'hdy_colsum', (dzp, lddz, N * H * W, K, ptr(out), int(accumulate), dcode(dz.dtype), ptr(ws)))
+
+
+def rec_det_grad_pack(g, out, na, no):
+    """g: fp32 gradient of the logits view (B, na, ny, nx, no), any strides -> out NHWC [B, ny, nx, ld]."""
+    require_gpu(g)
+    B, na_, ny, nx, no_ = g.shape
+    assert (na_, no_) == (na, no) and g.dtype == torch.float32
+    op, _, _, _, _, ldo = nhwc(out)
+    assert out.shape[:3] == (B, ny, nx) and out.is_contiguous()
+    return _rec(locals(), 'hdy_det_grad_pack', (g.data_ptr(), g.stride(0), g.stride(1), g.stride(2), g.stride(3), g.stride(4), op,
+                                                out.shape[3], B, na, ny, nx, no, dcode(out.dtype)))
 
 
 def rec_add_inplace(out, a):

@@ -1,0 +1,478 @@
+"""Static execution plan for the metayolo backbone + neck + detection convs on MI355X.
+
+The reference runs the network as ~200 eager ATen calls per forward plus autograd's dynamic graph
+(metayolo/models/yolov5.py:53-59, :68-77; layers.py:37-38; train.py:457,472).  Here the module tree is traced
+ONCE per (input shape, arithmetic type, train/eval) into a flat list of kernel launches over pre-allocated
+NHWC buffers; forward and backward are replays of two launch lists.  What the tracing decides:
+
+  * layout      activations NHWC bf16/fp32 in HBM, never NCHW; torch.cat along C is free: every producer writes
+                straight into its channel slice of the concat buffer (pixel pitch = concat width).
+  * fusion      C3's cv1 and cv2 (two 1x1 convs on the same input) become ONE conv with K = 2c_ (train mode);
+                BN statistics come out of the conv kernel's epilogue as per-tile slabs; normalise+SiLU(+residual)
+                is one streaming pass; in eval mode BN is folded into the conv epilogue (scale/shift/SiLU/residual).
+  * backward    reverse replay: [BN+SiLU backward -> dy] -> wgrad -> dgrad, gradients of multiply-consumed tensors are
+                accumulated in the dgrad epilogue (no add kernels); the Bottleneck shortcut aliases gradient storage.
+  * gradients   all parameter gradients live in one flat fp32 buffer (views per parameter) so data-parallel
+                all-reduce is a few large RCCL calls (hd_yolo_amd/parallel.py).
+
+torch is used for memory (torch.empty), streams and the autograd hook-in (one custom Function around the whole
+plan); every arithmetic op inside is a HIP kernel from libhdyolo_hip.so.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+
+
+class Val:
+    """A tensor of the traced graph: logical NHWC shape + where it lives (buffer, channel offset)."""
+    __slots__ = ('n', 'h', 'w', 'c', 'name', 'buf', 'off', 'cat', 'parts', 'gbuf', 'goff', 'ginit', 'galias', 'gfinal',
+                 'order', 'last_use', 'index')
+
+    def __init__(self, n, h, w, c, name, order):
+        self.n, self.h, self.w, self.c, self.name, self.order = n, h, w, c, name, order
+        self.buf = self.gbuf = self.cat = self.galias = self.gfinal = None
+        self.off = self.goff = 0
+        self.parts = None          # for concat values: [(Val, offset)]
+        self.ginit = False
+        self.last_use = order
+        self.index = None          # model-level node index, when this is a layer output
+
+    def t(self):
+        return self.buf[..., self.off:self.off + self.c]
+
+    def g(self):
+        return self.gbuf[..., self.goff:self.goff + self.c]
+
+    def gread(self):
+        return self.gfinal if self.gfinal is not None else self.g()
+
+
+class ConvUnit:
+    def __init__(self, mods, x, res, outs, stem):
+        self.mods, self.x, self.res, self.outs, self.stem = mods, x, res, outs, stem
+        c = mods[0].conv
+        self.k, self.s, self.p = c.kernel_size[0], c.stride[0], c.padding[0]
+        self.Ks = [m.conv.out_channels for m in mods]
+        self.K = sum(self.Ks)
+        self.C = c.in_channels
+        self.has_bn = hasattr(mods[0], 'bn')
+        self.act = act_code(mods[0].act)
+
+
+class DetUnit:
+    def __init__(self, conv, x, level):
+        self.conv, self.x, self.level = conv, x, level
+        self.K = conv.out_channels
+        self.Kp = (self.K + 7) // 8 * 8
+
+
+class PoolUnit:
+    def __init__(self, x, outs):
+        self.x, self.outs = x, outs
+
+
+class UpUnit:
+    def __init__(self, x, out):
+        self.x, self.out = x, out
+
+
+def act_code(act):
+    if isinstance(act, nn.SiLU):
+        return ops.ACT_SILU
+    if isinstance(act, nn.Identity):
+        return ops.ACT_NONE
+    raise _lib.HdyError(f'activation {type(act).__name__} has no HIP kernel on this path (SiLU / Identity only)')
+
+
+def _is(m, name):
+    return type(m).__name__ == name
+
+
+class Plan:
+    def __init__(self, backbone, neck, head, shape, dtype, training, device, grad_store=None):
+        """backbone / neck: the metayolo CSPDarkNet / FPN containers (neck, head may be None);
+        head: Detect module or None; shape = (B, 3, H, W)."""
+        self.dtype, self.training, self.device = dtype, training, device
+        self.B, self.Cin, self.H, self.W = shape
+        self.input = None
+        self.vals, self.units = [], []
+        self.grad_store = grad_store
+        self._order = 0
+        self._trace(backbone, neck, head)
+        self._allocate()
+        self.fwd = self._compile_forward()
+        self.bwd = self._compile_backward() if training else None
+
+    # ------------------------------------------------------------------ tracing
+    def _val(self, n, h, w, c, name):
+        v = Val(n, h, w, c, name, self._order)
+        self._order += 1
+        self.vals.append(v)
+        return v
+
+    def _use(self, v):
+        v.last_use = self._order
+
+    def _conv(self, mods, x, res=None, stem=False):
+        c0 = mods[0].conv
+        for m in mods:
+            c = m.conv
+            if c.groups != 1 or c.dilation[0] != 1 or c.kernel_size[0] != c.kernel_size[1] or c.stride[0] != c.stride[1]:
+                raise _lib.HdyError('grouped / dilated / non-square convolutions are outside the hot path')
+            assert (c.kernel_size, c.stride, c.padding, c.in_channels) == (c0.kernel_size, c0.stride, c0.padding, c0.in_channels)
+        k, s, p = c0.kernel_size[0], c0.stride[0], c0.padding[0]
+        if stem:
+            n, h, w = self.B, self.H, self.W
+        else:
+            n, h, w = x.n, x.h, x.w
+            self._use(x)
+        if res is not None:
+            self._use(res)
+        ho, wo = ops.out_dim(h, k, s, p), ops.out_dim(w, k, s, p)
+        outs = [self._val(n, ho, wo, m.conv.out_channels, 'conv') for m in mods]
+        u = ConvUnit(mods, x, res, outs, stem)
+        self.units.append(u)
+        if res is not None and self.training:
+            if res.cat is not None or res.parts is not None:
+                raise _lib.HdyError('shortcut from a concat member is not plannable')
+            res.galias = outs[0]
+        return outs
+
+    def _concat(self, vals):
+        n, h, w = vals[0].n, vals[0].h, vals[0].w
+        cat = self._val(n, h, w, sum(v.c for v in vals), 'cat')
+        off, cat.parts = 0, []
+        for v in vals:
+            if v.cat is not None or v.parts is not None:
+                raise _lib.HdyError('a tensor may sit in one concat only (nested / shared concats are not planned)')
+            assert (v.n, v.h, v.w) == (n, h, w)
+            v.cat, v.off = cat, off
+            cat.parts.append((v, off))
+            off += v.c
+            self._use(v)
+        return cat
+
+    def _module(self, m, x):
+        t = type(m).__name__
+        if t == 'Conv':
+            return self._conv([m], x, stem=(x is None))[0]
+        if t == 'Bottleneck':
+            h = self._conv([m.cv1], x)[0]
+            return self._conv([m.cv2], h, res=x if m.add else None)[0]
+        if t == 'C3':
+            fuse = self.training and hasattr(m.cv1, 'bn') and hasattr(m.cv2, 'bn')
+            if fuse:
+                a, b = self._conv([m.cv1, m.cv2], x)
+            else:
+                a, b = self._conv([m.cv1], x)[0], self._conv([m.cv2], x)[0]
+            for bt in m.m:
+                a = self._module(bt, a)
+            return self._conv([m.cv3], self._concat([a, b]))[0]
+        if t == 'SPPF':
+            if m.m.kernel_size != 5:
+                raise _lib.HdyError('SPPF pooling kernel must be 5')
+            a = self._conv([m.cv1], x)[0]
+            self._use(a)
+            ys = [self._val(a.n, a.h, a.w, a.c, 'pool') for _ in range(3)]
+            self.units.append(PoolUnit(a, ys))
+            return self._conv([m.cv2], self._concat([a] + ys))[0]
+        if t == 'Upsample':
+            if m.mode != 'nearest' or float(m.scale_factor) != 2.0:
+                raise _lib.HdyError('only 2x nearest upsampling is on the hot path')
+            self._use(x)
+            out = self._val(x.n, 2 * x.h, 2 * x.w, x.c, 'up')
+            self.units.append(UpUnit(x, out))
+            return out
+        if t == 'Concat':
+            if m.d != 1:
+                raise _lib.HdyError('Concat along a dimension other than channels')
+            return self._concat(x)
+        if t == 'Sequential':
+            for sub in m:
+                x = self._module(sub, x)
+            return x
+        raise _lib.HdyError(f'module {t} is outside the metayolo hot path (no HIP plan for it)')
+
+    def _trace(self, backbone, neck, head):
+        outs = {}
+        first = backbone[0]
+        is_stem = (type(first).__name__ == 'Conv' and self.Cin == 3 and first.conv.kernel_size == (6, 6)
+                   and first.conv.stride == (2, 2) and first.conv.padding == (2, 2))
+        if is_stem:
+            x = None                       # the 6x6/s2 stem reads the padded 4-channel image directly
+        else:
+            if self.Cin % 8:
+                raise _lib.HdyError(f'input with {self.Cin} channels: only the 6x6/s2 RGB stem or channel counts that are '
+                                    'multiples of 8 can enter a HIP plan')
+            x = self.input = self._val(self.B, self.H, self.W, self.Cin, 'input')
+        for i, m in enumerate(backbone):
+            x = self._module(m, x)
+            x.index = i
+            outs[i] = x
+        self.feature_keys = list(getattr(backbone, 'save', [len(backbone) - 1]))
+        if neck is not None:
+            cur = None
+            for m in neck:
+                f = m.f
+                if isinstance(f, int):
+                    src = cur if f == -1 else outs[f]
+                else:
+                    src = [cur if j == -1 else outs[j] for j in f]
+                cur = self._module(m, src)
+                cur.index = m.i
+                outs[m.i] = cur
+            self.feature_keys = list(neck.save)
+        self.outs = outs
+        self.det_units = []
+        if head is not None:
+            f = head.f if isinstance(head.f, (list, tuple)) else [head.f]
+            for l, (j, conv) in enumerate(zip(f, head.m)):
+                self._use(outs[j])
+                u = DetUnit(conv, outs[j], l)
+                self.units.append(u)
+                self.det_units.append(u)
+            self.na, self.no = head.na, head.no
+
+    # ------------------------------------------------------------------ memory
+    def _new(self, *shape, dtype=None, zero=False):
+        f = torch.zeros if zero else torch.empty
+        return f(shape, dtype=dtype or self.dtype, device=self.device)
+
+    def _allocate(self):
+        dt = self.dtype
+        for v in self.vals:
+            if v.parts is not None or v.cat is None:
+                v.buf = self._new(v.n, v.h, v.w, v.c)
+        for v in self.vals:
+            if v.cat is not None:
+                v.buf = v.cat.buf
+        self.prep = self._new(self.B, self.H + 4, self.W + 4, 4)
+        f32 = torch.float32
+        max_stats = max_dy = max_wg = max_bnws = 1
+        for u in self.units:
+            if isinstance(u, ConvUnit):
+                o = u.outs[0]
+                M = o.n * o.h * o.w
+                kind = ops.PACK_STEM if u.stem else ops.PACK_FWD
+                if self.training or len(u.mods) > 1:
+                    u.wp = ops.pack_alloc(u.K, u.C, u.k, u.k, u.s, u.p, kind, dt, self.device)
+                else:
+                    u.wp = ops.pack_alloc(u.K, u.C, u.k, u.k, u.s, u.p, kind, dt, self.device)
+                u.scale, u.shift = self._new(u.K, dtype=f32), self._new(u.K, dtype=f32)
+                if self.training:
+                    if not u.has_bn:
+                        raise _lib.HdyError('training a fused (BN-folded) model is not supported: build the model unfused')
+                    u.yraw = self._new(o.n, o.h, o.w, u.K)
+                    u.mean, u.invstd = self._new(u.K, dtype=f32), self._new(u.K, dtype=f32)
+                    u.mtiles = _lib.query('hdy_conv_mtiles', M)
+                    max_stats = max(max_stats, u.mtiles * 2 * u.K)
+                    max_dy = max(max_dy, M * u.K)
+                    hin, win = (self.H, self.W) if u.stem else (u.x.h, u.x.w)
+                    max_wg = max(max_wg, ops.wgrad_ws_bytes(o.n, hin, win, u.C, u.K, u.k, u.k, u.s, u.p, dt, stem=u.stem))
+                    max_bnws = max(max_bnws, ops.bn_bwd_ws_floats(M, max(u.Ks)))
+                    if not u.stem:
+                        u.wpd = ops.pack_alloc(u.K, u.C, u.k, u.k, u.s, u.p, ops.PACK_DGRAD, dt, self.device)
+            elif isinstance(u, DetUnit):
+                x = u.x
+                u.wp = ops.pack_alloc(u.K, x.c, 1, 1, 1, 0, ops.PACK_FWD, dt, self.device)
+                u.logits = self._new(x.n, x.h, x.w, u.Kp, dtype=f32, zero=True)
+                if self.training:
+                    M = x.n * x.h * x.w
+                    u.wpd = ops.pack_alloc(u.Kp, x.c, 1, 1, 1, 0, ops.PACK_DGRAD, dt, self.device)
+                    u.gdet = self._new(x.n, x.h, x.w, u.Kp)
+                    max_wg = max(max_wg, ops.wgrad_ws_bytes(x.n, x.h, x.w, x.c, u.Kp, 1, 1, 1, 0, dt))
+                    max_bnws = max(max_bnws, ops.bn_bwd_ws_floats(M, u.Kp))
+            elif isinstance(u, PoolUnit):
+                if self.training:
+                    a = u.x
+                    u.idx = [self._new(a.n, a.h, a.w, a.c, dtype=torch.uint8) for _ in range(3)]
+        if not self.training:
+            return
+        self.stats = self._new(max_stats, dtype=f32)
+        self.dy = self._new(max_dy)
+        self.wg_ws = self._new(max_wg // 4 + 16, dtype=f32)
+        self.bn_ws = self._new(max_bnws, dtype=f32)
+        # gradient storage mirrors activation storage
+        for v in self.vals:
+            if v.parts is not None or v.cat is None:
+                v.gbuf = None       # allocated below unless aliased
+        for v in reversed(self.vals):
+            if v.cat is not None:
+                continue
+            if v.galias is not None and v.parts is None:
+                continue
+            v.gbuf = self._new(v.n, v.h, v.w, v.c)
+        for v in self.vals:
+            if v.cat is not None:
+                v.gbuf, v.goff = v.cat.gbuf, v.off
+        for v in reversed(self.vals):      # shortcut inputs share the gradient storage of the block output
+            if v.galias is not None and v.cat is None:
+                o = v.galias
+                v.gbuf, v.goff = o.gbuf, o.goff
+        for u in self.units:
+            if isinstance(u, PoolUnit):
+                u.x.gfinal = self._new(u.x.n, u.x.h, u.x.w, u.x.c)
+
+    # ------------------------------------------------------------------ parameter access
+    def _bn(self, m):
+        return m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var
+
+    def _grad_views(self, p):
+        return self.grad_store.view_of(p)
+
+    # ------------------------------------------------------------------ forward
+    def _compile_forward(self):
+        recs = []
+        t = self.training
+        for u in self.units:
+            if isinstance(u, ConvUnit):
+                x = self.prep if u.stem else u.x.t()
+                stem_hw = (self.H, self.W) if u.stem else None
+                kind = ops.PACK_STEM if u.stem else ops.PACK_FWD
+                o0 = u.outs[0]
+                if t:
+                    wb = u.mods[1].conv.weight if len(u.mods) > 1 else None
+                    recs.append(ops.rec_pack(u.mods[0].conv.weight, wb, u.s, u.p, kind, u.wp))
+                    M = o0.n * o0.h * o0.w
+                    stats = self.stats[:u.mtiles * 2 * u.K].view(u.mtiles, 2, u.K)
+                    recs.append(ops.rec_conv_fwd(x, u.wp, u.yraw, u.K, u.k, u.k, u.s, u.p, stats=stats, stem_hw=stem_hw))
+                    k0 = 0
+                    for m, o in zip(u.mods, u.outs):
+                        K = m.conv.out_channels
+                        g, b, rm, rv = self._bn(m)
+                        recs.append(ops.rec_bn_finalize(stats[:, :, k0:], u.mtiles, K, M, g, b, rm, rv, u.scale[k0:], u.shift[k0:],
+                                                        u.mean[k0:], u.invstd[k0:], stats_ld=u.K))
+                        res = u.res.t() if u.res is not None else None
+                        recs.append(ops.rec_bn_act_fwd(u.yraw[..., k0:k0 + K], u.scale[k0:k0 + K], u.shift[k0:k0 + K], o.t(), res=res, act=u.act))
+                        k0 += K
+                else:
+                    m, o = u.mods[0], u.outs[0]
+                    recs.append(ops.rec_pack(m.conv.weight, None, u.s, u.p, kind, u.wp))
+                    if u.has_bn:
+                        g, b, rm, rv = self._bn(m)
+                        recs.append(ops.rec_bn_eval_coeffs(g, b, rm, rv, u.scale, u.shift))
+                        scale, shift = u.scale, u.shift
+                    else:
+                        scale, shift = None, m.conv.bias
+                    res = u.res.t() if u.res is not None else None
+                    recs.append(ops.rec_conv_fwd(x, u.wp, o.t(), u.K, u.k, u.k, u.s, u.p, scale=scale, shift=shift, act=u.act, stem_hw=stem_hw,
+                                                 res=res))
+            elif isinstance(u, PoolUnit):
+                idx = u.idx if t else None
+                recs.append(ops.rec_sppf_pool_fwd(u.x.t(), u.outs[0].t(), u.outs[1].t(), u.outs[2].t(), idx))
+            elif isinstance(u, UpUnit):
+                recs.append(ops.rec_upsample_fwd(u.x.t(), u.out.t()))
+            elif isinstance(u, DetUnit):
+                recs.append(ops.rec_pack(u.conv.weight, None, 1, 0, ops.PACK_FWD, u.wp))
+                recs.append(ops.rec_conv_fwd(u.x.t(), u.wp, u.logits[..., :u.K], u.K, 1, 1, 1, 0, shift=u.conv.bias))
+        return recs
+
+    def bn_counters(self):
+        return [m.bn.num_batches_tracked for u in self.units if isinstance(u, ConvUnit) and u.has_bn for m in u.mods]
+
+    def run_forward(self, images):
+        ops.require_gpu(images)
+        if images.dtype != torch.float32 or not images.is_contiguous():
+            images = images.float().contiguous()
+        assert tuple(images.shape) == (self.B, self.Cin, self.H, self.W), (images.shape, self.B, self.H, self.W)
+        assert images.shape[1] == self.Cin
+        if self.input is None:
+            ops.run([ops.rec_stem_prep(images, self.prep)])
+        else:
+            ops.run([ops.rec_nchw_to_nhwc(images, self.input.t())])
+        ops.run(self.fwd)
+        if self.training:
+            torch._foreach_add_(self.bn_counters(), 1)
+        return self.det_views()
+
+    def det_views(self):
+        views = []
+        for u in self.det_units:
+            x = u.x
+            views.append(u.logits[..., :u.K].view(x.n, x.h, x.w, self.na, self.no).permute(0, 3, 1, 2, 4))
+        return views
+
+    def feature(self, index):
+        """NCHW-shaped (channels-last strided) view of layer `index`'s output."""
+        return self.outs[index].t().permute(0, 3, 1, 2)
+
+    # ------------------------------------------------------------------ backward
+    def _contrib(self, v):
+        """Is a gradient contribution to v an accumulation?  Marks the storage initialised."""
+        if v.cat is not None:
+            if v.cat.ginit or v.ginit:
+                return True
+            v.ginit = True
+            return False
+        if v.galias is not None:
+            return True            # storage already holds the block output's gradient (shortcut identity)
+        acc = v.ginit
+        v.ginit = True
+        return acc
+
+    def _compile_backward(self):
+        recs = []
+        for v in self.vals:
+            v.ginit = False
+        for u in reversed(self.units):
+            if isinstance(u, DetUnit):
+                x = u.x
+                gw, gb = self._grad_views(u.conv.weight), self._grad_views(u.conv.bias)
+                recs.append(ops.rec_colsum(u.gdet, self._det_bias_tmp(u), self.bn_ws))
+                recs.append(ops.rec_conv_wgrad(x.t(), u.gdet, gw, None, 1, 1, 1, 0, self.wg_ws))
+                recs.append(ops.rec_pack(u.conv.weight, None, 1, 0, ops.PACK_DGRAD, u.wpd, K=u.Kp))
+                recs.append(ops.rec_conv_dgrad(u.gdet, u.wpd, x.g(), 1, 1, 1, 0, accumulate=self._contrib(x)))
+                u.gb = gb
+            elif isinstance(u, UpUnit):
+                recs.append(ops.rec_upsample_bwd(u.out.gread(), u.x.g(), accumulate=self._contrib(u.x)))
+            elif isinstance(u, PoolUnit):
+                a = u.x
+                gs = [a.g()] + [o.g() for o in u.outs]
+                recs.append(ops.rec_sppf_pool_bwd(gs[0], gs[1], gs[2], gs[3], u.idx, a.gfinal))
+            elif isinstance(u, ConvUnit):
+                o0 = u.outs[0]
+                dy = self.dy[:o0.n * o0.h * o0.w * u.K].view(o0.n, o0.h, o0.w, u.K)
+                k0 = 0
+                for m, o in zip(u.mods, u.outs):
+                    K = m.conv.out_channels
+                    recs.append(ops.rec_bn_act_bwd(o.gread(), u.yraw[..., k0:k0 + K], u.scale[k0:k0 + K], u.shift[k0:k0 + K], u.mean[k0:k0 + K],
+                                                   u.invstd[k0:k0 + K], dy[..., k0:k0 + K], self._grad_views(m.bn.weight),
+                                                   self._grad_views(m.bn.bias), self.bn_ws, act=u.act))
+                    k0 += K
+                x = self.prep if u.stem else u.x.t()
+                stem_hw = (self.H, self.W) if u.stem else None
+                ga = self._grad_views(u.mods[0].conv.weight)
+                gb = self._grad_views(u.mods[1].conv.weight) if len(u.mods) > 1 else None
+                recs.append(ops.rec_conv_wgrad(x, dy, ga, gb, u.k, u.k, u.s, u.p, self.wg_ws, stem_hw=stem_hw))
+                if not u.stem and u.x is not self.input:
+                    wb = u.mods[1].conv.weight if len(u.mods) > 1 else None
+                    recs.append(ops.rec_pack(u.mods[0].conv.weight, wb, u.s, u.p, ops.PACK_DGRAD, u.wpd))
+                    xv = u.x
+                    if xv.parts is not None:
+                        # writing the whole concat gradient: no part may already hold a partial contribution
+                        if any(pv.ginit for pv, _ in xv.parts) and not xv.ginit:
+                            raise _lib.HdyError('gradient ordering not plannable: a concat input receives gradient before the concat')
+                        acc = xv.ginit
+                        xv.ginit = True
+                    else:
+                        acc = self._contrib(xv)
+                    recs.append(ops.rec_conv_dgrad(dy, u.wpd, xv.g(), u.k, u.k, u.s, u.p, accumulate=acc))
+        return recs
+
+    def _det_bias_tmp(self, u):
+        if not hasattr(u, 'gbias_pad'):
+            u.gbias_pad = self._new(u.Kp, dtype=torch.float32)
+        return u.gbias_pad
+
+    def run_backward(self, gdets):
+        pre = []
+        for u, g in zip(self.det_units, gdets):
+            if g is None:
+                u.gdet.zero_()
+            else:
+                pre.append(ops.rec_det_grad_pack(g, u.gdet, self.na, self.no))
+        ops.run(pre)
+        ops.run(self.bwd)
+        for u in self.det_units:
+            u.gb.copy_(u.gbias_pad[:u.K])

@@ -50,16 +50,17 @@ int hdy_conv_out_dim(int in, int k, int stride, int pad);
 int hdy_conv_mtiles(long long M); /* number of BatchNorm statistic slabs hdy_conv_fwd writes for M output pixels */
 
 size_t hdy_conv_pack_elems(int K, int C, int R, int S, int stride, int pad, int kind, int dtype);
-int hdy_conv_pack(const float* w_a, int K_a, const float* w_b, int K_b, int C, int R, int S, int stride, int pad, int kind, int dtype,
-                  void* out, void* stream);
+/* Logical weight [K][C][R][S] = rows of w_a, then rows of w_b (two convs fused along K; may be NULL/0), then zero rows up to K. */
+int hdy_conv_pack(const float* w_a, int K_a, const float* w_b, int K_b, int K, int C, int R, int S, int stride, int pad, int kind,
+                  int dtype, void* out, void* stream);
 
-/* y = act(scale[k] * conv(x, w)[.., k] + shift[k]) (+= y when accumulate).  scale/shift may be NULL (1 / 0).
+/* y = act(scale[k] * conv(x, w)[.., k] + shift[k]) + res (+= y when accumulate).  scale/shift/res may be NULL (1 / 0 / none).
  * stats (optional, train-mode BN): [hdy_conv_mtiles(N*Ho*Wo)][2][K] floats, per-tile sum and sum of squares of
  * the raw convolution (before scale/shift/act).  out_f32: write fp32 even when dtype is bf16 (detection logits).
  * stem: x is the hdy_stem_prep buffer; requires C=3, R=S=6, stride=2, pad=2, ldx=4. */
-int hdy_conv_fwd(const void* x, int ldx, const void* w_packed, const float* scale, const float* shift, void* y, int ldy, float* stats,
-                 int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int act, int accumulate, int dtype, int out_f32,
-                 int stem, void* stream);
+int hdy_conv_fwd(const void* x, int ldx, const void* w_packed, const float* scale, const float* shift, const void* res, int ldr, void* y,
+                 int ldy, float* stats, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int act, int accumulate,
+                 int dtype, int out_f32, int stem, void* stream);
 
 /* dx[N][H][W][C] (+)= conv_transpose(dy[N][Ho][Wo][K], w); stride 1 or 2. */
 int hdy_conv_dgrad(const void* dy, int lddy, const void* w_packed_dgrad, void* dx, int lddx, int N, int H, int W, int C, int K, int R,
@@ -76,7 +77,7 @@ int hdy_conv_wgrad(const void* x, int ldx, const void* dy, int lddy, int N, int 
  * Replaces nn.BatchNorm2d (eps 1e-3, momentum 0.03: metayolo/models/utils_torch.py:47-49) and nn.SiLU in
  * Conv.forward (metayolo/models/layers.py:37-38), the shortcut add of Bottleneck.forward (:97), their backward,
  * and the eval-time folding of fuse_conv_and_bn (metayolo/models/utils_torch.py:79-99). */
-int hdy_bn_finalize(const float* stats, int mtiles, int K, long long count, const float* gamma, const float* beta, float* running_mean,
+int hdy_bn_finalize(const float* stats, int stats_ld, int mtiles, int K, long long count, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float eps, float momentum, float* scale, float* shift, float* save_mean, float* save_invstd,
                     void* stream);
 int hdy_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, int K,
@@ -89,6 +90,8 @@ int hdy_bn_act_bwd(const void* dz, int lddz, const void* y, int ldy, const float
                    const float* invstd, void* dy, int lddy, float* dgamma, float* dbeta, int accumulate, long long M, int K, int act,
                    int dtype, float* workspace, void* stream);
 int hdy_add_inplace(void* out, int ldo, const void* a, int lda, long long M, int K, int dtype, void* stream);
+/* out[k] (+)= sum_m dz[m][k]: bias gradient of Detect's conv (yolo_head.py:112).  workspace: hdy_bn_bwd_blocks(M)*2*K floats */
+int hdy_colsum(const void* dz, int lddz, long long M, int K, float* out, int accumulate, int dtype, float* workspace, void* stream);
 
 /* ---- SPPF pooling, upsample, layout --------------------------------------------------------------------------
  * Replaces nn.MaxPool2d(5,1,2) x3 of SPPF.forward (metayolo/models/layers.py:181-189), nn.Upsample(None,2,'nearest')
@@ -117,6 +120,9 @@ int hdy_nchw_to_nhwc(const float* src, void* dst, int ldd, int N, int C, int H, 
  * max_det <= 4096.  workspace: hdy_nms_workspace_bytes(B, N). */
 int hdy_decode(const float* det, long long sb, long long sa, long long sy, long long sx, const float* anchor_px, float stride, float* out,
                int row_offset, int rows_per_image, int level_id, int B, int na, int ny, int nx, int no, void* stream);
+/* autograd's logits gradient (b,a,y,x,o; element strides) -> NHWC [B][ny][nx][ldo] of dtype, channel a*no+o, zero padded */
+int hdy_det_grad_pack(const float* g, long long sb, long long sa, long long sy, long long sx, long long so, void* out, int ldo, int B, int na,
+                      int ny, int nx, int no, int dtype, void* stream);
 size_t hdy_nms_workspace_bytes(int B, int N);
 int hdy_nms_batched(const float* preds, int B, int N, int row, int nc, float conf, float iou, int max_det, float min_wh, int class_aware,
                     long long* keep, int* n_keep, float* out_boxes, float* out_scores, float* out_extra, float* out_conf, int* out_cls,

@@ -1,6 +1,8 @@
 import os
 import sys
 
+os.environ.setdefault('YOLOv5_VERBOSE', 'false')     # keep the layer tables out of test logs
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

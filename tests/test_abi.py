@@ -46,7 +46,7 @@ def test_pure_host_queries(lib):
 
 
 def test_invalid_arguments_return_status_not_crash(lib):
-    rc = lib.hdy_conv_fwd(None, 8, None, None, None, None, 8, None, 1, 4, 4, 8, 8, 1, 1, 1, 0, 0, 0, _lib.BF16, 0, 0, None)
+    rc = lib.hdy_conv_fwd(None, 8, None, None, None, None, 0, None, 8, None, 1, 4, 4, 8, 8, 1, 1, 1, 0, 0, 0, _lib.BF16, 0, 0, None)
     assert rc < 0 and b'null' in lib.hdy_last_error()
     rc = lib.hdy_nms_batched(None, 1, 4, 7, 1, 0.1, 2.0, 10, 2.0, 0, None, None, None, None, None, None, None, None, 0, None)
     assert rc < 0

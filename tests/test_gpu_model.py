@@ -1,0 +1,185 @@
+"""Whole-model parity on a real MI355X: metayolo.models.yolo.Model (HIP plans) against the reference's golden vectors
+and against the CPU oracle (oracle/ref_net.py) on the same seeded weights, tiles and targets.
+
+Tolerances (north star: fp32 boxes/logits within 1e-4 relative, NMS order bit-exact):
+  fp32 mode  activations / logits 1e-4 of the tensor's max magnitude; decoded boxes rtol 1e-4 + 1e-3 px;
+             loss rtol 2e-4; gradients 1e-3 of the per-tensor max (summation order differs: split-K slabs, MFMA chains);
+  bf16 mode  logits 6e-2 of max after 24 layers of bf16 operands (stated, not a parity claim), loss within 3 %.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from hd_yolo_amd import synth  # noqa: E402
+
+DEV = 'cuda:0'
+
+
+def build(variant, nc, hyp=None):
+    from metayolo.models.yolo import Model
+    model = Model(synth.make_cfg(variant, nc), hyp or synth.make_hyp())
+    sd = synth.synth_state_dict(synth.shapes_of(model), seed=0)
+    missing = model.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys
+    return model.to(DEV)
+
+
+def relmax(got, ref):
+    got, ref = torch.as_tensor(got).float().cpu(), torch.as_tensor(ref).float().cpu()
+    return ((got - ref).abs().max() / (ref.abs().max() + 1e-12)).item()
+
+
+@pytest.mark.parametrize('tag,variant', [('n_64', 'n'), ('s_128', 's')])
+def test_eval_matches_reference_golden_fp32(golden_dir, tag, variant):
+    g = np.load(os.path.join(golden_dir, f'stages_{tag}.npz'))
+    batch, size, nc = (int(v) for v in g['meta'])
+    model = build(variant, nc, synth.make_hyp(conf_thres=float(g['conf_thres']))).eval()
+    x = synth.synth_images(batch, size, seed=7).to(DEV)
+    with torch.no_grad():
+        losses, outputs = model(x)
+        eng = model._eng()
+        plan = next(iter(eng.plans.values()))
+        worst = 0.0
+        for k in g.files:
+            if k.startswith('stage_'):
+                worst = max(worst, relmax(plan.feature(int(k[6:])), g[k]))
+            elif k.startswith('neck_'):
+                worst = max(worst, relmax(plan.feature(int(k[5:])), g[k]))
+        assert worst < 1e-4, f'feature maps: {worst:.2e}'
+        dets = plan.det_views()
+        for i in range(3):
+            assert relmax(dets[i], g[f'det_{i}']) < 1e-4
+        head = model.headers['det']
+        preds = head.compute_proposals(dets)
+        for i in range(3):
+            np.testing.assert_allclose(preds[i].cpu().numpy(), g[f'pred_{i}'], rtol=1e-4, atol=1e-3)
+    assert losses == {'det': {}}
+    total = 0
+    for b in range(batch):
+        o = outputs[b]['det']
+        rb, rs, rl = g[f'out_{b}_boxes'], g[f'out_{b}_scores'], g[f'out_{b}_labels']
+        assert o['boxes'].shape == rb.shape, 'number of detections differs from the reference'
+        np.testing.assert_allclose(o['boxes'].cpu().numpy(), rb, rtol=1e-4, atol=1e-3)
+        np.testing.assert_allclose(o['scores'].cpu().numpy(), rs, rtol=1e-4, atol=1e-6)
+        assert np.array_equal(o['labels'].cpu().numpy(), rl)
+        total += len(rb)
+    assert total > 0
+
+
+def test_eval_nms_order_bit_exact_vs_oracle():
+    """Same logits -> decode -> NMS on both sides: kept rows must be identical and in identical order."""
+    from oracle.ref_net import RefNet
+    nc = 8
+    model = build('s', nc, synth.make_hyp(conf_thres=0.02)).eval()
+    x = synth.synth_images(2, 128, seed=3).to(DEV)
+    with torch.no_grad():
+        model(x)
+        plan = next(iter(model._eng().plans.values()))
+        dets = [d.contiguous() for d in plan.det_views()]
+        head = model.headers['det']
+        flat = head.decode_all(dets)
+        from metayolo.models.utils_general import nms_per_image
+        got = nms_per_image(flat, nc, 0.02, 0.45, 300)
+    net = RefNet(synth.make_cfg('s', nc), synth.make_hyp(conf_thres=0.02))
+    # feed the oracle the GPU's decoded rows so that the comparison isolates filter + sort + suppression
+    from oracle import nms_ref
+    ref = nms_ref.nms_per_image_numpy(flat.cpu().numpy(), nc, 0.02, 0.45, 300)
+    assert sum(len(r['index']) for r in ref) > 20
+    for b in range(2):
+        assert np.array_equal(got[b]['index'].cpu().numpy(), ref[b]['index'])
+        assert np.array_equal(got[b]['boxes'].cpu().numpy(), ref[b]['boxes'])
+    # and the oracle's own decode of the same logits agrees with the kernel's
+    opreds = net.decode([d.cpu() for d in dets])
+    oflat = torch.cat([torch.nn.functional.pad(p.reshape(2, -1, nc + 5), [0, 1], value=float(i)) for i, p in enumerate(opreds)], 1)
+    np.testing.assert_allclose(flat.cpu().numpy(), oflat.numpy(), rtol=1e-4, atol=1e-3)
+
+
+def test_fuse_keeps_eval_outputs(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'stages_n_64.npz'))
+    batch, size, nc = (int(v) for v in g['meta'])
+    model = build('n', nc).eval()
+    x = synth.synth_images(batch, size, seed=7).to(DEV)
+    with torch.no_grad():
+        model.fuse()
+        assert not any(hasattr(m, 'bn') for m in model.modules() if type(m).__name__ == 'Conv')
+        feats = model.features(x)
+        for k in g.files:
+            if k.startswith('fused_neck_'):
+                assert relmax(feats[int(k[11:])], g[k]) < 2e-4
+
+
+@pytest.mark.parametrize('tag,variant', [('n_64', 'n'), ('s_128', 's')])
+def test_train_step_matches_reference_golden_fp32(golden_dir, tag, variant):
+    g = np.load(os.path.join(golden_dir, f'train_{tag}.npz'))
+    batch, size, nc, nmin, nmax = (int(v) for v in g['meta'])
+    model = build(variant, nc).train()
+    x = synth.synth_images(batch, size, seed=11).to(DEV)
+    targets = synth.synth_targets(batch, size, nc, nmin=nmin, nmax=nmax, seed=5)
+    losses, outputs = model(x, targets, compute_masks=True)
+    loss = losses['det']['det_loss'] + losses['det']['mask_loss']
+    loss.backward()
+    np.testing.assert_allclose(losses['det']['det_loss'].detach().cpu().numpy(), g['loss'], rtol=2e-4)
+    for k in ('box', 'obj', 'cls'):
+        np.testing.assert_allclose(losses['det']['loss_items'][k].cpu().numpy(), g[f'loss_{k}'], rtol=2e-4)
+    sd = model.state_dict()
+    params = dict(model.named_parameters())
+    for k in g.files:
+        if k.startswith('stat:'):
+            assert relmax(sd[k[5:]], g[k]) < 1e-4, k
+        elif k.startswith('grad:'):
+            assert relmax(params[k[5:]].grad, g[k]) < 1e-3, k
+    bad = []
+    for name, (s, a, l2) in zip(g['gradsum_names'], g['gradsum']):
+        gr = params[str(name)].grad
+        assert gr is not None, name
+        got = gr.double().pow(2).sum().sqrt().item()
+        if abs(got - l2) > 2e-3 * l2 + 1e-9:
+            bad.append((str(name), got, l2))
+    assert not bad, bad[:8]
+    assert int(sd['backbone.0.bn.num_batches_tracked']) == 1
+    # a second backward without zero_grad accumulates (train.py's `accumulate` micro-steps)
+    g1 = params['backbone.1.conv.weight'].grad.clone()
+    losses, _ = model(x, synth.synth_targets(batch, size, nc, nmin=nmin, nmax=nmax, seed=5), compute_masks=True)
+    losses['det']['det_loss'].backward()
+    g2 = params['backbone.1.conv.weight'].grad
+    assert relmax(g2 - g1, g1) < 0.5 and (g2 - g1).abs().max() > 0      # second step has different BN statistics: not 2x, but added
+
+
+def test_train_step_bf16_is_close_to_fp32():
+    nc = 8
+    model = build('s', nc).train()
+    x = synth.synth_images(2, 128, seed=11).to(DEV)
+    t1 = synth.synth_targets(2, 128, nc, nmin=10, nmax=30, seed=5)
+    t2 = synth.synth_targets(2, 128, nc, nmin=10, nmax=30, seed=5)
+    ref_model = build('s', nc).train()
+    l32, _ = ref_model(x, t1)
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        l16, _ = model(x, t2)
+    a, b = l32['det']['det_loss'].item(), l16['det']['det_loss'].item()
+    assert abs(a - b) / a < 0.03, (a, b)
+    l32['det']['det_loss'].backward()
+    l16['det']['det_loss'].backward()
+    p32, p16 = dict(ref_model.named_parameters()), dict(model.named_parameters())
+    # This randomly initialised train-mode-BN network is chaotic: rounding only the WEIGHTS and the input to bf16 inside the
+    # exact fp32 pipeline already moves deep-layer gradients to cosine 0.86-0.96 (scripts/bf16_grad_check.py, measured on
+    # MI355X).  So the bf16 plan is held to: the shallowest gradient path (head) agrees to 1e-3, and the bulk of the layers
+    # stay strongly aligned.  Per-kernel bf16 exactness is what tests/test_gpu_kernels.py pins.
+    cos = {}
+    for k in p32:
+        u, v = p32[k].grad.flatten().double(), p16[k].grad.flatten().double()
+        cos[k] = (torch.dot(u, v) / (u.norm() * v.norm() + 1e-30)).item()
+    assert cos['headers.det.m.0.weight'] > 0.999 and cos['headers.det.m.2.bias'] > 0.999, cos
+    vals = sorted(cos.values())
+    assert vals[len(vals) // 2] > 0.85 and vals[0] > 0.5, (vals[0], vals[len(vals) // 2])
+
+
+def test_cpu_tensors_fail_loudly():
+    from hd_yolo_amd._lib import HdyError
+    from metayolo.models.yolo import Model
+    model = Model(synth.make_cfg('n', 2), synth.make_hyp()).eval()
+    with pytest.raises(HdyError):
+        model(torch.zeros(1, 3, 64, 64))
