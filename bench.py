@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Headline benchmark: tiles/s (640x640) forward + backward + optimizer step of the metayolo detector on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch of synthetic tiles already resident in HBM: HIP-plan forward of
+backbone + neck + detection convs (bf16 operands, fp32 accumulate), target assignment + DetLoss, HIP-plan backward (BN/SiLU
+backward, wgrad, dgrad), the RCCL gradient all-reduce when N > 1, and the SGD(Nesterov) update.  Workload = BASELINE.json
+configs[1]: yolov5s, 8 classes, batch 64 per GPU, 640x640 (weak scaling: per-GPU batch fixed).  One JSON line on rank 0.
+
+Extra objects on the line:
+  roofline      the dominant kernel (conv_igemm, bf16) on the layer the north star names — the fused 3x3 conv 64->64 at
+                80x80, batch 64 — timed live with HIP events on the launch stream; achieved = 2*N*K*C*9*Ho*Wo / t.
+  cpu_baseline  the CPU oracle (oracle/ref_net.py, a torch-fp32 port of the reference path) doing the same training step on
+                a bounded sample (a few 640x640 tiles) on this host's cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+os.environ.setdefault('YOLOv5_VERBOSE', 'false')
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from hd_yolo_amd import ops, synth  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def make_optimizer(model, hyp, batch_total):
+    """Three parameter groups and scaled weight decay as train.py:208-233."""
+    nbs = 64
+    accumulate = max(round(nbs / batch_total), 1)
+    wd = hyp['weight_decay'] * batch_total * accumulate / nbs
+    g_bn, g_w, g_b = [], [], []
+    for m in model.modules():
+        if hasattr(m, 'bias') and isinstance(m.bias, torch.nn.Parameter):
+            g_b.append(m.bias)
+        if isinstance(m, torch.nn.BatchNorm2d):
+            g_bn.append(m.weight)
+        elif hasattr(m, 'weight') and isinstance(m.weight, torch.nn.Parameter):
+            g_w.append(m.weight)
+    opt = torch.optim.SGD(g_bn, lr=hyp['lr0'], momentum=hyp['momentum'], nesterov=True)
+    opt.add_param_group({'params': g_w, 'weight_decay': wd})
+    opt.add_param_group({'params': g_b})
+    return opt
+
+
+def conv_roofline(device, iters=30):
+    """Time the bf16 conv_igemm kernel on yolov5s' 3x3 64->64 @ 80x80 layer at batch 64 (30.2 GFLOP per launch)."""
+    N, H, W, C, K = 64, 80, 80, 64, 64
+    dt = torch.bfloat16
+    x = torch.randn((N, H, W, C), device=device).to(dt)
+    w = torch.randn((K, C, 3, 3), device=device) * 0.05
+    y = torch.empty((N, H, W, K), dtype=dt, device=device)
+    wp = ops.pack_alloc(K, C, 3, 3, 1, 1, ops.PACK_FWD, dt, device)
+    mt = (N * H * W + 127) // 128
+    stats = torch.empty((mt, 2, K), dtype=torch.float32, device=device)
+    ops.run([ops.rec_pack(w, None, 1, 1, ops.PACK_FWD, wp)])
+    rec = [ops.rec_conv_fwd(x, wp, y, K, 3, 3, 1, 1, stats=stats)]
+    for _ in range(5):
+        ops.run(rec)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        ops.run(rec)
+    e1.record()
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) / iters * 1e-3
+    flops = 2.0 * N * K * C * 9 * H * W
+    ach = flops / t / 1e12
+    return {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_BF16_TFLOPS, 4),
+            'traffic': None, 'kernel': 'conv_igemm_kernel<bf16,bf16,64> fwd 3x3 64->64 @80x80 B=64 (+BN stat slabs)',
+            'us_per_launch': round(t * 1e6, 2), 'algorithmic_gflop_per_launch': round(flops / 1e9, 2)}
+
+
+def cpu_baseline(variant, nc, size, tiles=4, iters=2):
+    """Reference-path port on the host: oracle train step (forward + DetLoss + backward) on `tiles` 640x640 tiles."""
+    from oracle.ref_net import RefNet
+    torch.set_num_threads(min(16, os.cpu_count() or 1))       # a 1-GPU box owns a 16-core share of the host
+    net = RefNet(synth.make_cfg(variant, nc), synth.make_hyp())
+    sd = net.init_state()
+    for k, t in sd.items():
+        if 'running' not in k:
+            t.requires_grad_(True)
+    x = synth.synth_images(tiles, size, seed=0)
+    targets = synth.synth_targets(tiles, size, nc, seed=1)
+    times = []
+    for i in range(iters + 1):
+        t0 = time.perf_counter()
+        loss, _, _ = net.train_forward(sd, x, targets)
+        loss.backward()
+        times.append(time.perf_counter() - t0)
+        for t in sd.values():
+            t.grad = None
+    t = sorted(times[1:])[len(times[1:]) // 2]
+    return {'value': round(tiles / t, 3), 'unit': 'tiles/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'oracle/ref_net.py (torch fp32 CPU restatement of the reference path), yolov5{variant} nc={nc}, '
+                      f'{tiles} tiles {size}x{size}, fwd+DetLoss+bwd, median of {iters} after 1 warm-up'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=64, help='tiles per GPU')
+    ap.add_argument('--size', type=int, default=640)
+    ap.add_argument('--variant', default='s')
+    ap.add_argument('--nc', type=int, default=8)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+    device = torch.device('cuda', local)
+    torch.cuda.set_device(device)
+
+    from metayolo.models.yolo import Model
+    from hd_yolo_amd.parallel import DataParallel
+    hyp = synth.make_hyp()
+    model = Model(synth.make_cfg(args.variant, args.nc), hyp)
+    model.load_state_dict(synth.synth_state_dict(synth.shapes_of(model), seed=0), strict=False)
+    model = model.to(device).train()
+    if args.dtype == 'bf16':
+        model.half()                      # bf16 operands, fp32 accumulate / master weights
+    net = DataParallel(model) if world > 1 else model
+    opt = make_optimizer(model, hyp, args.batch * world)
+
+    x = synth.synth_images(args.batch, args.size, seed=rank).to(device)
+    targets = synth.synth_targets(args.batch, args.size, args.nc, seed=1 + rank)
+    for t in targets:
+        for a in t['anns']['det']:
+            a['boxes'], a['labels'] = a['boxes'].to(device), a['labels'].to(device)
+
+    # learning-rate / momentum warm-up exactly as train.py:354,436-444 (nw = max(3 epochs, 100 iterations)): weights ramp up
+    # from 0, biases down from warmup_bias_lr.  A 64-tile synthetic "epoch" is one iteration, so nw = 100.
+    nw, it = 100, [0]
+    lf = lambda e: (1 - e / 300) * (1.0 - hyp['lrf']) + hyp['lrf']          # linear schedule, epoch 0
+
+    def warm():
+        ni = it[0]
+        if ni <= nw:
+            for j, g in enumerate(opt.param_groups):
+                lo = hyp['warmup_bias_lr'] if j == 2 else 0.0
+                g['lr'] = lo + (hyp['lr0'] * lf(0) - lo) * ni / nw
+                g['momentum'] = hyp['warmup_momentum'] + (hyp['momentum'] - hyp['warmup_momentum']) * ni / nw
+        it[0] += 1
+
+    def step():
+        warm()
+        losses, _ = net(x, targets, compute_masks=False)
+        loss = losses['det']['det_loss']
+        loss.backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = tmax.item()
+    final_loss = float(loss.detach())
+
+    if rank == 0:
+        tiles = args.batch * world * args.steps
+        line = {
+            'metric': 'tiles/sec (640x640) fwd+bwd', 'value': round(tiles / dt, 2), 'unit': 'tiles/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if args.dtype == 'bf16' else 'f32', 'data': 'synthetic',
+            'config': {'workload': f'metayolo yolov5{args.variant} {args.nc}-class nuclei, {args.size}x{args.size} RGB tiles, '
+                                   f'batch {args.batch}/GPU, train step = fwd + DetLoss + bwd + all-reduce + SGD(nesterov)',
+                       'global_batch': args.batch * world, 'parallelism': f'dp{world}'},
+            'final_loss': round(final_loss, 4),
+        }
+        if not args.no_roofline:
+            line['roofline'] = conv_roofline(device)
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(args.variant, args.nc, args.size)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -6,6 +6,9 @@ import ctypes
 import os
 from ctypes import c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
 
+import torch  # noqa: F401  -- must come first: the library has to bind to the HIP runtime torch already loaded,
+#                              otherwise a second libamdhip64 gets mapped and sees no device
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'build', 'libhdyolo_hip.so')
 
@@ -27,7 +30,8 @@ SIGNATURES = {
     'hdy_conv_dgrad': (_I, [_P, _I, _P, _P, _I] + [_I] * 11 + [_P]),
     'hdy_conv_wgrad_workspace_bytes': (_Z, [_I] * 11),
     'hdy_conv_wgrad': (_I, [_P, _I, _P, _I] + [_I] * 9 + [_P, _I, _P, _I, _I, _P, _Z, _I, _I, _P]),
-    'hdy_bn_finalize': (_I, [_P, _I, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
+    'hdy_bn_finalize_workspace_bytes': (_Z, [_I, _I]),
+    'hdy_bn_finalize': (_I, [_P, _I, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P]),
     'hdy_bn_eval_coeffs': (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
     'hdy_bn_act_fwd': (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _L, _I, _I, _I, _P]),
     'hdy_bn_bwd_blocks': (_I, [_L]),

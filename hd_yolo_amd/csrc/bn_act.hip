@@ -1,7 +1,10 @@
 // BatchNorm (train / eval) + SiLU (+ residual) forward and backward around the conv kernels, gfx950.
 //
 // All of these are HBM-bound streaming kernels over NHWC tensors with explicit pixel pitches: one 16-byte
-// vector (8 bf16 / 4 f32 channels) per lane per access, fp32 math, per-channel coefficients kept in registers.
+// vector (8 bf16 / 4 f32 channels) per lane per access, fp32 math.  Thread mapping: a lane owns ONE channel
+// vector for its whole life (vc = tid % vectors_per_row, computed once in 32-bit), keeps that vector's
+// per-channel coefficients in registers and walks rows with a grid stride — no per-element integer division,
+// no per-element coefficient loads; consecutive lanes read consecutive 16-byte vectors of a row (coalesced).
 //
 //   forward (train):  conv writes raw y and per-tile (sum, sumsq) slabs  ->  bn_finalize (deterministic slab
 //                     reduction in fp64, running-stat update, scale/shift)  ->  bn_act_fwd: z = silu(y*scale+shift) [+ res]
@@ -45,9 +48,59 @@ template <> __device__ __forceinline__ i32x4 pack<bf16_t>(const float* f) {
     return u.i;
 }
 
+// v_exp_f32 + v_rcp_f32 (1 ulp): plenty for activations and far cheaper than the IEEE division sequence
+__device__ __forceinline__ float fast_sigmoid(float u) { return __builtin_amdgcn_rcpf(1.0f + __expf(-u)); }
+__device__ __forceinline__ float fast_silu(float u) { return u * fast_sigmoid(u); }
+__device__ __forceinline__ float dsilu_f(float u) {
+    const float s = fast_sigmoid(u);
+    return s * (1.0f + u * (1.0f - s));
+}
+
+// lane -> (channel vector, row lane) for a 256-thread block over rows of VCt vectors
+struct Lane {
+    int vc, rl, RL;
+    bool live;
+};
+__device__ __forceinline__ Lane lane_map(int VCt, int chunk) {
+    Lane L;
+    const int VC = min(256, VCt - chunk * 256);
+    L.RL = 256 / VC;
+    L.vc = chunk * 256 + (int)(threadIdx.x % (unsigned)VC);
+    L.rl = (int)(threadIdx.x / (unsigned)VC);
+    L.live = L.rl < L.RL;
+    return L;
+}
+
 // ---------------------------------------------------------------- finalize (forward)
+// Stage A (only for many tiles): grid (ceil(K/32), G): partial fp64 sums of a range of tiles -> part[g][2][K]
+__global__ __launch_bounds__(1024) void bn_partial_kernel(const float* __restrict__ stats, int stats_ld, int mtiles, int K, int tiles_per_group,
+                                                          double* __restrict__ part) {
+    __shared__ double red[2][32][33];
+    const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
+    const int k = blockIdx.x * 32 + cl;
+    const int t0 = blockIdx.y * tiles_per_group, t1 = min(t0 + tiles_per_group, mtiles);
+    double s = 0.0, ss = 0.0;
+    if (k < K) {
+        for (int t = t0 + tl; t < t1; t += 32) {
+            s += (double)stats[((size_t)t * 2 + 0) * stats_ld + k];
+            ss += (double)stats[((size_t)t * 2 + 1) * stats_ld + k];
+        }
+    }
+    red[0][tl][cl] = s;
+    red[1][tl][cl] = ss;
+    __syncthreads();
+    if (tl == 0 && k < K) {
+        s = 0.0; ss = 0.0;
+        for (int t = 0; t < 32; ++t) { s += red[0][t][cl]; ss += red[1][t][cl]; }
+        part[((size_t)blockIdx.y * 2 + 0) * K + k] = s;
+        part[((size_t)blockIdx.y * 2 + 1) * K + k] = ss;
+    }
+}
+
+// Final stage.  Input is either the fp32 slabs (ST = float) or stage A's fp64 partials (ST = double).
 // grid = ceil(K/32), block = 32 channels x 32 tile-lanes
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ stats, int stats_ld, int mtiles, int K, double count,
+template <typename ST>
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const ST* __restrict__ stats, int stats_ld, int mtiles, int K, double count,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float* __restrict__ rmean, float* __restrict__ rvar, float eps, float momentum,
                                                            float* __restrict__ scale, float* __restrict__ shift,
@@ -98,60 +151,61 @@ __global__ void bn_eval_coeffs_kernel(const float* __restrict__ gamma, const flo
 template <typename T>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, const T* __restrict__ res, int ldr,
-                                                         T* __restrict__ z, int ldz, long long M, int K, int act) {
+                                                         T* __restrict__ z, int ldz, int M, int K, int act) {
     constexpr int VE = VT<T>::VE;
-    const int VC = K / VE;
-    const long long total = M * VC;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-        const long long m = idx / VC;
-        const int c = (int)(idx - m * VC) * VE;
-        float v[VE], r[VE];
-        unpack<T>(*(const i32x4*)(y + m * ldy + c), v);
-        if (res) unpack<T>(*(const i32x4*)(res + m * ldr + c), r);
+    const int VCt = K / VE;
+    for (int chunk = 0; chunk * 256 < VCt; ++chunk) {
+        const Lane L = lane_map(VCt, chunk);
+        if (!L.live) continue;
+        const int c = L.vc * VE;
+        float sc[VE], sh[VE];
 #pragma unroll
-        for (int i = 0; i < VE; ++i) {
-            float u = v[i] * scale[c + i] + shift[c + i];
-            if (act == 1) u = silu_f(u);
-            if (res) u += r[i];
-            v[i] = u;
+        for (int i = 0; i < VE; ++i) { sc[i] = scale[c + i]; sh[i] = shift[c + i]; }
+        for (int m = blockIdx.x * L.RL + L.rl; m < M; m += gridDim.x * L.RL) {
+            float v[VE], r[VE];
+            unpack<T>(*(const i32x4*)(y + (size_t)m * ldy + c), v);
+            if (res) unpack<T>(*(const i32x4*)(res + (size_t)m * ldr + c), r);
+#pragma unroll
+            for (int i = 0; i < VE; ++i) {
+                float u = v[i] * sc[i] + sh[i];
+                if (act == 1) u = fast_silu(u);
+                if (res) u += r[i];
+                v[i] = u;
+            }
+            *(i32x4*)(z + (size_t)m * ldz + c) = pack<T>(v);
         }
-        *(i32x4*)(z + m * ldz + c) = pack<T>(v);
     }
 }
 
 // ---------------------------------------------------------------- backward
-__device__ __forceinline__ float dsilu_f(float u) {
-    const float s = sigmoid_f(u);
-    return s * (1.0f + u * (1.0f - s));
-}
-
-// partial[block][2][K]: sum(du), sum(du*xhat) over this block's rows.  grid.x = row blocks, grid.y = column groups.
+// partial[block][2][K]: sum(du), sum(du*xhat) over this block's rows.  grid.x = row blocks, grid.y = column chunks.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restrict__ dz, int lddz, const T* __restrict__ y, int ldy,
                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                                long long M, int K, int act, int rows_per_block, float* __restrict__ partial) {
+                                                                int M, int K, int act, int rows_per_block, float* __restrict__ partial) {
     constexpr int VE = VT<T>::VE;
     __shared__ float red[2][256 * VE];
     const int VCt = K / VE;
-    const int vc0 = blockIdx.y * 256;
-    const int VC = min(256, VCt - vc0);
-    const int RL = 256 / VC;
-    const int vc = threadIdx.x % VC, rl = threadIdx.x / VC;
-    const int c = (vc0 + vc) * VE;
+    const Lane L = lane_map(VCt, blockIdx.y);
+    const int VC = min(256, VCt - blockIdx.y * 256);
+    const int c = L.vc * VE;
     float a1[VE], a2[VE], sc[VE], sh[VE], mu[VE], is[VE];
 #pragma unroll
     for (int i = 0; i < VE; ++i) {
         a1[i] = 0.f; a2[i] = 0.f;
-        sc[i] = scale ? scale[c + i] : 1.f; sh[i] = shift ? shift[c + i] : 0.f; mu[i] = mean ? mean[c + i] : 0.f; is[i] = invstd ? invstd[c + i] : 0.f;
+        sc[i] = (scale && L.live) ? scale[c + i] : 1.f;
+        sh[i] = (shift && L.live) ? shift[c + i] : 0.f;
+        mu[i] = (mean && L.live) ? mean[c + i] : 0.f;
+        is[i] = (invstd && L.live) ? invstd[c + i] : 0.f;
     }
-    const long long mbeg = (long long)blockIdx.x * rows_per_block;
-    const long long mend = min(mbeg + rows_per_block, M);
-    if (rl < RL) {
-        for (long long m = mbeg + rl; m < mend; m += RL) {
+    const int mbeg = blockIdx.x * rows_per_block;
+    const int mend = min(mbeg + rows_per_block, M);
+    if (L.live) {
+        for (int m = mbeg + L.rl; m < mend; m += L.RL) {
             float g[VE], v[VE];
-            unpack<T>(*(const i32x4*)(dz + m * lddz + c), g);
-            if (y) unpack<T>(*(const i32x4*)(y + m * ldy + c), v);
+            unpack<T>(*(const i32x4*)(dz + (size_t)m * lddz + c), g);
+            if (y) unpack<T>(*(const i32x4*)(y + (size_t)m * ldy + c), v);
             else {
 #pragma unroll
                 for (int i = 0; i < VE; ++i) v[i] = 0.f;
@@ -164,24 +218,21 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restr
                 a2[i] += du * ((v[i] - mu[i]) * is[i]);
             }
         }
-    }
-    // reduce over row lanes: thread (rl, vc) -> red[q][rl*VC*VE + vc*VE + i]
-    if (rl < RL) {
 #pragma unroll
         for (int i = 0; i < VE; ++i) {
-            red[0][(rl * VC + vc) * VE + i] = a1[i];
-            red[1][(rl * VC + vc) * VE + i] = a2[i];
+            red[0][(L.rl * VC + (L.vc - blockIdx.y * 256)) * VE + i] = a1[i];
+            red[1][(L.rl * VC + (L.vc - blockIdx.y * 256)) * VE + i] = a2[i];
         }
     }
     __syncthreads();
     for (int j = threadIdx.x; j < VC * VE; j += 256) {
         float s1 = 0.f, s2 = 0.f;
-        for (int r = 0; r < RL; ++r) {
+        for (int r = 0; r < L.RL; ++r) {
             s1 += red[0][r * VC * VE + j];
             s2 += red[1][r * VC * VE + j];
         }
-        partial[((size_t)blockIdx.x * 2 + 0) * K + vc0 * VE + j] = s1;
-        partial[((size_t)blockIdx.x * 2 + 1) * K + vc0 * VE + j] = s2;
+        partial[((size_t)blockIdx.x * 2 + 0) * K + blockIdx.y * 256 * VE + j] = s1;
+        partial[((size_t)blockIdx.x * 2 + 1) * K + blockIdx.y * 256 * VE + j] = s2;
     }
 }
 
@@ -217,49 +268,60 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restri
                                                                const float* __restrict__ scale, const float* __restrict__ shift,
                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                const float* __restrict__ c1, const float* __restrict__ c2,
-                                                               T* __restrict__ dy, int lddy, long long M, int K, int act) {
+                                                               T* __restrict__ dy, int lddy, int M, int K, int act) {
     constexpr int VE = VT<T>::VE;
-    const int VC = K / VE;
-    const long long total = M * VC;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-        const long long m = idx / VC;
-        const int c = (int)(idx - m * VC) * VE;
-        float g[VE], v[VE];
-        unpack<T>(*(const i32x4*)(dz + m * lddz + c), g);
-        unpack<T>(*(const i32x4*)(y + m * ldy + c), v);
+    const int VCt = K / VE;
+    for (int chunk = 0; chunk * 256 < VCt; ++chunk) {
+        const Lane L = lane_map(VCt, chunk);
+        if (!L.live) continue;
+        const int c = L.vc * VE;
+        float sc[VE], sh[VE], mu[VE], is[VE], k1[VE], k2[VE];
 #pragma unroll
         for (int i = 0; i < VE; ++i) {
-            const float sc = scale[c + i];
-            float du = g[i];
-            if (act == 1) du *= dsilu_f(v[i] * sc + shift[c + i]);
-            const float xh = (v[i] - mean[c + i]) * invstd[c + i];
-            g[i] = sc * (du - c1[c + i] - xh * c2[c + i]);
+            sc[i] = scale[c + i]; sh[i] = shift[c + i]; mu[i] = mean[c + i]; is[i] = invstd[c + i];
+            k1[i] = c1[c + i]; k2[i] = c2[c + i];
         }
-        *(i32x4*)(dy + m * lddy + c) = pack<T>(g);
+        for (int m = blockIdx.x * L.RL + L.rl; m < M; m += gridDim.x * L.RL) {
+            float g[VE], v[VE];
+            unpack<T>(*(const i32x4*)(dz + (size_t)m * lddz + c), g);
+            unpack<T>(*(const i32x4*)(y + (size_t)m * ldy + c), v);
+#pragma unroll
+            for (int i = 0; i < VE; ++i) {
+                float du = g[i];
+                if (act == 1) du *= dsilu_f(v[i] * sc[i] + sh[i]);
+                const float xh = (v[i] - mu[i]) * is[i];
+                g[i] = sc[i] * (du - k1[i] - xh * k2[i]);
+            }
+            *(i32x4*)(dy + (size_t)m * lddy + c) = pack<T>(g);
+        }
     }
 }
 
 // out[m][c] (+)= a[m][c]  -- gradient accumulation between pitched NHWC views
 template <typename T>
-__global__ __launch_bounds__(256) void add_inplace_kernel(T* __restrict__ out, int ldo, const T* __restrict__ a, int lda, long long M, int K) {
+__global__ __launch_bounds__(256) void add_inplace_kernel(T* __restrict__ out, int ldo, const T* __restrict__ a, int lda, int M, int K) {
     constexpr int VE = VT<T>::VE;
-    const int VC = K / VE;
-    const long long total = M * VC;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-        const long long m = idx / VC;
-        const int c = (int)(idx - m * VC) * VE;
-        float o[VE], v[VE];
-        unpack<T>(*(const i32x4*)(out + m * ldo + c), o);
-        unpack<T>(*(const i32x4*)(a + m * lda + c), v);
+    const int VCt = K / VE;
+    for (int chunk = 0; chunk * 256 < VCt; ++chunk) {
+        const Lane L = lane_map(VCt, chunk);
+        if (!L.live) continue;
+        const int c = L.vc * VE;
+        for (int m = blockIdx.x * L.RL + L.rl; m < M; m += gridDim.x * L.RL) {
+            float o[VE], v[VE];
+            unpack<T>(*(const i32x4*)(out + (size_t)m * ldo + c), o);
+            unpack<T>(*(const i32x4*)(a + (size_t)m * lda + c), v);
 #pragma unroll
-        for (int i = 0; i < VE; ++i) o[i] += v[i];
-        *(i32x4*)(out + m * ldo + c) = pack<T>(o);
+            for (int i = 0; i < VE; ++i) o[i] += v[i];
+            *(i32x4*)(out + (size_t)m * ldo + c) = pack<T>(o);
+        }
     }
 }
 
-inline int stream_grid(long long total_vec) {
-    long long g = (total_vec + 255) / 256;
-    if (g > 256 * 16) g = 256 * 16;      // <= 16 workgroups per CU, grid-stride the rest
+// rows each block-iteration covers = 256 / min(256, VC); enough blocks for ~8 per CU, grid-stride the rest
+inline int stream_grid(long long M, int VC) {
+    const int rl = 256 / (VC < 256 ? VC : 256);
+    long long g = (M + rl - 1) / rl;
+    if (g > 256 * 8) g = 256 * 8;
     if (g < 1) g = 1;
     return (int)g;
 }
@@ -267,17 +329,31 @@ inline int stream_grid(long long total_vec) {
 }  // namespace
 
 #define VEC_OK(ptr, ld, VE) ((((uintptr_t)(ptr)) & 15) == 0 && (ld) % (VE) == 0)
+#define M_OK(M) ((M) > 0 && (M) < (1LL << 31))
 
 extern "C" {
 
+size_t hdy_bn_finalize_workspace_bytes(int mtiles, int K) { return mtiles > 256 ? (size_t)32 * 2 * K * sizeof(double) : 0; }
+
 int hdy_bn_finalize(const float* stats, int stats_ld, int mtiles, int K, long long count, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float eps, float momentum, float* scale, float* shift, float* save_mean, float* save_invstd,
-                    void* stream) {
+                    void* workspace, void* stream) {
     HDY_ARG(stats && gamma && beta && scale && shift && save_mean && save_invstd, "bn_finalize: null pointer");
     HDY_ARG(mtiles > 0 && K > 0 && count > 0 && stats_ld >= K, "bn_finalize: bad sizes");
     HDY_ARG((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running_mean/var must both be given or both null");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(K, 32)), dim3(1024), 0, (hipStream_t)stream, stats, stats_ld, mtiles, K, (double)count, gamma,
-                       beta, running_mean, running_var, eps, momentum, scale, shift, save_mean, save_invstd);
+    hipStream_t st = (hipStream_t)stream;
+    if (mtiles > 256 && workspace) {
+        // two stages: 32 groups of tiles reduced in parallel, then the usual final stage over 32 fp64 partials
+        const int G = 32, tpg = cdiv(mtiles, G);
+        double* part = (double*)workspace;
+        hipLaunchKernelGGL(bn_partial_kernel, dim3(cdiv(K, 32), G), dim3(1024), 0, st, stats, stats_ld, mtiles, K, tpg, part);
+        HDY_LAUNCH_CHECK("bn_partial");
+        hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3(cdiv(K, 32)), dim3(1024), 0, st, (const double*)part, K, cdiv(mtiles, tpg), K,
+                           (double)count, gamma, beta, running_mean, running_var, eps, momentum, scale, shift, save_mean, save_invstd);
+    } else {
+        hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3(cdiv(K, 32)), dim3(1024), 0, st, stats, stats_ld, mtiles, K, (double)count, gamma,
+                           beta, running_mean, running_var, eps, momentum, scale, shift, save_mean, save_invstd);
+    }
     HDY_LAUNCH_CHECK("bn_finalize");
     return HDY_OK;
 }
@@ -294,15 +370,15 @@ int hdy_bn_eval_coeffs(const float* gamma, const float* beta, const float* runni
 int hdy_bn_act_fwd(const void* y, int ldy, const float* scale, const float* shift, const void* res, int ldr, void* z, int ldz,
                    long long M, int K, int act, int dtype, void* stream) {
     const int VE = dtype == HDY_BF16 ? 8 : 4;
-    HDY_ARG(y && z && scale && shift && M > 0 && K > 0, "bn_act_fwd: bad args");
+    HDY_ARG(y && z && scale && shift && M_OK(M) && K > 0, "bn_act_fwd: bad args");
     HDY_ARG(K % VE == 0 && VEC_OK(y, ldy, VE) && VEC_OK(z, ldz, VE) && (!res || VEC_OK(res, ldr, VE)), "bn_act_fwd: K/pitch/alignment must be multiples of one 16-byte vector");
-    const int grid = stream_grid(M * (K / VE));
+    const int grid = stream_grid(M, K / VE);
     if (dtype == HDY_BF16)
         hipLaunchKernelGGL(bn_act_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y, ldy, scale, shift,
-                           (const bf16_t*)res, ldr, (bf16_t*)z, ldz, M, K, act);
+                           (const bf16_t*)res, ldr, (bf16_t*)z, ldz, (int)M, K, act);
     else
         hipLaunchKernelGGL(bn_act_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)y, ldy, scale, shift,
-                           (const float*)res, ldr, (float*)z, ldz, M, K, act);
+                           (const float*)res, ldr, (float*)z, ldz, (int)M, K, act);
     HDY_LAUNCH_CHECK("bn_act_fwd");
     return HDY_OK;
 }
@@ -321,7 +397,7 @@ int hdy_bn_act_bwd(const void* dz, int lddz, const void* y, int ldy, const float
                    const float* invstd, void* dy, int lddy, float* dgamma, float* dbeta, int accumulate, long long M, int K, int act,
                    int dtype, float* workspace, void* stream) {
     const int VE = dtype == HDY_BF16 ? 8 : 4;
-    HDY_ARG(dz && y && dy && scale && shift && mean && invstd && workspace && M > 0 && K > 0, "bn_act_bwd: bad args");
+    HDY_ARG(dz && y && dy && scale && shift && mean && invstd && workspace && M_OK(M) && K > 0, "bn_act_bwd: bad args");
     HDY_ARG(K % VE == 0 && VEC_OK(dz, lddz, VE) && VEC_OK(y, ldy, VE) && VEC_OK(dy, lddy, VE), "bn_act_bwd: K/pitch/alignment must be multiples of one 16-byte vector");
     const int nb = hdy_bn_bwd_blocks(M);
     const int rows = (int)((M + nb - 1) / nb);
@@ -332,21 +408,21 @@ int hdy_bn_act_bwd(const void* dz, int lddz, const void* y, int ldy, const float
     dim3 grid(nb, cdiv(K / VE, 256));
     if (dtype == HDY_BF16)
         hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dz, lddz, (const bf16_t*)y, ldy, scale,
-                           shift, mean, invstd, M, K, act, rows, partial);
+                           shift, mean, invstd, (int)M, K, act, rows, partial);
     else
         hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<float>, grid, dim3(256), 0, st, (const float*)dz, lddz, (const float*)y, ldy, scale,
-                           shift, mean, invstd, M, K, act, rows, partial);
+                           shift, mean, invstd, (int)M, K, act, rows, partial);
     HDY_LAUNCH_CHECK("bn_act_bwd_reduce");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(K, 32)), dim3(1024), 0, st, partial, nb, K, (double)M, dgamma, dbeta, accumulate, c1,
                        c2);
     HDY_LAUNCH_CHECK("bn_bwd_finalize");
-    const int g2 = stream_grid(M * (K / VE));
+    const int g2 = stream_grid(M, K / VE);
     if (dtype == HDY_BF16)
         hipLaunchKernelGGL(bn_act_bwd_apply_kernel<bf16_t>, dim3(g2), dim3(256), 0, st, (const bf16_t*)dz, lddz, (const bf16_t*)y, ldy, scale,
-                           shift, mean, invstd, c1, c2, (bf16_t*)dy, lddy, M, K, act);
+                           shift, mean, invstd, c1, c2, (bf16_t*)dy, lddy, (int)M, K, act);
     else
         hipLaunchKernelGGL(bn_act_bwd_apply_kernel<float>, dim3(g2), dim3(256), 0, st, (const float*)dz, lddz, (const float*)y, ldy, scale,
-                           shift, mean, invstd, c1, c2, (float*)dy, lddy, M, K, act);
+                           shift, mean, invstd, c1, c2, (float*)dy, lddy, (int)M, K, act);
     HDY_LAUNCH_CHECK("bn_act_bwd_apply");
     return HDY_OK;
 }
@@ -354,17 +430,17 @@ int hdy_bn_act_bwd(const void* dz, int lddz, const void* y, int ldy, const float
 // out[k] (+)= sum over the M rows of dz[m][k]  (bias gradient of the detection conv).  workspace: hdy_bn_bwd_blocks(M)*2*K floats.
 int hdy_colsum(const void* dz, int lddz, long long M, int K, float* out, int accumulate, int dtype, float* workspace, void* stream) {
     const int VE = dtype == HDY_BF16 ? 8 : 4;
-    HDY_ARG(dz && out && workspace && M > 0 && K > 0 && K % VE == 0 && VEC_OK(dz, lddz, VE), "colsum: bad args");
+    HDY_ARG(dz && out && workspace && M_OK(M) && K > 0 && K % VE == 0 && VEC_OK(dz, lddz, VE), "colsum: bad args");
     const int nb = hdy_bn_bwd_blocks(M);
     const int rows = (int)((M + nb - 1) / nb);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(nb, cdiv(K / VE, 256));
     if (dtype == HDY_BF16)
         hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dz, lddz, (const bf16_t*)nullptr, 0,
-                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, M, K, 0, rows, workspace);
+                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (int)M, K, 0, rows, workspace);
     else
         hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<float>, grid, dim3(256), 0, st, (const float*)dz, lddz, (const float*)nullptr, 0,
-                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, M, K, 0, rows, workspace);
+                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (int)M, K, 0, rows, workspace);
     HDY_LAUNCH_CHECK("colsum_reduce");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(K, 32)), dim3(1024), 0, st, workspace, nb, K, (double)M, (float*)nullptr, out, accumulate,
                        (float*)nullptr, (float*)nullptr);
@@ -374,12 +450,12 @@ int hdy_colsum(const void* dz, int lddz, long long M, int K, float* out, int acc
 
 int hdy_add_inplace(void* out, int ldo, const void* a, int lda, long long M, int K, int dtype, void* stream) {
     const int VE = dtype == HDY_BF16 ? 8 : 4;
-    HDY_ARG(out && a && M > 0 && K > 0 && K % VE == 0 && VEC_OK(out, ldo, VE) && VEC_OK(a, lda, VE), "add_inplace: bad args");
-    const int grid = stream_grid(M * (K / VE));
+    HDY_ARG(out && a && M_OK(M) && K > 0 && K % VE == 0 && VEC_OK(out, ldo, VE) && VEC_OK(a, lda, VE), "add_inplace: bad args");
+    const int grid = stream_grid(M, K / VE);
     if (dtype == HDY_BF16)
-        hipLaunchKernelGGL(add_inplace_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (bf16_t*)out, ldo, (const bf16_t*)a, lda, M, K);
+        hipLaunchKernelGGL(add_inplace_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (bf16_t*)out, ldo, (const bf16_t*)a, lda, (int)M, K);
     else
-        hipLaunchKernelGGL(add_inplace_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (float*)out, ldo, (const float*)a, lda, M, K);
+        hipLaunchKernelGGL(add_inplace_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (float*)out, ldo, (const float*)a, lda, (int)M, K);
     HDY_LAUNCH_CHECK("add_inplace");
     return HDY_OK;
 }

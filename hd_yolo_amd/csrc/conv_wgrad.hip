@@ -185,12 +185,23 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
         }
 }
 
-// grad[kofs + k][c][r][s] (+)= sum_split partial[split][k][q]
+// grad[k][c][r][s] (+)= sum_split partial[split][k][q]
 // mode 0: q = (r*S + s)*C + c          mode 1 (stem): q = r*(S*4) + s*4 + c, c < 3
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int splits, size_t slab_stride, int K, int Q, int mode, int C,
-                                    int R, int S, float* __restrict__ grad, int accumulate) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= K * Q) return;
+// block = 64 outputs x 16 split-lanes: slabs are read coalesced along q and 16 splits are in flight per output
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ partial, int splits, size_t slab_stride, int K, int Q,
+                                                            int mode, int C, int R, int S, float* __restrict__ grad, int accumulate) {
+    __shared__ float red[16][65];
+    const int ql = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + ql;
+    const bool ok = idx < K * Q;
+    float sum = 0.f;
+    if (ok)
+        for (int sp = sl; sp < splits; sp += 16) sum += partial[(size_t)sp * slab_stride + idx];
+    red[sl][ql] = sum;
+    __syncthreads();
+    if (sl != 0 || !ok) return;
+#pragma unroll
+    for (int i = 1; i < 16; ++i) sum += red[i][ql];
     const int k = idx / Q, q = idx - k * Q;
     int c, r, s;
     if (mode == 0) {
@@ -205,8 +216,6 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int split
         c = rem & 3;
         if (c >= C) return;
     }
-    float sum = 0.f;
-    for (int sp = 0; sp < splits; ++sp) sum += partial[(size_t)sp * slab_stride + idx];
     float* g = grad + (((size_t)k * C + c) * R + r) * S + s;
     *g = accumulate ? *g + sum : sum;
 }
@@ -253,7 +262,8 @@ __global__ void pack_weight_kernel(const float* __restrict__ w_a, int K_a, const
 int hdy_wgrad_plan(int K, int Q, long long P, int dtype, int* splits, int* pix_per_split) {
     const int TK = dtype == HDY_BF16 ? 64 : 32;
     const int tiles = cdiv(K, TK) * cdiv(Q, TK);
-    int s = cdiv(1536, tiles);
+    int s = cdiv(1024, tiles);
+    if (s > 512) s = 512;
     const int maxs = cdiv(P, 256);
     if (s > maxs) s = maxs;
     if (s < 1) s = 1;
@@ -289,7 +299,7 @@ int hdy_wgrad_launch(WgradArgs a, int dtype, hipStream_t st) {
 int hdy_wgrad_reduce_launch(const float* partial, int splits, size_t slab_stride, int K, int Q, int mode, int C, int R, int S, float* grad,
                             int accumulate, hipStream_t st) {
     const int n = K * Q;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, partial, splits, slab_stride, K, Q, mode, C, R, S, grad,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(n, 64)), dim3(1024), 0, st, partial, splits, slab_stride, K, Q, mode, C, R, S, grad,
                        accumulate);
     HDY_LAUNCH_CHECK("wgrad_reduce");
     return HDY_OK;

@@ -215,6 +215,14 @@ class Detect(nn.Module):
         mask_loss = torch.zeros_like(det_loss)
         return {'det_loss': det_loss, 'mask_loss': mask_loss, 'loss_items': {**items, 'mask': mask_loss.detach()}}
 
+    def _const(self, key, dev, make):
+        """small constant tensors are uploaded once per device, not once per step (each upload is a host sync)"""
+        cache = self.__dict__.setdefault('_consts', {})
+        k = (key, str(dev))
+        if k not in cache:
+            cache[k] = make().to(dev)
+        return cache[k]
+
     def matcher(self, p, gts):
         """Assign each ground-truth box (img, cx, cy, w, h; normalised) to anchors whose w/h ratio is within anchor_t and to
         the cell containing its centre plus the up-to-two nearest neighbour cells.  Returns per level
@@ -225,17 +233,17 @@ class Detect(nn.Module):
         ai = torch.arange(na, device=dev, dtype=gts.dtype).view(na, 1, 1).expand(na, nt, 1)
         rows = torch.cat([ai, rows[None].expand(na, nt, rows.shape[1])], 2)                               # (na, nt, 7)
         g = 0.5
-        shifts = torch.tensor([[0, 0], [1, 0], [0, 1], [-1, 0], [0, -1]], device=dev, dtype=gts.dtype) * g
+        shifts = self._const(('shifts',), dev, lambda: torch.tensor([[0, 0], [1, 0], [0, 1], [-1, 0], [0, -1]], dtype=gts.dtype) * g)
         tbox, tids, indices, anch = [], [], [], []
         for i, buf in enumerate(self.anchors):
             anc = buf.anchor.to(dev)
             ny, nx = p[i].shape[2:4]
-            t = rows * torch.tensor([1, 1, 1, nx, ny, nx, ny], device=dev, dtype=gts.dtype)
+            t = rows * self._const(('gain', nx, ny), dev, lambda: torch.tensor([1, 1, 1, nx, ny, nx, ny], dtype=gts.dtype))
             if nt:
                 ratio = t[:, :, 5:7] / anc[:, None]
                 t = t[torch.max(ratio, 1. / ratio).max(2)[0] < self.det_loss.hyp['anchor_t']]
                 gxy = t[:, 3:5]
-                inv = torch.tensor([nx, ny], device=dev, dtype=gts.dtype) - gxy
+                inv = self._const(('wh', nx, ny), dev, lambda: torch.tensor([nx, ny], dtype=gts.dtype)) - gxy
                 j, k = ((gxy % 1. < g) & (gxy > 1.)).T
                 l, m = ((inv % 1. < g) & (inv > 1.)).T
                 sel = torch.stack((torch.ones_like(j), j, k, l, m))

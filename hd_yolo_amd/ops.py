@@ -133,10 +133,10 @@ def rec_conv_wgrad(x, dy, grad_a, grad_b, R, S, stride, pad, ws, accumulate=Fals
 
 # ------------------------------------------------------------------------------------------ BN / act
 def rec_bn_finalize(stats, mtiles, K, count, gamma, beta, rmean, rvar, scale, shift, save_mean, save_invstd,
-                    eps=BN_EPS, momentum=BN_MOMENTUM, stats_ld=None):
+                    eps=BN_EPS, momentum=BN_MOMENTUM, stats_ld=None, ws=None):
     """stats may be a channel slice [.., k0:k0+K] of a wider slab: stats_ld is the slab's channel count."""
     return _rec(locals(), 'hdy_bn_finalize', (ptr(stats), K if stats_ld is None else stats_ld, mtiles, K, count, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), eps, momentum, ptr(scale),
-                                ptr(shift), ptr(save_mean), ptr(save_invstd)))
+                                ptr(shift), ptr(save_mean), ptr(save_invstd), ptr(ws)))
 
 
 def rec_bn_eval_coeffs(gamma, beta, rmean, rvar, scale, shift, eps=BN_EPS):

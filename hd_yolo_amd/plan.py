@@ -293,6 +293,8 @@ class Plan:
         self.dy = self._new(max_dy)
         self.wg_ws = self._new(max_wg // 4 + 16, dtype=f32)
         self.bn_ws = self._new(max_bnws, dtype=f32)
+        kmax = max(u.K for u in self.units if isinstance(u, ConvUnit))
+        self.fin_ws = self._new(32 * 2 * kmax, dtype=torch.float64)
         # gradient storage mirrors activation storage
         for v in self.vals:
             if v.parts is not None or v.cat is None:
@@ -342,7 +344,7 @@ class Plan:
                         K = m.conv.out_channels
                         g, b, rm, rv = self._bn(m)
                         recs.append(ops.rec_bn_finalize(stats[:, :, k0:], u.mtiles, K, M, g, b, rm, rv, u.scale[k0:], u.shift[k0:],
-                                                        u.mean[k0:], u.invstd[k0:], stats_ld=u.K))
+                                                        u.mean[k0:], u.invstd[k0:], stats_ld=u.K, ws=self.fin_ws))
                         res = u.res.t() if u.res is not None else None
                         recs.append(ops.rec_bn_act_fwd(u.yraw[..., k0:k0 + K], u.scale[k0:k0 + K], u.shift[k0:k0 + K], o.t(), res=res, act=u.act))
                         k0 += K

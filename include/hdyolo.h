@@ -77,9 +77,12 @@ int hdy_conv_wgrad(const void* x, int ldx, const void* dy, int lddy, int N, int 
  * Replaces nn.BatchNorm2d (eps 1e-3, momentum 0.03: metayolo/models/utils_torch.py:47-49) and nn.SiLU in
  * Conv.forward (metayolo/models/layers.py:37-38), the shortcut add of Bottleneck.forward (:97), their backward,
  * and the eval-time folding of fuse_conv_and_bn (metayolo/models/utils_torch.py:79-99). */
+/* stats: [mtiles][2][stats_ld] slabs from hdy_conv_fwd (channel slice of K).  workspace (optional, enables the parallel
+ * two-stage reduction for mtiles > 256): hdy_bn_finalize_workspace_bytes(mtiles, K) bytes, 8-byte aligned. */
+size_t hdy_bn_finalize_workspace_bytes(int mtiles, int K);
 int hdy_bn_finalize(const float* stats, int stats_ld, int mtiles, int K, long long count, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float eps, float momentum, float* scale, float* shift, float* save_mean, float* save_invstd,
-                    void* stream);
+                    void* workspace, void* stream);
 int hdy_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, int K,
                        float* scale, float* shift, void* stream);
 int hdy_bn_act_fwd(const void* y, int ldy, const float* scale, const float* shift, const void* res, int ldr, void* z, int ldz,

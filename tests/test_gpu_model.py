@@ -149,12 +149,50 @@ def test_train_step_matches_reference_golden_fp32(golden_dir, tag, variant):
     assert relmax(g2 - g1, g1) < 0.5 and (g2 - g1).abs().max() > 0      # second step has different BN statistics: not 2x, but added
 
 
+def test_three_sgd_steps_track_the_oracle():
+    """fwd + bwd + SGD(nesterov) x3 in fp32: the loss trajectory and the updated weights follow the CPU oracle."""
+    from oracle.ref_net import RefNet
+    nc, B, S = 2, 2, 64
+    cfg, hyp = synth.make_cfg('n', nc), synth.make_hyp()
+    model = build('n', nc).train()
+    net = RefNet(cfg, hyp)
+    sd = net.init_state()
+    names = [k for k in sd if 'running' not in k]
+    for k in names:
+        sd[k].requires_grad_(True)
+    params = dict(model.named_parameters())
+    opt_g = torch.optim.SGD([params[k] for k in names], lr=0.002, momentum=0.9, nesterov=True)
+    opt_c = torch.optim.SGD([sd[k] for k in names], lr=0.002, momentum=0.9, nesterov=True)
+    before = {k: sd[k].detach().clone() for k in names}
+    x = synth.synth_images(B, S, seed=11)
+    xg = x.to(DEV)
+    for step in range(3):
+        lg, _ = model(xg, synth.synth_targets(B, S, nc, nmin=3, nmax=8, seed=5))
+        lg['det']['det_loss'].backward()
+        opt_g.step()
+        opt_g.zero_grad(set_to_none=True)
+        lc, _, _ = net.train_forward(sd, x, synth.synth_targets(B, S, nc, nmin=3, nmax=8, seed=5))
+        lc.backward()
+        opt_c.step()
+        opt_c.zero_grad(set_to_none=True)
+        a, b = lg['det']['det_loss'].item(), lc.item()
+        # the tiny 64x64 / batch-2 case normalises over as few as 8 samples per channel: trajectories separate quickly,
+        # so the step size is small and the bar is on the UPDATE (delta of the weights), not on long-run agreement
+        assert abs(a - b) <= 5e-3 * abs(b), (step, a, b)
+    for k in ('backbone.0.conv.weight', 'backbone.4.cv3.conv.weight', 'neck.13.cv3.bn.weight', 'headers.det.m.1.bias'):
+        dg, dc = params[k].detach().cpu() - before[k], sd[k].detach() - before[k]
+        assert dc.abs().max() > 0 and relmax(dg, dc) < 3e-2, (k, relmax(dg, dc))
+    msd = model.state_dict()
+    assert relmax(msd['backbone.2.cv1.bn.running_var'], sd['backbone.2.cv1.bn.running_var']) < 1e-3
+    assert int(msd['backbone.2.cv1.bn.num_batches_tracked']) == 3
+
+
 def test_train_step_bf16_is_close_to_fp32():
     nc = 8
     model = build('s', nc).train()
-    x = synth.synth_images(2, 128, seed=11).to(DEV)
-    t1 = synth.synth_targets(2, 128, nc, nmin=10, nmax=30, seed=5)
-    t2 = synth.synth_targets(2, 128, nc, nmin=10, nmax=30, seed=5)
+    x = synth.synth_images(4, 256, seed=11).to(DEV)
+    t1 = synth.synth_targets(4, 256, nc, nmin=20, nmax=60, seed=5)
+    t2 = synth.synth_targets(4, 256, nc, nmin=20, nmax=60, seed=5)
     ref_model = build('s', nc).train()
     l32, _ = ref_model(x, t1)
     with torch.autocast('cuda', dtype=torch.bfloat16):
@@ -174,7 +212,7 @@ def test_train_step_bf16_is_close_to_fp32():
         cos[k] = (torch.dot(u, v) / (u.norm() * v.norm() + 1e-30)).item()
     assert cos['headers.det.m.0.weight'] > 0.999 and cos['headers.det.m.2.bias'] > 0.999, cos
     vals = sorted(cos.values())
-    assert vals[len(vals) // 2] > 0.85 and vals[0] > 0.5, (vals[0], vals[len(vals) // 2])
+    assert vals[len(vals) // 2] > 0.85 and vals[0] > 0.6, (vals[0], vals[len(vals) // 2])
 
 
 def test_cpu_tensors_fail_loudly():
