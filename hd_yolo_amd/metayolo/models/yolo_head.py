@@ -203,12 +203,24 @@ class Detect(nn.Module):
 
     # ------------------------------------------------------------------ training side
     def compute_losses(self, dets, preds, features, targets, compute_masks=False):
+        """Target rows [img, cx, cy, w, h] + one-hot labels -> matcher -> DetLoss.  The reference builds the rows image by
+        image (yolo_head.py:218-223); here the per-image box tensors are clamped in place with one multi-tensor call (the
+        reference's xyxy2xywh(clip=True) also clamps the caller's boxes) and everything else runs once on the concatenation."""
         dev = dets[0].device
-        rows = []
-        for idx, t in enumerate(targets):
-            rows.append(torch.cat([torch.full_like(t['boxes'][:, :1], idx), xyxy2xywh(t['boxes'], clip=True, eps=0.0)], -1))
-        gts = torch.cat(rows).to(dev)
-        gt_labels = torch.cat([one_hot_labels(t['labels'], self.nc) if t['labels'].dim() == 1 else t['labels'] for t in targets]).to(dev)
+        boxes = [t['boxes'] for t in targets]
+        if boxes:
+            torch._foreach_clamp_min_(boxes, 0.0)
+            torch._foreach_clamp_max_(boxes, 1.0)
+        counts = [int(b.shape[0]) for b in boxes]
+        allb = torch.cat(boxes).to(dev) if boxes else torch.zeros((0, 4), device=dev)
+        img = torch.repeat_interleave(torch.arange(len(boxes), dtype=allb.dtype), torch.tensor(counts)).to(dev)   # one small upload
+        gts = torch.stack([img, (allb[:, 0] + allb[:, 2]) / 2, (allb[:, 1] + allb[:, 3]) / 2, allb[:, 2] - allb[:, 0],
+                           allb[:, 3] - allb[:, 1]], 1)
+        labs = [t['labels'] for t in targets]
+        if all(l.dim() == 1 for l in labs):
+            gt_labels = one_hot_labels(torch.cat(labs).to(dev), self.nc)
+        else:
+            gt_labels = torch.cat([one_hot_labels(l, self.nc) if l.dim() == 1 else l for l in labs]).to(dev)
         tbox, tids, indices, anchors = self.matcher(dets, gts)
         tcls = [gt_labels[i] for i in tids]
         det_loss, items = self.det_loss(dets, tcls, tbox, indices, anchors)

@@ -1,0 +1,72 @@
+"""Per-launch timing of the training plan (yolov5s, B=64, 640, bf16): every record of the forward and backward
+launch lists is replayed `reps` times between HIP events; prints time, algorithmic FLOP/s and bytes/s per launch."""
+import os, sys, json
+os.environ.setdefault('YOLOv5_VERBOSE', 'false')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from hd_yolo_amd import synth, ops
+from metayolo.models.yolo import Model
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 640
+variant = sys.argv[3] if len(sys.argv) > 3 else 's'
+reps = 10
+m = Model(synth.make_cfg(variant, 8), synth.make_hyp())
+m.load_state_dict(synth.synth_state_dict(synth.shapes_of(m), seed=0), strict=False)
+m = m.to('cuda:0').train(); m.half()
+x = synth.synth_images(B, S, seed=0).to('cuda:0')
+t = synth.synth_targets(B, S, 8, seed=1)
+l, _ = m(x, t); l['det']['det_loss'].backward()
+plan = next(iter(m._eng().plans.values()))
+torch.cuda.synchronize()
+
+def describe(rec):
+    name, a = rec[0], rec[1]
+    if name == 'hdy_conv_fwd':
+        N, H, W, C, K, R, S_, st, pad = a[10:19]
+        Ho, Wo = ops.out_dim(H, R, st, pad), ops.out_dim(W, S_, st, pad)
+        fl = 2.0 * N * Ho * Wo * K * C * R * S_
+        by = 2.0 * (N * H * W * C + N * Ho * Wo * K)
+        return f'fwd  {C:4d}->{K:4d} k{R} s{st} @{H}x{W}', fl, by
+    if name == 'hdy_conv_dgrad':
+        N, H, W, C, K, R, S_, st, pad = a[5:14]
+        Ho, Wo = ops.out_dim(H, R, st, pad), ops.out_dim(W, S_, st, pad)
+        return f'dgrd {C:4d}<-{K:4d} k{R} s{st} @{H}x{W}', 2.0 * N * Ho * Wo * K * C * R * S_, 2.0 * (N * H * W * C + N * Ho * Wo * K)
+    if name == 'hdy_conv_wgrad':
+        N, H, W, C, K, R, S_, st, pad = a[4:13]
+        Ho, Wo = ops.out_dim(H, R, st, pad), ops.out_dim(W, S_, st, pad)
+        return f'wgrd {C:4d}x{K:4d} k{R} s{st} @{H}x{W}', 2.0 * N * Ho * Wo * K * C * R * S_, 2.0 * (N * H * W * C + N * Ho * Wo * K)
+    if name == 'hdy_bn_act_fwd':
+        M, K = a[8], a[9]
+        return f'bnfw K={K} M={M}', 0.0, 2.0 * M * K * (3 if a[4] else 2)
+    if name == 'hdy_bn_act_bwd':
+        M, K = a[13], a[14]
+        return f'bnbw K={K} M={M}', 0.0, 2.0 * M * K * 5
+    return name[4:], 0.0, 0.0
+
+rows = []
+for phase, recs in (('F', plan.fwd), ('B', plan.bwd)):
+    for rec in recs:
+        for _ in range(2):
+            ops.run([rec])
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            ops.run([rec])
+        e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / reps * 1e3
+        d, fl, by = describe(rec)
+        rows.append((phase, d, us, fl, by))
+tot = sum(r[2] for r in rows)
+print(f'sum of launches: {tot/1e3:.2f} ms')
+agg = {}
+for ph, d, us, fl, by in rows:
+    k = d.split()[0]
+    agg.setdefault(k, [0, 0.0]); agg[k][0] += 1; agg[k][1] += us
+for k, (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    print(f'  {k:10s} n={n:3d} {us/1e3:7.2f} ms')
+print('--- conv/bn launches (time us, TFLOP/s, GB/s, bound us = max(flop/2.5P, bytes/6.3T))')
+for ph, d, us, fl, by in rows:
+    if fl or by:
+        bound = max(fl / 2.5e15, by / 6.3e12) * 1e6
+        print(f'{ph} {d:34s} {us:8.1f} us  {fl/us/1e6:7.1f} TF  {by/us/1e3:7.0f} GB/s  bound {bound:6.1f} us  eff {bound/us:5.2f}')

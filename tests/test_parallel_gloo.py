@@ -1,0 +1,98 @@
+"""Data-parallel plumbing on CPU: two processes over gloo (the N > 1 path of bench.py / train.py without a GPU).
+
+Checks the properties the 8-GPU run relies on: rank 0's state is what every rank starts from; the flat-gradient
+all-reduce is a SUM (no division: DDP's mean of the WORLD_SIZE-prescaled loss) and is identical on all
+ranks whatever the bucket count; summed per-rank gradients of per-rank losses equal the single-process gradient of the
+concatenated batch for a loss of the form sum-over-images (which DetLoss * bs is, per image row)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from hd_yolo_amd import parallel
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+class _Store:
+    def __init__(self, n):
+        self.cur = torch.zeros(n)
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.manual_seed(100 + rank)                       # ranks start different on purpose
+        net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.BatchNorm2d(8), torch.nn.Conv2d(8, 4, 1))
+        net[1].running_mean.add_(rank + 1.0)
+        parallel.broadcast_state(net, 0)
+        state = torch.cat([t.detach().reshape(-1).double() for t in list(net.parameters()) + list(net.buffers())])
+        gathered = [torch.zeros_like(state) for _ in range(world)]
+        dist.all_gather(gathered, state)
+        same_start = all(torch.equal(gathered[0], g) for g in gathered)
+
+        # per-rank shard of a global batch; loss = sum over images (like DetLoss * bs)
+        g = torch.Generator().manual_seed(7)
+        x_all = torch.randn((4, 3, 8, 8), generator=g)
+        net.eval()                                          # BN statistics are per rank in training; keep the check linear
+        shard = x_all[rank * 2:(rank + 1) * 2]
+        net.zero_grad()
+        net(shard).pow(2).sum().backward()
+        params = list(net.parameters())
+        store = _Store(sum(p.numel() for p in params) + 5)   # deliberately not a multiple of the bucket alignment
+        off = 0
+        for p in params:
+            store.cur[off:off + p.numel()] = p.grad.reshape(-1)
+            off += p.numel()
+        results = []
+        for nb in (1, 3, 64):
+            s2 = _Store(store.cur.numel())
+            s2.cur.copy_(store.cur)
+            parallel.GradAllReduce(nbuckets=nb)(s2)
+            results.append(s2.cur.clone())
+        net.zero_grad()
+        net(x_all).pow(2).sum().backward()
+        ref = torch.cat([p.grad.reshape(-1) for p in params])
+        q.put((rank, same_start, [r[:ref.numel()] for r in results], ref, results[0][ref.numel():]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_broadcast_and_sum_allreduce():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=100) for _ in range(world)]
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    out.sort(key=lambda t: t[0])
+    for rank, same_start, results, ref, tail in out:
+        assert same_start, 'ranks did not start from rank 0 state'
+        for r in results:
+            torch.testing.assert_close(r, ref, rtol=1e-5, atol=1e-6)       # SUM of shards == full-batch gradient
+            assert torch.equal(r, results[0])                              # independent of bucket count
+        assert torch.equal(tail, torch.zeros_like(tail))
+    assert torch.equal(out[0][2][0], out[1][2][0]), 'ranks disagree after the all-reduce'
+
+
+def test_bucket_bounds_cover_exactly():
+    for n in (1, 1000, 1024, 7041205, 7041205 + 3):
+        for nb in (1, 4, 7, 1000000):
+            b = parallel.bucket_bounds(n, nb)
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(x[1] == y[0] for x, y in zip(b, b[1:]))
+            assert all(lo < hi for lo, hi in b)
+            assert len(b) <= max(nb, 1)
