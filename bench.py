@@ -85,7 +85,8 @@ def conv_roofline(device, iters=30):
 def cpu_baseline(variant, nc, size, tiles=4, iters=2):
     """Reference-path port on the host: oracle train step (forward + DetLoss + backward) on `tiles` 640x640 tiles."""
     from oracle.ref_net import RefNet
-    torch.set_num_threads(min(16, os.cpu_count() or 1))       # a 1-GPU box owns a 16-core share of the host
+    from hd_yolo_amd import host_cpu_quota
+    torch.set_num_threads(host_cpu_quota())                      # the cores the cgroup really grants (16 on a 1-GPU box)
     net = RefNet(synth.make_cfg(variant, nc), synth.make_hyp())
     sd = net.init_state()
     for k, t in sd.items():
@@ -135,6 +136,10 @@ def main():
     from metayolo.models.yolo import Model
     from hd_yolo_amd.parallel import DataParallel
     hyp = synth.make_hyp()
+    # the reference ships no hyp file; these are the YOLOv5 scratch defaults except warmup_bias_lr: with 50-400 synthetic
+    # boxes per tile and random weights, a 0.1 bias learning rate drives box logits to sigmoid saturation within ~25 steps
+    # (NaN in CIoU's aspect term, in the reference's autograd as well), so biases warm up from 0 like the weights
+    hyp['warmup_bias_lr'] = 0.0
     model = Model(synth.make_cfg(args.variant, args.nc), hyp)
     model.load_state_dict(synth.synth_state_dict(synth.shapes_of(model), seed=0), strict=False)
     model = model.to(device).train()
@@ -180,6 +185,20 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    if os.environ.get('HDY_BENCH_PHASES'):          # diagnostic only: serialises the phases, never used for the reported value
+        acc = [0.0, 0.0, 0.0]
+        for _ in range(5):
+            warm()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            losses, _ = net(x, targets, compute_masks=False)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            losses['det']['det_loss'].backward()
+            torch.cuda.synchronize(); t2 = time.perf_counter()
+            opt.step(); opt.zero_grad(set_to_none=True)
+            torch.cuda.synchronize(); t3 = time.perf_counter()
+            acc = [acc[0] + t1 - t0, acc[1] + t2 - t1, acc[2] + t3 - t2]
+        if rank == 0:
+            print('phases ms (fwd+loss, bwd, opt):', [round(a / 5 * 1e3, 2) for a in acc], file=sys.stderr, flush=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()

@@ -2,29 +2,40 @@
 // four parity classes of stride 2) and the 6x6/s2 stem (as 6 row-taps over a 24-wide pseudo channel).
 //
 //   y[n, oh_off + i*oh_mul, ow_off + j*ow_mul, k] (+)= act( scale[k] * SUM_{t,c} x[n, i*ih_mul + dh0 + t/TW,
-//                                                     j*iw_mul + dw0 + t%TW, c] * w[k][t][c] + shift[k] )
+//                                                     j*iw_mul + dw0 + t%TW, c] * w[k][t][c] + shift[k] ) + res
 //
 // Activations are NHWC with an explicit pixel pitch (ldx / ldy elements), so a tensor may be a channel
 // slice of a wider concat buffer; out-of-image taps read as zero.  GEMM view: M = N*Ho*Wo pixels,
 // N = K output channels, Kd = T*C.  Weights are pre-packed [Kpad][Kdp] (K-contiguous per output channel,
-// zero padded), see pack.hip.
+// zero padded), see conv_wgrad.hip:pack_weight_kernel.
 //
-// Tiling (CDNA4): 256 threads = 4 waves as 2(M) x 2(N); block tile 128 x BN x 128 bytes of K; each wave owns
-// (64 x BN/2) as 16x16 MFMA tiles.  One template serves both arithmetic types: LDS rows are 128 B
-// (64 bf16 / 32 f32), a fragment is one 16-byte ds_read_b128 per lane, and mma16() is one
-// v_mfma_f32_16x16x32_bf16 or four v_mfma_f32_16x16x4_f32 (exact fp32, used for the 1e-4 parity mode).
-// LDS chunk index is XOR-swizzled with (row>>1)&7 so the 16 rows of a fragment read hit 16 distinct
-// 16-byte slots (conflict-free ds_read_b128).  Register-staged double buffering: global loads for
-// k-block kb+1 are issued before the MFMAs of kb and written to the other LDS buffer after them.
+// CDNA4 mapping
+//  * 256 threads = 4 waves as 2(M) x 2(N); block tile 128 x BN x (128 bytes of K); each wave owns 64 x BN/2 as
+//    16x16 MFMA tiles.  One template serves both arithmetic types: LDS rows are 128 B (64 bf16 / 32 f32), a
+//    fragment is one 16-byte ds_read_b128 per lane, mma16() is one v_mfma_f32_16x16x32_bf16 or four
+//    v_mfma_f32_16x16x4_f32 (exact fp32: the 1e-4 parity mode).
+//  * staging is LDS-DMA (global_load_lds_dwordx4): no staging VGPRs, no ds_write pass (ds_write_b128 moves
+//    ~79 B/clk/CU and was the limiter of the register-staged version).  The DMA writes LDS linearly
+//    (wave base + lane*16), so the XOR swizzle that makes the fragment reads conflict-free is applied to the
+//    SOURCE address: lane l of a row fetches logical chunk (l&7) ^ ((row>>1)&7).  Padding / tail lanes fetch
+//    from a 16-byte zero page instead of being masked (a masked lane would leave stale LDS bytes).
+//  * persistent workgroups: each block walks a contiguous range of output tiles; the loader runs one k-block
+//    ahead of the MFMAs ACROSS tile boundaries, so the 1x1 layers (one or two k-blocks per tile) still overlap
+//    their loads with compute and the per-launch ramp is paid once.  Tile ranges follow the XCD-aware order,
+//    so the n-tiles of one m-tile and neighbouring m-tiles (3x3 halos) share an XCD's L2.
+//  * epilogue: accumulators -> (scale, shift, SiLU) -> bf16 -> XOR-swizzled LDS tile -> 16-byte coalesced
+//    row stores (+ residual / accumulate on the way out).  fp32 outputs and ragged K use a direct path.
 //
-// Train-mode BatchNorm support: when `stats` is given, each block also writes per-channel partial
-// sum / sum-of-squares of its fp32 accumulators (rows >= M are zero by construction) to
-// stats[mtile][2][K]; bn_finalize reduces the slabs deterministically (no atomics).
+// Train-mode BatchNorm: with `stats`, each tile also writes per-channel partial sum / sum-of-squares of its
+// fp32 accumulators (rows >= M are zero by construction) to stats[mtile][2][K]; bn_finalize reduces the slabs
+// deterministically (no atomics).
 //
 // Reference semantics replaced: nn.Conv2d inside metayolo/models/layers.py:31 (Conv), :92-93 (Bottleneck),
 // :124-126 (C3), :179-180 (SPPF), yolo_head.py:112 (det conv), and autograd's conv backward-data.
 #include "common.h"
 #include "hdyolo_internal.h"
+
+__device__ uint4 g_hdy_zero16[4];   // zero page for padded / out-of-range 16-byte fetches
 
 namespace {
 
@@ -46,6 +57,11 @@ template <> __device__ __forceinline__ f32x4 mma16<float>(const V16& a, const V1
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
+__device__ __forceinline__ void glds16(const void* g, unsigned char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g,
+                                     (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
+}
+
 constexpr int BM = 128;
 
 template <typename T, typename OT, int BN>
@@ -56,92 +72,259 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     constexpr int NT = BN / 32;          // 16-col tiles per wave
     constexpr int AR = BM / 32;          // A rows staged per thread
     constexpr int BR = BN / 32;          // B rows staged per thread
-    constexpr int ASZ = BM * 128, BSZ = BN * 128;
+    constexpr int ASZ = BM * 128, BSZ = BN * 128, STAGE = ASZ + BSZ;
+    constexpr bool VEC_OUT = sizeof(OT) == 2;
 
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* sA = smem;                 // [2][BM][128]
-    unsigned char* sB = smem + 2 * ASZ;       // [2][BN][128]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2][A | B]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fq = lane >> 4;
     const int ntiles = p.ntiles;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int mtile = bid / ntiles, ntile = bid - mtile * ntiles;
-    const int m0 = mtile * BM, n0 = ntile * BN;
+    const int tiles_total = p.mtiles * ntiles;
+    const int tpb = (tiles_total + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int tile_begin = xcd_remap(blockIdx.x, gridDim.x) * tpb;
+    const int tile_end = min(tile_begin + tpb, tiles_total);
+    if (tile_begin >= tile_end) return;
+    const int nkb = p.Kdp / BKE;
 
     const T* __restrict__ x = (const T*)p.x;
     const T* __restrict__ w = (const T*)p.w;
+    const unsigned char* zero = (const unsigned char*)g_hdy_zero16;
 
-    // ---- per-thread staging coordinates (fixed for the whole k loop)
-    const int c8 = tid & 7, r0 = tid >> 3;
-    int pixbase[AR], hb[AR], wb[AR];
-    const int HoWo = p.Ho * p.Wo;
-#pragma unroll
-    for (int i = 0; i < AR; ++i) {
-        const int m = m0 + r0 + 32 * i;
-        if (m < p.M) {
-            const int n = m / HoWo, rem = m - n * HoWo;
-            const int oi = rem / p.Wo, oj = rem - oi * p.Wo;
-            pixbase[i] = n * p.Hin * p.Win;
-            hb[i] = oi * p.ih_mul + p.dh0;
-            wb[i] = oj * p.iw_mul + p.dw0;
-        } else {
-            pixbase[i] = 0;
-            hb[i] = -(1 << 28);          // fails every bounds test -> zero rows
-            wb[i] = 0;
-        }
-    }
-    int cc = c8 * VE, th = 0, tw = 0;   // (tap row, tap col, channel) of this thread's chunk in k-block 0
-    while (cc >= p.C) {
-        cc -= p.C;
-        if (++tw == p.TW) { tw = 0; ++th; }
-    }
+    // ------------------------------------------------------------------ loader (runs one k-block ahead)
+    const int r0 = tid >> 3;
+    const int lc = (tid & 7) ^ ((tid >> 4) & 7);       // logical chunk fetched into physical slot (tid & 7)
+    int rm[AR], rn[AR], ri[AR], rj[AR];                  // output pixel of each staged row (general path)
+    int ld_tile = tile_begin, ld_kb = 0, ld_mtile = -1;
+    int cc = 0, th = 0, tw = 0;
     const T* wrow[BR];
-#pragma unroll
-    for (int i = 0; i < BR; ++i) wrow[i] = w + (size_t)(n0 + r0 + 32 * i) * p.Kdp + c8 * VE;
+    const int HoWo = p.Ho * p.Wo;
 
-    i32x4 ra[AR], rb[BR];
-    auto load_tiles = [&](int kb) {
+    auto loader_set_tile = [&](int t) {
+        const int mt = t / ntiles, nt = t - mt * ntiles;
+        if (mt != ld_mtile) {
+            if (ld_mtile < 0 || p.pointwise) {
 #pragma unroll
-        for (int i = 0; i < AR; ++i) {
-            const int hi = hb[i] + th, wi = wb[i] + tw;
-            const bool ok = (th < p.TH) && (unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win;
-            i32x4 v = {0, 0, 0, 0};
-            if (ok) v = *(const i32x4*)(x + ((size_t)(pixbase[i] + hi * p.Win + wi) * p.ldx + cc));
-            ra[i] = v;
+                for (int i = 0; i < AR; ++i) {
+                    rm[i] = mt * BM + r0 + 32 * i;
+                    if (!p.pointwise) {
+                        const int mc = min(rm[i], p.M - 1);
+                        rn[i] = mc / HoWo;
+                        const int rem = mc - rn[i] * HoWo;
+                        ri[i] = rem / p.Wo;
+                        rj[i] = rem - ri[i] * p.Wo;
+                    }
+                }
+            } else {
+                const int dm = (mt - ld_mtile) * BM;
+#pragma unroll
+                for (int i = 0; i < AR; ++i) {
+                    rm[i] += dm;
+                    rj[i] += dm;
+                    while (rj[i] >= p.Wo) {
+                        rj[i] -= p.Wo;
+                        if (++ri[i] == p.Ho) { ri[i] = 0; ++rn[i]; }
+                    }
+                }
+            }
+            ld_mtile = mt;
         }
 #pragma unroll
-        for (int i = 0; i < BR; ++i) rb[i] = *(const i32x4*)(wrow[i] + (size_t)kb * BKE);
-        // advance this thread's chunk to the next k-block
-        cc += BKE;
+        for (int i = 0; i < BR; ++i) wrow[i] = w + (size_t)(nt * BN + r0 + 32 * i) * p.Kdp + lc * VE;
+        cc = lc * VE; th = 0; tw = 0;
         while (cc >= p.C) {
             cc -= p.C;
             if (++tw == p.TW) { tw = 0; ++th; }
         }
     };
-    auto store_tiles = [&](int buf) {
+
+    auto loader_issue = [&](int buf) {
+        unsigned char* sa = smem + buf * STAGE;
+        unsigned char* sb = sa + ASZ;
 #pragma unroll
-        for (int i = 0; i < AR; ++i) *(i32x4*)(sA + buf * ASZ + swz(r0 + 32 * i, c8)) = ra[i];
+        for (int i = 0; i < AR; ++i) {
+            const void* src = zero;
+            if (p.pointwise) {
+                if (rm[i] < p.M && th < 1) src = x + ((size_t)rm[i] * p.ldx + cc);
+            } else {
+                const int hi = ri[i] * p.ih_mul + p.dh0 + th, wi = rj[i] * p.iw_mul + p.dw0 + tw;
+                if (rm[i] < p.M && th < p.TH && (unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win)
+                    src = x + (((size_t)rn[i] * p.Hin + hi) * p.Win + wi) * p.ldx + cc;
+            }
+            glds16(src, sa + (wave * 64 + 256 * i) * 16);
+        }
 #pragma unroll
-        for (int i = 0; i < BR; ++i) *(i32x4*)(sB + buf * BSZ + swz(r0 + 32 * i, c8)) = rb[i];
+        for (int i = 0; i < BR; ++i) glds16(wrow[i] + (size_t)ld_kb * BKE, sb + (wave * 64 + 256 * i) * 16);
+        // advance to the next k-block, possibly of the next tile
+        if (++ld_kb == nkb) {
+            ld_kb = 0;
+            if (++ld_tile < tile_end) loader_set_tile(ld_tile);
+        } else {
+            cc += BKE;
+            while (cc >= p.C) {
+                cc -= p.C;
+                if (++tw == p.TW) { tw = 0; ++th; }
+            }
+        }
     };
 
     f32x4 acc[MT][NT];
+    auto zero_acc = [&]() {
 #pragma unroll
-    for (int a = 0; a < MT; ++a)
+        for (int a = 0; a < MT; ++a)
 #pragma unroll
-        for (int b = 0; b < NT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int b = 0; b < NT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
 
-    const int nkb = p.Kdp / BKE;
-    load_tiles(0);
-    store_tiles(0);
+    // ------------------------------------------------------------------ epilogue of one finished tile
+    auto epilogue = [&](int t, unsigned char* scratch) {
+        const int mtile = t / ntiles, ntile = t - mtile * ntiles;
+        const int m0 = mtile * BM, n0 = ntile * BN;
+        if (p.stats) {
+            float* red = (float*)scratch;       // [2 (wm)][BN][2]
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                float s = 0.f, ss = 0.f;
+#pragma unroll
+                for (int a = 0; a < MT; ++a)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = acc[a][b][r];
+                        s += v;
+                        ss += v * v;
+                    }
+                s += __shfl_xor(s, 16);
+                ss += __shfl_xor(ss, 16);
+                s += __shfl_xor(s, 32);
+                ss += __shfl_xor(ss, 32);
+                if (lane < 16) {
+                    const int col = wn * (BN / 2) + b * 16 + lane;
+                    red[(wm * BN + col) * 2 + 0] = s;
+                    red[(wm * BN + col) * 2 + 1] = ss;
+                }
+            }
+            __syncthreads();
+            if (tid < BN && n0 + tid < p.K) {
+                p.stats[((size_t)mtile * 2 + 0) * p.K + n0 + tid] = red[tid * 2] + red[(BN + tid) * 2];
+                p.stats[((size_t)mtile * 2 + 1) * p.K + n0 + tid] = red[tid * 2 + 1] + red[(BN + tid) * 2 + 1];
+            }
+            __syncthreads();
+        }
+        float sc[NT], sh[NT];
+        int kcol[NT];
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            kcol[b] = n0 + wn * (BN / 2) + b * 16 + fr;
+            const bool okk = kcol[b] < p.K;
+            sc[b] = (p.scale && okk) ? p.scale[kcol[b]] : 1.0f;
+            sh[b] = (p.shift && okk) ? p.shift[kcol[b]] : 0.0f;
+        }
+        OT* __restrict__ y = (OT*)p.y;
+        if (VEC_OUT && p.vec_out) {
+            // stage the bf16 tile in LDS (32-byte column blocks XORed with (row>>2)&3 so the four 4-row groups of a
+            // store instruction land on different banks), then write full rows with 16-byte stores
+            constexpr int ROWB = BN * 2;                  // bytes per staged row
+            constexpr int CPR = ROWB / 16;                // 16-byte chunks per row
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = wm * (BM / 2) + a * 16 + fq * 4 + r;
+#pragma unroll
+                    for (int b = 0; b < NT; ++b) {
+                        float v = acc[a][b][r] * sc[b] + sh[b];
+                        if (p.act == 1) v = silu_f(v);
+                        const int col = wn * (BN / 2) + b * 16 + fr;
+                        const int chunk = (col >> 3) ^ ((((row >> 2) & 3) << 1) & (CPR - 1));
+                        *(bf16_t*)(scratch + row * ROWB + chunk * 16 + (col & 7) * 2) = (bf16_t)v;
+                    }
+                }
+            __syncthreads();
+            constexpr int RPI = 256 / CPR;                // rows per pass
+            const int ch = tid % CPR, rr = tid / CPR;
+            const int kc = n0 + ch * 8;
+            if (kc < p.K) {
+                for (int row = rr; row < BM; row += RPI) {
+                    const int m = m0 + row;
+                    if (m >= p.M) break;
+                    size_t opix;
+                    if (p.dense_out) {
+                        opix = (size_t)m;
+                    } else {
+                        const int n = m / HoWo, rem = m - n * HoWo;
+                        const int oi = rem / p.Wo, oj = rem - oi * p.Wo;
+                        opix = ((size_t)n * p.Hout + (p.oh_off + oi * p.oh_mul)) * p.Wout + (p.ow_off + oj * p.ow_mul);
+                    }
+                    const int chunk = ch ^ ((((row >> 2) & 3) << 1) & (CPR - 1));
+                    V16 v;
+                    v.i = *(const i32x4*)(scratch + row * ROWB + chunk * 16);
+                    if (p.res || p.accumulate) {
+                        float f[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] = (float)v.h[e];
+                        if (p.res) {
+                            V16 q;
+                            q.i = *(const i32x4*)((const bf16_t*)p.res + opix * p.ldr + kc);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) f[e] += (float)q.h[e];
+                        }
+                        if (p.accumulate) {
+                            V16 q;
+                            q.i = *(const i32x4*)((const bf16_t*)p.y + opix * p.ldy + kc);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) f[e] += (float)q.h[e];
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v.h[e] = (bf16_t)f[e];
+                    }
+                    *(i32x4*)((bf16_t*)p.y + opix * p.ldy + kc) = v.i;
+                }
+            }
+            __syncthreads();
+            return;
+        }
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * (BM / 2) + a * 16 + fq * 4 + r;
+                if (m >= p.M) continue;
+                size_t opix;
+                if (p.dense_out) {
+                    opix = (size_t)m;
+                } else {
+                    const int n = m / HoWo, rem = m - n * HoWo;
+                    const int oi = rem / p.Wo, oj = rem - oi * p.Wo;
+                    opix = ((size_t)n * p.Hout + (p.oh_off + oi * p.oh_mul)) * p.Wout + (p.ow_off + oj * p.ow_mul);
+                }
+                OT* yrow = y + opix * p.ldy;
+                const OT* rrow = p.res ? (const OT*)p.res + opix * p.ldr : nullptr;
+#pragma unroll
+                for (int b = 0; b < NT; ++b) {
+                    if (kcol[b] >= p.K) continue;
+                    float v = acc[a][b][r] * sc[b] + sh[b];
+                    if (p.act == 1) v = silu_f(v);
+                    if (rrow) v += to_f32<OT>(rrow[kcol[b]]);
+                    if (p.accumulate) v += to_f32<OT>(yrow[kcol[b]]);
+                    yrow[kcol[b]] = from_f32<OT>(v);
+                }
+            }
+        }
+    };
+
+    // ------------------------------------------------------------------ main loop over (tile, k-block)
+    loader_set_tile(tile_begin);
+    loader_issue(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const int fr = lane & 15, fq = lane >> 4;
-    for (int kb = 0; kb < nkb; ++kb) {
-        const int cur = kb & 1;
-        if (kb + 1 < nkb) load_tiles(kb + 1);
-        const unsigned char* a_s = sA + cur * ASZ;
-        const unsigned char* b_s = sB + cur * BSZ;
+    zero_acc();
+    int c_tile = tile_begin, c_kb = 0, cur = 0;
+    while (true) {
+        const bool more = ld_tile < tile_end;
+        if (more) loader_issue(cur ^ 1);
+        const unsigned char* a_s = smem + cur * STAGE;
+        const unsigned char* b_s = a_s + ASZ;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             V16 af[MT], bf[NT];
@@ -154,80 +337,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
                 for (int b = 0; b < NT; ++b) acc[a][b] = mma16<T>(af[a], bf[b], acc[a][b]);
         }
-        if (kb + 1 < nkb) store_tiles(cur ^ 1);
+        if (++c_kb == nkb) {
+            __syncthreads();                       // every wave is done reading stage `cur`: reuse it as scratch
+            epilogue(c_tile, smem + cur * STAGE);
+            zero_acc();
+            c_kb = 0;
+            ++c_tile;
+        }
+        if (!more) break;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-    }
-
-    // ---- BatchNorm partial statistics of the raw accumulators
-    if (p.stats) {
-        float* red = (float*)smem;       // [2 (wm)][BN][2]; the k loop ended with a barrier
-#pragma unroll
-        for (int b = 0; b < NT; ++b) {
-            float s = 0.f, ss = 0.f;
-#pragma unroll
-            for (int a = 0; a < MT; ++a)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v = acc[a][b][r];
-                    s += v;
-                    ss += v * v;
-                }
-            s += __shfl_xor(s, 16);
-            ss += __shfl_xor(ss, 16);
-            s += __shfl_xor(s, 32);
-            ss += __shfl_xor(ss, 32);
-            if (lane < 16) {
-                const int col = wn * (BN / 2) + b * 16 + lane;
-                red[(wm * BN + col) * 2 + 0] = s;
-                red[(wm * BN + col) * 2 + 1] = ss;
-            }
-        }
-        __syncthreads();
-        if (tid < BN && n0 + tid < p.K) {
-            const float s = red[tid * 2] + red[(BN + tid) * 2];
-            const float ss = red[tid * 2 + 1] + red[(BN + tid) * 2 + 1];
-            p.stats[((size_t)mtile * 2 + 0) * p.K + n0 + tid] = s;
-            p.stats[((size_t)mtile * 2 + 1) * p.K + n0 + tid] = ss;
-        }
-    }
-
-    // ---- epilogue: scale/shift, activation, optional accumulate, store
-    OT* __restrict__ y = (OT*)p.y;
-    float sc[NT], sh[NT];
-    int kcol[NT];
-#pragma unroll
-    for (int b = 0; b < NT; ++b) {
-        kcol[b] = n0 + wn * (BN / 2) + b * 16 + fr;
-        const bool okk = kcol[b] < p.K;
-        sc[b] = (p.scale && okk) ? p.scale[kcol[b]] : 1.0f;
-        sh[b] = (p.shift && okk) ? p.shift[kcol[b]] : 0.0f;
-    }
-#pragma unroll
-    for (int a = 0; a < MT; ++a) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m0 + wm * (BM / 2) + a * 16 + fq * 4 + r;
-            if (m >= p.M) continue;
-            size_t opix;
-            if (p.dense_out) {
-                opix = (size_t)m;
-            } else {
-                const int n = m / HoWo, rem = m - n * HoWo;
-                const int oi = rem / p.Wo, oj = rem - oi * p.Wo;
-                opix = ((size_t)n * p.Hout + (p.oh_off + oi * p.oh_mul)) * p.Wout + (p.ow_off + oj * p.ow_mul);
-            }
-            OT* yrow = y + opix * p.ldy;
-            const OT* rrow = p.res ? (const OT*)p.res + opix * p.ldr : nullptr;
-#pragma unroll
-            for (int b = 0; b < NT; ++b) {
-                if (kcol[b] >= p.K) continue;
-                float v = acc[a][b][r] * sc[b] + sh[b];
-                if (p.act == 1) v = silu_f(v);
-                if (rrow) v += to_f32<OT>(rrow[kcol[b]]);
-                if (p.accumulate) v += to_f32<OT>(yrow[kcol[b]]);
-                yrow[kcol[b]] = from_f32<OT>(v);
-            }
-        }
+        cur ^= 1;
     }
 }
 
@@ -239,7 +359,11 @@ int launch(const ConvArgs& a, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, OT, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
     }
-    const int grid = a.mtiles * a.ntiles;
+    // persistent grid: as many workgroups as stay resident (LDS-limited), never more than tiles
+    const int per_cu = BN == 128 ? 2 : (BN == 64 ? 3 : 4);
+    int grid = 256 * per_cu;
+    const int tiles = a.mtiles * a.ntiles;
+    if (grid > tiles) grid = tiles;
     hipLaunchKernelGGL((conv_igemm_kernel<T, OT, BN>), dim3(grid), dim3(256), smem, st, a);
     HDY_LAUNCH_CHECK("conv_igemm");
     return HDY_OK;
@@ -277,6 +401,13 @@ int hdy_conv_igemm_launch(ConvArgs a, int dtype, int out_f32, hipStream_t st) {
     a.mtiles = cdiv(a.M, BM);
     a.ntiles = cdiv(a.K, a.bn);
     if (a.dense_out) HDY_ARG(a.oh_mul == 1 && a.ow_mul == 1 && a.oh_off == 0 && a.ow_off == 0 && a.Hout == a.Ho && a.Wout == a.Wo, "conv: dense_out geometry mismatch");
+    // 1x1 / stride 1 / no padding: input pixel == output pixel, no coordinate arithmetic in the loader
+    a.pointwise = (a.TH == 1 && a.TW == 1 && a.ih_mul == 1 && a.iw_mul == 1 && a.dh0 == 0 && a.dw0 == 0 && a.Hin == a.Ho && a.Win == a.Wo &&
+                   !a.span_pixels) ? 1 : 0;
+    // coalesced 16-byte epilogue needs bf16 output, whole vectors and aligned rows
+    const bool bf16_out = dtype == HDY_BF16 && !out_f32;
+    a.vec_out = (bf16_out && a.K % 8 == 0 && a.ldy % 8 == 0 && ((uintptr_t)a.y & 15) == 0 &&
+                 (!a.res || (a.ldr % 8 == 0 && ((uintptr_t)a.res & 15) == 0))) ? 1 : 0;
     if (dtype == HDY_BF16) return out_f32 ? launch_bn<bf16_t, float>(a, st) : launch_bn<bf16_t, bf16_t>(a, st);
     return launch_bn<float, float>(a, st);
 }

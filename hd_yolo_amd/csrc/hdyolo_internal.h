@@ -19,6 +19,8 @@ struct ConvArgs {
     int act, accumulate, dense_out;
     int mtiles, ntiles, bn;
     int span_pixels;      // 1: the C-wide read deliberately spans several ldx-pitched pixels (stem)
+    int pointwise;        // derived: 1x1 stride-1 unpadded (input pixel == output pixel)
+    int vec_out;          // derived: bf16 output rows can be written with 16-byte stores
 };
 
 struct WgradArgs {

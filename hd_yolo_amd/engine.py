@@ -73,6 +73,21 @@ class _PlanFn(torch.autograd.Function):
         return None, None, None, None
 
 
+class _FusedLossFn(torch.autograd.Function):
+    """loss = hdy_det_loss(plan logits, targets); its backward replays the plan's backward launch list."""
+
+    @staticmethod
+    def forward(ctx, engine, plan, hook, loss_view):
+        ctx.engine, ctx.plan = engine, plan
+        return loss_view.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.plan.run_backward(None, scale=g)
+        ctx.engine.after_backward()
+        return None, None, None, None
+
+
 class Engine:
     """Owns the plans of one (backbone, neck, head) triple."""
 
@@ -126,6 +141,14 @@ class Engine:
         else:
             dets = plan.run_forward(x)
         return plan, list(dets)
+
+    def forward_fused_loss(self, x, dtype, head, gts, tcls):
+        """Training forward + fused loss kernel.  Returns (plan, loss[1] attached to autograd, items[3])."""
+        plan = self.plan_for(x, True, dtype)
+        plan.run_forward(x)
+        plan.fused_loss(head)(gts, tcls)
+        loss = _FusedLossFn.apply(self, plan, self.hook, plan.loss_out[0:1])
+        return plan, loss, plan.loss_out[1:4].clone()
 
     def after_backward(self):
         for fn in self.grad_hooks:

@@ -71,7 +71,15 @@ class Model(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def forward(self, x: torch.Tensor, targets=None, visualize=False, compute_masks=False):
-        plan, dets = self._eng().forward(x, self.training, _engine.compute_dtype(self, x))
+        dtype = _engine.compute_dtype(self, x)
+        if self.training and targets is not None and torch.is_grad_enabled():
+            task_id, header = next(iter(self.headers.items()))
+            if header.fused_loss_ok() and all(task_id in t['anns'] and len(t['anns'][task_id]) == 1 for t in targets):
+                # forward launch list, then target assignment + loss + logits gradient in one fused launch sequence
+                gts = [t['anns'][task_id][0] for t in targets]
+                _, losses = header.fused_losses(self._eng(), x, dtype, gts)
+                return {task_id: losses}, self.post_processing([{task_id: o} for o in []])
+        plan, dets = self._eng().forward(x, self.training, dtype)
         losses, outputs = {}, {}
         for task_id, header in self.headers.items():
             task_dets, task_gts = dets, None

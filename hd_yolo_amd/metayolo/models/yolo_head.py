@@ -202,14 +202,18 @@ class Detect(nn.Module):
         return results
 
     # ------------------------------------------------------------------ training side
-    def compute_losses(self, dets, preds, features, targets, compute_masks=False):
-        """Target rows [img, cx, cy, w, h] + one-hot labels -> matcher -> DetLoss.  The reference builds the rows image by
-        image (yolo_head.py:218-223); here the per-image box tensors are clamped in place with one multi-tensor call (the
-        reference's xyxy2xywh(clip=True) also clamps the caller's boxes) and everything else runs once on the concatenation."""
-        dev = dets[0].device
+    def fused_loss_ok(self):
+        """The single-launch-sequence loss (csrc/loss.hip) covers the default DetLoss: BCE (no focal), fixed balance."""
+        import os
+        dl = self.det_loss
+        return (os.environ.get('HDY_FUSED_LOSS', '1') != '0' and not dl.autobalance and dl.hyp['fl_gamma'] == 0 and dl.gr == 1.0
+                and not dl.sort_obj_iou and self.nc <= 128)
+
+    def flatten_targets(self, targets, dev):
+        """Per-image ann dicts -> gts (nt,5) [img, cx, cy, w, h] and one-hot labels (nt, nc+1), built once per batch."""
         boxes = [t['boxes'] for t in targets]
         if boxes:
-            torch._foreach_clamp_min_(boxes, 0.0)
+            torch._foreach_clamp_min_(boxes, 0.0)      # the reference's xyxy2xywh(clip=True) clamps the caller's boxes too
             torch._foreach_clamp_max_(boxes, 1.0)
         counts = [int(b.shape[0]) for b in boxes]
         allb = torch.cat(boxes).to(dev) if boxes else torch.zeros((0, 4), device=dev)
@@ -221,6 +225,21 @@ class Detect(nn.Module):
             gt_labels = one_hot_labels(torch.cat(labs).to(dev), self.nc)
         else:
             gt_labels = torch.cat([one_hot_labels(l, self.nc) if l.dim() == 1 else l for l in labs]).to(dev)
+        return gts, gt_labels
+
+    def fused_losses(self, engine, x, dtype, targets):
+        gts, gt_labels = self.flatten_targets(targets, x.device)
+        tcls = gt_labels[:, 1:].float().contiguous()
+        plan, loss, items = engine.forward_fused_loss(x, dtype, self, gts.contiguous(), tcls)
+        mask_loss = torch.zeros_like(loss)
+        return plan, {'det_loss': loss, 'mask_loss': mask_loss,
+                      'loss_items': {'box': items[0:1], 'obj': items[1:2], 'cls': items[2:3], 'mask': mask_loss.detach()}}
+
+    def compute_losses(self, dets, preds, features, targets, compute_masks=False):
+        """Target rows [img, cx, cy, w, h] + one-hot labels -> matcher -> DetLoss.  The reference builds the rows image by
+        image (yolo_head.py:218-223); here the per-image box tensors are clamped in place with one multi-tensor call (the
+        reference's xyxy2xywh(clip=True) also clamps the caller's boxes) and everything else runs once on the concatenation."""
+        gts, gt_labels = self.flatten_targets(targets, dets[0].device)
         tbox, tids, indices, anchors = self.matcher(dets, gts)
         tcls = [gt_labels[i] for i in tids]
         det_loss, items = self.det_loss(dets, tcls, tbox, indices, anchors)

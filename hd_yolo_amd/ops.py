@@ -273,3 +273,45 @@ def nms_batched(preds, nc, conf_thres, iou_thres, max_det, min_wh=2.0, class_awa
               int(class_aware), keep.data_ptr(), n_keep.data_ptr(), boxes.data_ptr(), scores.data_ptr(),
               extra.data_ptr() if nex > 0 else None, conf.data_ptr(), cls.data_ptr(), ws.data_ptr(), ws.numel() * 8, stream_ptr())
     return {'keep': keep, 'n_keep': n_keep, 'boxes': boxes, 'scores': scores, 'extra': extra[:, :, :nex], 'conf': conf, 'cls': cls}
+
+
+# ------------------------------------------------------------------------------------------ fused detection loss
+class DetLossCall:
+    """Pre-marshalled hdy_det_loss call for one plan (pointers and geometry are static; only the targets change)."""
+
+    def __init__(self, logits, gdets, na, nc, anchors_grid, balance, cls_cw, hyp, out, device):
+        nl = len(logits)
+        self.nl, self.na, self.nc = nl, na, nc
+        self.B = logits[0].shape[0]
+        self.ny = (ctypes.c_int * nl)(*[t.shape[1] for t in logits])
+        self.nx = (ctypes.c_int * nl)(*[t.shape[2] for t in logits])
+        self.ldl, self.ldg = logits[0].shape[3], gdets[0].shape[3]
+        assert all(t.dtype == torch.float32 and t.is_contiguous() and t.shape[3] == self.ldl for t in logits)
+        assert all(g.is_contiguous() and g.shape[:3] == t.shape[:3] and g.shape[3] == self.ldg for g, t in zip(gdets, logits))
+        self.lp = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in logits])
+        self.gp = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in gdets])
+        self.anc = (ctypes.c_float * (nl * na * 2))(*[float(v) for v in anchors_grid])
+        self.bal = (ctypes.c_float * nl)(*[float(v) for v in balance])
+        self.cw = (ctypes.c_float * nc)(*[float(v) for v in cls_cw])
+        self.hyp = hyp
+        self.dtype = dcode(gdets[0].dtype)
+        nbytes = _lib.query('hdy_det_loss_workspace_bytes', nl, self.ny, self.nx, self.B, na, self.ldl)
+        self.ws = torch.empty(nbytes // 4 + 4, dtype=torch.float32, device=device)
+        self.out = out
+        self.keep = (logits, gdets)
+
+    def __call__(self, gts, tcls):
+        nt = int(gts.shape[0])
+        assert gts.dtype == torch.float32 and gts.is_contiguous() and (nt == 0 or gts.shape[1] == 5)
+        assert tcls.dtype == torch.float32 and tcls.is_contiguous() and (nt == 0 or tuple(tcls.shape) == (nt, self.nc))
+        h = self.hyp
+        _lib.call('hdy_det_loss', self.lp, self.ldl, self.gp, self.ldg, self.dtype, self.ny, self.nx, self.nl, self.B, self.na, self.nc,
+                  self.anc, self.bal, gts.data_ptr() if nt else None, tcls.data_ptr() if nt else None, nt, self.cw,
+                  float(h['cls_pw']), float(h['obj_pw']), float(h['anchor_t']), float(h['label_smoothing']), float(h['box']),
+                  float(h['obj']), float(h['cls']), self.out.data_ptr(), self.ws.data_ptr(), self.ws.numel() * 4, stream_ptr())
+
+
+def scale_inplace(t, scale):
+    """t *= scale (a 1-element fp32 device tensor), no host sync"""
+    assert t.is_contiguous() and scale.dtype == torch.float32 and scale.is_cuda
+    _lib.call('hdy_scale_inplace', t.data_ptr(), t.numel(), scale.data_ptr(), dcode(t.dtype), stream_ptr())

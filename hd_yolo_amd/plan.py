@@ -18,10 +18,14 @@ NHWC buffers; forward and backward are replays of two launch lists.  What the tr
 torch is used for memory (torch.empty), streams and the autograd hook-in (one custom Function around the whole
 plan); every arithmetic op inside is a HIP kernel from libhdyolo_hip.so.
 """
+import os
+
 import torch
 import torch.nn as nn
 
 from . import _lib, ops
+
+USE_GRAPHS = os.environ.get('HDY_GRAPH', '0') == '1'   # hipGraph replay of ~400-node graphs measured slower than eager on ROCm 7.2
 
 
 class Val:
@@ -103,6 +107,10 @@ class Plan:
         self._allocate()
         self.fwd = self._compile_forward()
         self.bwd = self._compile_backward() if training else None
+        # the two launch lists have fixed pointers and shapes: after one eager run each they are captured into hipGraphs and
+        # replayed with one call (the eager lists are ~350 / ~450 launches per step for yolov5s)
+        self._graphs = {'fwd': None, 'bwd': None}
+        self._runs = {'fwd': 0, 'bwd': 0}
 
     # ------------------------------------------------------------------ tracing
     def _val(self, n, h, w, c, name):
@@ -280,7 +288,6 @@ class Plan:
                 if self.training:
                     M = x.n * x.h * x.w
                     u.wpd = ops.pack_alloc(u.Kp, x.c, 1, 1, 1, 0, ops.PACK_DGRAD, dt, self.device)
-                    u.gdet = self._new(x.n, x.h, x.w, u.Kp)
                     max_wg = max(max_wg, ops.wgrad_ws_bytes(x.n, x.h, x.w, x.c, u.Kp, 1, 1, 1, 0, dt))
                     max_bnws = max(max_bnws, ops.bn_bwd_ws_floats(M, u.Kp))
             elif isinstance(u, PoolUnit):
@@ -289,6 +296,15 @@ class Plan:
                     u.idx = [self._new(a.n, a.h, a.w, a.c, dtype=torch.uint8) for _ in range(3)]
         if not self.training:
             return
+        # logits gradients of all levels live in one flat buffer (one scale launch, one owner)
+        sizes = [u.x.n * u.x.h * u.x.w * u.Kp for u in self.det_units]
+        self.gdet_flat = self._new(max(sum(sizes), 1), zero=True)
+        off = 0
+        for u, n in zip(self.det_units, sizes):
+            u.gdet = self.gdet_flat[off:off + n].view(u.x.n, u.x.h, u.x.w, u.Kp)
+            off += n
+        self.loss_out = self._new(4, dtype=f32, zero=True)
+        self.loss_call = None
         self.stats = self._new(max_stats, dtype=f32)
         self.dy = self._new(max_dy)
         self.wg_ws = self._new(max_wg // 4 + 16, dtype=f32)
@@ -370,6 +386,21 @@ class Plan:
                 recs.append(ops.rec_conv_fwd(u.x.t(), u.wp, u.logits[..., :u.K], u.K, 1, 1, 1, 0, shift=u.conv.bias))
         return recs
 
+    def _replay(self, key, recs):
+        if not USE_GRAPHS:
+            return ops.run(recs)
+        g = self._graphs[key]
+        if g is None:
+            self._runs[key] += 1
+            if self._runs[key] < 2:
+                return ops.run(recs)                 # first call eager: lazy one-time host setup happens here
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g):
+                ops.run(recs)
+            self._graphs[key] = g
+        g.replay()
+
     def bn_counters(self):
         return [m.bn.num_batches_tracked for u in self.units if isinstance(u, ConvUnit) and u.has_bn for m in u.mods]
 
@@ -383,7 +414,7 @@ class Plan:
             ops.run([ops.rec_stem_prep(images, self.prep)])
         else:
             ops.run([ops.rec_nchw_to_nhwc(images, self.input.t())])
-        ops.run(self.fwd)
+        self._replay('fwd', self.fwd)
         if self.training:
             torch._foreach_add_(self.bn_counters(), 1)
         return self.det_views()
@@ -467,14 +498,31 @@ class Plan:
             u.gbias_pad = self._new(u.Kp, dtype=torch.float32)
         return u.gbias_pad
 
-    def run_backward(self, gdets):
-        pre = []
-        for u, g in zip(self.det_units, gdets):
-            if g is None:
-                u.gdet.zero_()
-            else:
-                pre.append(ops.rec_det_grad_pack(g, u.gdet, self.na, self.no))
+    def fused_loss(self, head):
+        """The hdy_det_loss call bound to this plan's logits / gradient buffers (built once)."""
+        if self.loss_call is None:
+            anc = [float(v) for buf in head.anchors for v in buf.anchor.flatten().tolist()]
+            cw = head.det_loss.BCEcls.weight if hasattr(head.det_loss.BCEcls, 'weight') else None
+            cw = [1.0] * head.nc if cw is None else ([float(cw)] * head.nc if cw.numel() == 1 else [float(v) for v in cw.flatten().tolist()])
+            self.loss_call = ops.DetLossCall([u.logits for u in self.det_units], [u.gdet for u in self.det_units], head.na, head.nc, anc,
+                                             head.det_loss.balance, cw, head.det_loss.hyp, self.loss_out, self.device)
+        return self.loss_call
+
+    def run_backward(self, gdets=None, scale=None):
+        """gdets: autograd's logits gradients (unfused loss), or None when the fused loss kernel already filled the plan's
+        gradient buffers; then `scale` is the upstream gradient of the loss (1-element device tensor)."""
+        if gdets is None:
+            if scale is not None:
+                ops.scale_inplace(self.gdet_flat, scale.reshape(-1)[:1].float().contiguous())
+            pre = []
+        else:
+            pre = []
+            for u, g in zip(self.det_units, gdets):
+                if g is None:
+                    u.gdet.zero_()
+                else:
+                    pre.append(ops.rec_det_grad_pack(g, u.gdet, self.na, self.no))
         ops.run(pre)
-        ops.run(self.bwd)
+        self._replay('bwd', self.bwd)
         for u in self.det_units:
             u.gb.copy_(u.gbias_pad[:u.K])

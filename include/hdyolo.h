@@ -131,6 +131,20 @@ int hdy_nms_batched(const float* preds, int B, int N, int row, int nc, float con
                     long long* keep, int* n_keep, float* out_boxes, float* out_scores, float* out_extra, float* out_conf, int* out_cls,
                     void* workspace, size_t ws_bytes, void* stream);
 
+/* ---- fused detection loss --------------------------------------------------------------
+ * Replaces Detect.matcher (metayolo/models/yolo_head.py:358-417), DetLoss.forward (metayolo/models/loss.py:190-244) with
+ * bbox_iou(CIoU) (metayolo/models/utils_general.py:193-231) and their autograd backward: target assignment, CIoU box loss,
+ * objectness / class BCE, and the gradient w.r.t. the logits, written into the NHWC buffers the backward plan consumes.
+ * logits[l]: fp32 [B][ny][nx][ldl], channel a*no+o;  gdet[l]: dtype [B][ny][nx][ldg];  anchors_grid: nl*na*2 HOST floats in grid
+ * units; balance: nl HOST floats; gts: device [nt][5] (img, cx, cy, w, h normalised); tcls: device [nt][nc] class targets;
+ * cls_cw: nc HOST floats.  out: device [4] = loss (x batch), box, obj, cls items.  Supported: fl_gamma = 0, no autobalance. */
+size_t hdy_det_loss_workspace_bytes(int nl, const int* ny, const int* nx, int B, int na, int ldl);
+int hdy_det_loss(const float* const* logits, int ldl, void* const* gdet, int ldg, int dtype, const int* ny, const int* nx, int nl, int B,
+                 int na, int nc, const float* anchors_grid, const float* balance, const float* gts, const float* tcls, int nt,
+                 const float* cls_cw, float cls_pw, float obj_pw, float anchor_t, float label_smoothing, float h_box, float h_obj, float h_cls,
+                 float* out, void* workspace, size_t ws_bytes, void* stream);
+int hdy_scale_inplace(void* p, long long n, const float* scale_dev, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -112,8 +112,11 @@ def test_fuse_keeps_eval_outputs(golden_dir):
                 assert relmax(feats[int(k[11:])], g[k]) < 2e-4
 
 
+@pytest.mark.parametrize('fused', ['1', '0'])
 @pytest.mark.parametrize('tag,variant', [('n_64', 'n'), ('s_128', 's')])
-def test_train_step_matches_reference_golden_fp32(golden_dir, tag, variant):
+def test_train_step_matches_reference_golden_fp32(golden_dir, tag, variant, fused, monkeypatch):
+    """fused = '1': target assignment + loss + logits gradient by csrc/loss.hip; '0': the tensor-expression DetLoss."""
+    monkeypatch.setenv('HDY_FUSED_LOSS', fused)
     g = np.load(os.path.join(golden_dir, f'train_{tag}.npz'))
     batch, size, nc, nmin, nmax = (int(v) for v in g['meta'])
     model = build(variant, nc).train()
