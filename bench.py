@@ -127,10 +127,14 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(local)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        torch.cuda.set_device(local % torch.cuda.device_count())
+        backend = os.environ.get('HDY_DIST_BACKEND', 'nccl')      # 'gloo' lets two ranks share one GPU when rehearsing the N>1 path
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
-    device = torch.device('cuda', local)
+    device = torch.device('cuda', local % torch.cuda.device_count())
     torch.cuda.set_device(device)
 
     from metayolo.models.yolo import Model

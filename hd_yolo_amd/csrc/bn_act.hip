@@ -385,8 +385,12 @@ int hdy_bn_act_fwd(const void* y, int ldy, const float* scale, const float* shif
 
 // number of row blocks hdy_bn_act_bwd uses (size of the partial slab = blocks*2*K floats)
 int hdy_bn_bwd_blocks(long long M) {
-    long long b = (M + 255) / 256;
-    if (b > 1024) b = 1024;
+    // large tensors: 256+ rows per block (amortises the per-block coefficient loads and LDS reduction), at most 1024 blocks;
+    // small ones: down to 64 rows per block so that a few hundred blocks are in flight (measured on MI355X, both ends)
+    long long big = (M + 255) / 256, small = (M + 63) / 64;
+    if (big > 1024) big = 1024;
+    if (small > 512) small = 512;
+    long long b = big > small ? big : small;
     if (b < 1) b = 1;
     return (int)b;
 }

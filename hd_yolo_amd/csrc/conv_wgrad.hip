@@ -19,6 +19,8 @@
 #include "common.h"
 #include "hdyolo_internal.h"
 
+__device__ uint4 g_hdy_zero16_w[4];   // zero page for masked 16-byte fetches
+
 namespace {
 
 __device__ __forceinline__ int fsw(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 1); }
@@ -49,7 +51,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     const T* __restrict__ x = (const T*)p.x;
     const T* __restrict__ dy = (const T*)p.dy;
 
-    const int c8 = tid & 7, r0 = tid >> 3;
+    const int r0 = tid >> 3;
+    // LDS-DMA writes linearly (wave base + lane*16): this thread fills physical slot (row, tid&7) of both tiles, so it
+    // fetches the LOGICAL 16-byte chunk that the 32-byte-block swizzle places there (row bits 1,3 are the same for its 2 rows)
+    const int c8 = ((((tid & 7) >> 1) ^ fsw(r0)) << 1) | (tid & 1);
     // fixed per thread: dy channel of its chunk, x (tap, channel) of its chunk
     const int kch = k0 + c8 * VE;
     const bool k_ok = kch < p.K;
@@ -74,20 +79,24 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
         pj[i] = rem - pi[i] * p.Wo;
     }
 
-    i32x4 rd[2], rx[2];
-    auto load_stage = [&]() {
+    const unsigned char* zero = (const unsigned char*)g_hdy_zero16_w;
+    auto stage = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const bool live = pp[i] < pend;
-            i32x4 vd = {0, 0, 0, 0}, vx = {0, 0, 0, 0};
-            if (live && k_ok) vd = *(const i32x4*)(dy + (size_t)pp[i] * p.lddy + kch);
+            const void* sd = zero;
+            const void* sx = zero;
+            if (live && k_ok) sd = dy + (size_t)pp[i] * p.lddy + kch;
             if (live && q_ok) {
                 const int hi = pi[i] * p.ih_mul + p.dh0 + th, wi = pj[i] * p.iw_mul + p.dw0 + tw;
                 if ((unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win)
-                    vx = *(const i32x4*)(x + ((size_t)(pn[i] * p.Hin + hi) * p.Win + wi) * p.ldx + cch);
+                    sx = x + ((size_t)(pn[i] * p.Hin + hi) * p.Win + wi) * p.ldx + cch;
             }
-            rd[i] = vd;
-            rx[i] = vx;
+            const int woff = (wave * 64 + 256 * i) * 16;
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)sd,
+                                             (void __attribute__((address_space(3)))*)(sD + buf * PB * 128 + woff), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)sx,
+                                             (void __attribute__((address_space(3)))*)(sX + buf * PB * 128 + woff), 16, 0, 0);
             // advance this row by one stage
             pp[i] += PB;
             pj[i] += PB;
@@ -95,15 +104,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
                 pj[i] -= p.Wo;
                 if (++pi[i] == p.Ho) { pi[i] = 0; ++pn[i]; }
             }
-        }
-    };
-    auto store_stage = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = r0 + 32 * i;
-            const int off = row * 128 + (((c8 >> 1) ^ fsw(row)) << 5) + ((c8 & 1) << 4);
-            *(i32x4*)(sD + buf * PB * 128 + off) = rd[i];
-            *(i32x4*)(sX + buf * PB * 128 + off) = rx[i];
         }
     };
 
@@ -114,15 +114,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
         for (int b = 0; b < WTL; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nst = (pend - pbeg + PB - 1) / PB;
-    if (nst > 0) {
-        load_stage();
-        store_stage(0);
-    }
+    if (nst > 0) stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int g = lane >> 4, i16 = lane & 15;
     for (int s = 0; s < nst; ++s) {
         const int cur = s & 1;
-        if (s + 1 < nst) load_stage();
+        if (s + 1 < nst) stage(cur ^ 1);
         const unsigned char* d_s = sD + cur * PB * 128;
         const unsigned char* x_s = sX + cur * PB * 128;
         if constexpr (sizeof(T) == 2) {
@@ -166,7 +164,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
                 acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[0][0], 0, 0, 0);
             }
         }
-        if (s + 1 < nst) store_stage(cur ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 

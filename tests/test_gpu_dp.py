@@ -1,0 +1,90 @@
+"""N = 2 data-parallel path on one MI355X: two processes (gloo backend, both on cuda:0 — RCCL needs one device per rank,
+which a 1-GPU box cannot give) run HIP-plan training steps through hd_yolo_amd.parallel.DataParallel.
+Checks: parameters start identical (rank-0 broadcast), the applied gradient is the SUM of the per-rank gradients
+(SURVEY.md §8e), and parameters stay bit-identical across ranks after optimizer steps."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), YOLOv5_VERBOSE='false')
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from hd_yolo_amd import synth
+    from hd_yolo_amd.parallel import DataParallel
+    from metayolo.models.yolo import Model
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        dev = torch.device('cuda', 0)
+        torch.manual_seed(10 + rank)
+        model = Model(synth.make_cfg('n', 2), synth.make_hyp())
+        sd = synth.synth_state_dict(synth.shapes_of(model), seed=rank)          # ranks differ before the broadcast
+        model.load_state_dict(sd, strict=False)
+        model = model.to(dev).train()
+        net = DataParallel(model, nbuckets=3)
+        start = torch.cat([p.detach().flatten() for p in model.parameters()]).cpu()
+        x = synth.synth_images(2, 64, seed=20 + rank).to(dev)
+        tg = synth.synth_targets(2, 64, 2, nmin=3, nmax=8, seed=30 + rank)
+        # local gradient without the hook, for the sum check
+        eng = model._eng()
+        hooks, eng.grad_hooks = eng.grad_hooks, []
+        losses, _ = net(x, tg)
+        losses['det']['det_loss'].backward()
+        local = torch.cat([p.grad.flatten() for p in model.parameters()]).cpu().clone()
+        for p in model.parameters():
+            p.grad = None
+        for m in model.modules():                     # undo the BN statistics update of the probe step
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.load_state_dict({k: v for k, v in sd_bn(m).items()})
+        eng.grad_hooks = hooks
+        opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.9)
+        losses, _ = net(x, synth.synth_targets(2, 64, 2, nmin=3, nmax=8, seed=30 + rank))
+        losses['det']['det_loss'].backward()
+        reduced = torch.cat([p.grad.flatten() for p in model.parameters()]).cpu().clone()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        losses, _ = net(x, synth.synth_targets(2, 64, 2, nmin=3, nmax=8, seed=30 + rank))
+        losses['det']['det_loss'].backward()
+        opt.step()
+        end = torch.cat([p.detach().flatten() for p in model.parameters()]).cpu()
+        q.put((rank, start.numpy(), local.numpy(), reduced.numpy(), end.numpy()))       # by value: the worker exits right after
+    finally:
+        dist.destroy_process_group()
+
+
+def sd_bn(m):
+    return {'weight': m.weight.detach(), 'bias': m.bias.detach(), 'running_mean': m.running_mean, 'running_var': m.running_var,
+            'num_batches_tracked': m.num_batches_tracked}
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_share_gradients_and_stay_in_sync():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, s0, l0, r0, e0), (_, s1, l1, r1, e1) = [(r, *map(torch.from_numpy, arrs)) for r, *arrs in out]
+    assert torch.equal(s0, s1), 'rank 0 state was not broadcast'
+    assert torch.equal(r0, r1), 'ranks disagree on the reduced gradient'
+    torch.testing.assert_close(r0, l0 + l1, rtol=1e-4, atol=1e-6)       # SUM of the per-rank gradients, no division
+    assert torch.equal(e0, e1), 'parameters drifted apart'
+    assert not torch.equal(e0, s0)
