@@ -53,8 +53,18 @@ def make_optimizer(model, hyp, batch_total):
     return opt
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, see
+    profiles/r01_conv3x3_pmc.json and scripts/roofline_kernel.py); None when the file is absent."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r01_conv3x3_pmc.json')) as f:
+            return json.load(f)['traffic_bytes_per_launch']
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def conv_roofline(device, iters=30):
-    """Time the bf16 conv_igemm kernel on yolov5s' 3x3 64->64 @ 80x80 layer at batch 64 (30.2 GFLOP per launch)."""
+    """Time the bf16 3x3 conv kernel on yolov5s' 64->64 @ 80x80 layer at batch 64 (30.2 GFLOP per launch), through the C ABI."""
     N, H, W, C, K = 64, 80, 80, 64, 64
     dt = torch.bfloat16
     x = torch.randn((N, H, W, C), device=device).to(dt)
@@ -78,7 +88,7 @@ def conv_roofline(device, iters=30):
     flops = 2.0 * N * K * C * 9 * H * W
     ach = flops / t / 1e12
     return {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_BF16_TFLOPS, 4),
-            'traffic': None, 'kernel': 'conv_igemm_kernel<bf16,bf16,64> fwd 3x3 64->64 @80x80 B=64 (+BN stat slabs)',
+            'traffic': pmc_traffic(), 'kernel': 'conv3x3_c64_kernel (bf16, filter-resident) fwd 3x3 64->64 @80x80 B=64 (+BN stat slabs)',
             'us_per_launch': round(t * 1e6, 2), 'algorithmic_gflop_per_launch': round(flops / 1e9, 2)}
 
 

@@ -337,15 +337,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
                 for (int b = 0; b < NT; ++b) acc[a][b] = mma16<T>(af[a], bf[b], acc[a][b]);
         }
+        bool stored = false;
         if (++c_kb == nkb) {
             __syncthreads();                       // every wave is done reading stage `cur`: reuse it as scratch
             epilogue(c_tile, smem + cur * STAGE);
+            // full tiles on the vector path issue exactly BM / (256 / (BN/8)) row stores per wave, after the prefetch DMA
+            stored = VEC_OUT && p.vec_out && ((c_tile / ntiles) + 1) * BM <= p.M;
             zero_acc();
             c_kb = 0;
             ++c_tile;
         }
         if (!more) break;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // vmcnt retires in issue order and the prefetch was issued before the epilogue's stores: leave those stores in flight
+        if (stored) {
+            if (BN == 128) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (BN == 64) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __syncthreads();
         cur ^= 1;
     }
@@ -408,6 +418,8 @@ int hdy_conv_igemm_launch(ConvArgs a, int dtype, int out_f32, hipStream_t st) {
     const bool bf16_out = dtype == HDY_BF16 && !out_f32;
     a.vec_out = (bf16_out && a.K % 8 == 0 && a.ldy % 8 == 0 && ((uintptr_t)a.y & 15) == 0 &&
                  (!a.res || (a.ldr % 8 == 0 && ((uintptr_t)a.res & 15) == 0))) ? 1 : 0;
+    int rc = 0;
+    if (hdy_conv3x3_c64_try(a, dtype, out_f32, st, &rc)) return rc;      // filter-resident 3x3 kernel when the shape qualifies
     if (dtype == HDY_BF16) return out_f32 ? launch_bn<bf16_t, float>(a, st) : launch_bn<bf16_t, bf16_t>(a, st);
     return launch_bn<float, float>(a, st);
 }

@@ -62,6 +62,8 @@ CONV_CASES = [
     (2, 20, 20, 32, 64, 3, 2, 1),
     (1, 18, 14, 64, 128, 3, 2, 1),
     (3, 40, 40, 256, 512, 1, 1, 0),
+    (2, 16, 32, 64, 64, 3, 1, 1),        # qualifies for the filter-resident 3x3 kernel (bf16): C=64, H%16==0, W%16==0
+    (3, 32, 48, 64, 32, 3, 1, 1),
 ]
 
 
