@@ -1,0 +1,31 @@
+"""Synthetic tile stream with the reference loader's batch schema (reference: metayolo/datasets.py:462-519 target dict,
+:850-870 create_dataloader, engines/torch_utils.py:172 collate).  BASELINE.json's workload is synthetic 640x640 RGB tiles;
+the reference's CSV/cv2/albumentations pipeline is CPU image I/O and out of scope."""
+import torch
+
+from hd_yolo_amd import synth
+
+
+class SyntheticTiles:
+    """Iterable of (imgs: tuple of (3,H,W) float tensors in 0..1, targets: tuple of target dicts).  Each rank draws from its
+    own seed offset (what DistributedSampler gives the reference: disjoint shards)."""
+
+    def __init__(self, batch_size, imgsz, nc, steps, rank=0, seed=0, task='det', nmin=50, nmax=400, device=None):
+        self.batch_size, self.imgsz, self.nc, self.steps = batch_size, imgsz, nc, steps
+        self.rank, self.seed, self.task, self.nmin, self.nmax, self.device = rank, seed, task, nmin, nmax, device
+        self.epoch = 0
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+    def __len__(self):
+        return self.steps
+
+    def __iter__(self):
+        for i in range(self.steps):
+            s = self.seed + 1000003 * self.rank + 7919 * self.epoch + i
+            x = synth.synth_images(self.batch_size, self.imgsz, seed=s)
+            t = synth.synth_targets(self.batch_size, self.imgsz, self.nc, nmin=self.nmin, nmax=self.nmax, seed=s, task=self.task)
+            if self.device is not None:
+                x = x.to(self.device, non_blocking=True)
+            yield tuple(x.unbind(0)), t
