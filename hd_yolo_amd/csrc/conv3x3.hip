@@ -17,6 +17,8 @@
 //
 // Requirements (checked by the launcher, otherwise the generic kernel runs): bf16 in/out, C == 64, K <= 64, R = S = 3,
 // stride 1, pad 1, H % 16 == 0, W % 16 == 0, 16-byte aligned rows.
+#include <stdlib.h>
+
 #include "common.h"
 #include "hdyolo_internal.h"
 
@@ -238,6 +240,8 @@ __global__ __launch_bounds__(NTHR) void conv3x3_c64_kernel(const ConvArgs p) {
 // Returns 1 and launches when the shape qualifies; 0 = not eligible (caller falls back to the generic kernel); <0 / >0 = error.
 int hdy_conv3x3_c64_try(const ConvArgs& a, int dtype, int out_f32, hipStream_t st, int* rc) {
     if (dtype != HDY_BF16 || out_f32) return 0;
+    static const bool disabled = getenv("HDY_NO_CONV3X3") != nullptr;      // tests: force the generic kernel for A/B comparison
+    if (disabled) return 0;
     if (!(a.TH == 3 && a.TW == 3 && a.ih_mul == 1 && a.iw_mul == 1 && a.dh0 == -1 && a.dw0 == -1 && a.dense_out)) return 0;
     if (!(a.C == 64 && a.K <= 64 && a.K % 8 == 0 && a.Hin == a.Ho && a.Win == a.Wo && a.Ho % TH == 0 && a.Wo % TW == 0)) return 0;
     if (!(a.ldx % 8 == 0 && a.ldy % 8 == 0 && ((uintptr_t)a.y & 15) == 0 && ((uintptr_t)a.x & 15) == 0)) return 0;

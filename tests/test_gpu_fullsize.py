@@ -1,0 +1,152 @@
+"""BASELINE-size checks through size-independent properties (the oracle cannot run these sizes in seconds) plus the other
+model variants against the oracle at sizes it can."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from hd_yolo_amd import ops, synth  # noqa: E402
+
+DEV = 'cuda:0'
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def relmax(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def _conv(x, w, dtype, stats=False):
+    N, H, W, C = x.shape
+    K = w.shape[0]
+    wp = ops.pack_alloc(K, C, 3, 3, 1, 1, ops.PACK_FWD, dtype, DEV)
+    y = torch.empty((N, H, W, K), dtype=dtype, device=DEV)
+    st = torch.zeros(((N * H * W + 127) // 128, 2, K), dtype=torch.float32, device=DEV) if stats else None
+    ops.run([ops.rec_pack(w, None, 1, 1, ops.PACK_FWD, wp), ops.rec_conv_fwd(x, wp, y, K, 3, 3, 1, 1, stats=st)])
+    return y, st
+
+
+def test_named_layer_full_size_linearity_and_stats_fp32():
+    """3x3 64->64 @80x80, batch 64 (the roofline layer): conv(a*x1 + b*x2) == a*conv(x1) + b*conv(x2); the BN slabs sum to the
+    output's channel sums; a 2-tile crop equals the CPU conv."""
+    g = torch.Generator().manual_seed(0)
+    x1 = torch.randn((64, 80, 80, 64), generator=g).to(DEV)
+    x2 = torch.randn((64, 80, 80, 64), generator=g).to(DEV)
+    w = (torch.randn((64, 64, 3, 3), generator=g) * 0.05).to(DEV)
+    y1, _ = _conv(x1, w, torch.float32)
+    y2, _ = _conv(x2, w, torch.float32)
+    y3, st = _conv(0.5 * x1 - 2.0 * x2, w, torch.float32, stats=True)
+    assert relmax(y3, 0.5 * y1 - 2.0 * y2) < 1e-5
+    assert relmax(st.sum(0)[0], y3.sum((0, 1, 2))) < 1e-4 and relmax(st.sum(0)[1], (y3 * y3).sum((0, 1, 2))) < 1e-4
+    ref = F.conv2d(x1[:2].permute(0, 3, 1, 2).cpu(), w.cpu(), None, 1, 1).permute(0, 2, 3, 1)
+    assert relmax(y1[:2], ref) < 1e-4
+
+
+def test_named_layer_two_bf16_kernels_agree_at_full_size():
+    """The filter-resident 3x3 kernel and the generic implicit GEMM are independent implementations: at full size their bf16
+    outputs and BN slabs must agree (accumulation order differs: 1 bf16 ulp), and both match fp32 within bf16 rounding."""
+    code = (
+        "import os, sys, torch; sys.path.insert(0, %r)\n"
+        "from tests.test_gpu_fullsize import _conv, DEV\n"
+        "g = torch.Generator().manual_seed(1)\n"
+        "x = torch.randn((64, 80, 80, 64), generator=g).to(DEV).bfloat16(); w = (torch.randn((64, 64, 3, 3), generator=g) * 0.05).to(DEV)\n"
+        "y, st = _conv(x, w, torch.bfloat16, stats=True)\n"
+        "torch.save({'y': y.float().cpu(), 'st': st.sum(0).cpu()}, sys.argv[1])\n") % ROOT
+    outs = []
+    for tag, env in (('fast', {}), ('generic', {'HDY_NO_CONV3X3': '1'})):
+        path = os.path.join('/tmp', f'hdy_conv_{tag}.pt')
+        p = subprocess.run([sys.executable, '-c', code, path], cwd=ROOT, env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-3000:]
+        outs.append(torch.load(path))
+    a, b = outs
+    assert relmax(a['y'], b['y']) < 1e-2 and relmax(a['st'], b['st']) < 1e-3
+    assert (a['y'] - b['y']).abs().mean() / b['y'].abs().mean() < 1e-3
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn((64, 80, 80, 64), generator=g).to(DEV).bfloat16().float()
+    w = (torch.randn((64, 64, 3, 3), generator=g) * 0.05).to(DEV)
+    y32, _ = _conv(x, w.bfloat16().float(), torch.float32)
+    assert relmax(a['y'], y32) < 1.5e-2
+
+
+def test_c4_size_nms_properties_and_oracle():
+    """C4 geometry: 1024x1024 tiles -> 64512 candidates per tile, dense nuclei (4096 / 16384 survivors)."""
+    from oracle import nms_ref
+    for survivors, max_det in ((4096, 300), (16384, 2000)):
+        preds = synth.synth_nms_preds(4, survivors, nc=8, size=1024, extra=64512 - survivors, seed=survivors)
+        res = ops.nms_batched(preds.to(DEV), 8, 0.15, 0.45, max_det)
+        nk = res['n_keep'].cpu().numpy()
+        keep, ref_nk, _ = nms_ref.nms_batched_c(preds.numpy(), 8, 0.15, 0.45, max_det)
+        assert np.array_equal(nk, ref_nk) and np.array_equal(res['keep'].cpu().numpy(), keep)
+        for b in range(4):
+            s = res['scores'][b, :nk[b], 0].cpu().numpy()
+            assert np.all(s[:-1] >= s[1:]), 'kept scores must be non-increasing'
+        # idempotence: NMS of the kept boxes keeps every one of them, in the same order
+        boxes = res['boxes'][:, :int(nk.min())]
+        again = torch.cat([(boxes[..., :2] + boxes[..., 2:]) / 2, boxes[..., 2:] - boxes[..., :2], res['scores'][:, :int(nk.min())]], 2).contiguous()
+        r2 = ops.nms_batched(again, 8, 0.15, 0.45, max_det)
+        assert (r2['n_keep'].cpu().numpy() == int(nk.min())).all()
+        assert (r2['keep'][:, :int(nk.min())].cpu() == torch.arange(int(nk.min()))).all()
+
+
+@pytest.mark.parametrize('variant,size,batch', [('m', 128, 2), ('l', 128, 1)])
+def test_other_variants_match_oracle_fp32(variant, size, batch):
+    """yolov5m (channels 48/96/192/...: not multiples of the 32/64-wide k-block) and yolov5l, eval + one training step."""
+    from metayolo.models.yolo import Model
+    from oracle.ref_net import RefNet
+    nc = 8
+    cfg, hyp = synth.make_cfg(variant, nc), synth.make_hyp(conf_thres=0.02)
+    model = Model(cfg, hyp)
+    model.load_state_dict(synth.synth_state_dict(synth.shapes_of(model), seed=0), strict=False)
+    model = model.to(DEV)
+    net = RefNet(cfg, hyp)
+    x = synth.synth_images(batch, size, seed=3)
+    model.eval()
+    with torch.no_grad():
+        _, outs = model(x.to(DEV))
+        feats, dets, _, ref = net.eval_forward(net.init_state(), x)
+    plan = next(iter(model._eng().plans.values()))
+    for i, d in enumerate(plan.det_views()):
+        assert relmax(d, dets[i]) < 2e-4
+    for o, r in zip(outs, ref):
+        assert o['det']['boxes'].shape == r['boxes'].shape
+        if r['boxes'].numel():      # 1e-4 relative to the box tensor's magnitude (hundreds of pixels) after 100+ fp32 layers
+            assert relmax(o['det']['boxes'], r['boxes']) < 1e-4
+        assert np.array_equal(o['det']['labels'].cpu().numpy(), r['labels'].numpy())
+    model.train()
+    tg = synth.synth_targets(batch, size, nc, nmin=10, nmax=30, seed=5)
+    losses, _ = model(x.to(DEV), tg)
+    losses['det']['det_loss'].backward()
+    sd = net.init_state()
+    for k, t in sd.items():
+        if 'running' not in k:
+            t.requires_grad_(True)
+    rl, _, _ = net.train_forward(sd, x, synth.synth_targets(batch, size, nc, nmin=10, nmax=30, seed=5))
+    rl.backward()
+    assert abs(losses['det']['det_loss'].item() - rl.item()) <= 3e-4 * abs(rl.item())
+    params = dict(model.named_parameters())
+    worst = max(relmax(params[k].grad, sd[k].grad) for k in params if 'running' not in k)
+    assert worst < 2e-3, worst
+
+
+def test_bench_config_step_is_sane_at_full_size():
+    """yolov5s, batch 64, 640x640, bf16: finite loss, gradients for every parameter, BN statistics moved, logits finite."""
+    from metayolo.models.yolo import Model
+    model = Model(synth.make_cfg('s', 8), synth.make_hyp())
+    model.load_state_dict(synth.synth_state_dict(synth.shapes_of(model), seed=0), strict=False)
+    model = model.to(DEV).train()
+    model.half()
+    rv0 = model.state_dict()['backbone.4.cv3.bn.running_var'].clone()
+    x = synth.synth_images(64, 640, seed=0).to(DEV)
+    losses, _ = model(x, synth.synth_targets(64, 640, 8, seed=1))
+    losses['det']['det_loss'].backward()
+    assert torch.isfinite(losses['det']['det_loss']).all()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().max() > 0 for p in model.parameters())
+    assert not torch.equal(rv0, model.state_dict()['backbone.4.cv3.bn.running_var'])
+    plan = next(iter(model._eng().plans.values()))
+    assert all(torch.isfinite(d).all() for d in plan.det_views())
