@@ -26,6 +26,8 @@ SIGNATURES = {
     'hdy_conv_mtiles': (_I, [_L]),
     'hdy_conv_pack_elems': (_Z, [_I, _I, _I, _I, _I, _I, _I, _I]),
     'hdy_conv_pack': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    'hdy_conv_pack_describe': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I]),
+    'hdy_conv_pack_run': (_I, [_P, _I, _I, _P]),
     'hdy_conv_fwd': (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _I, _P] + [_I] * 14 + [_P]),
     'hdy_conv_dgrad': (_I, [_P, _I, _P, _P, _I] + [_I] * 11 + [_P]),
     'hdy_conv_wgrad_workspace_bytes': (_Z, [_I] * 11),
@@ -52,6 +54,15 @@ SIGNATURES = {
     'hdy_nms_workspace_bytes': (_Z, [_I, _I]),
     'hdy_nms_batched': (_I, [_P, _I, _I, _I, _I, _F, _F, _I, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
 }
+
+
+
+class PackDesc(ctypes.Structure):
+    """mirror of hdy_pack_desc (include/hdyolo.h)"""
+    _fields_ = [('w_a', c_void_p), ('w_b', c_void_p), ('out', c_void_p)] + [(n, c_int) for n in (
+        'K_a', 'K_b', 'Kl', 'C', 'R', 'S', 'transpose', 'TH', 'TW', 'rbase', 'rstep', 'sbase', 'sstep', 'stem', 'rows_total', 'Kdp',
+        'dtype', 'first_block', 'nblocks', 'pad_')]
+
 
 _lib = None
 

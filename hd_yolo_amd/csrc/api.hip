@@ -6,12 +6,12 @@
 
 #include "common.h"
 #include "hdyolo_internal.h"
+#include "hdyolo.h"
 
 int hdy_wgrad_reduce_launch(const float* partial, int splits, size_t slab_stride, int K, int Q, int mode, int C, int R, int S, float* grad,
                             int accumulate, hipStream_t st);
-int hdy_pack_weight_launch(const float* w_a, int K_a, const float* w_b, int K_b, void* out, int Kl, int C, int R, int S, int transpose,
-                           int TH, int TW, int rbase, int rstep, int sbase, int sstep, int stem, int rows_total, int Kdp, int dtype,
-                           hipStream_t st);
+int hdy_pack_weight_launch(const hdy_pack_desc& d, hipStream_t st);
+int hdy_pack_batch_launch(const hdy_pack_desc* table, int n, int total_blocks, hipStream_t st);
 
 static thread_local char g_err[512] = "";
 
@@ -74,41 +74,72 @@ size_t hdy_conv_pack_elems(int K, int C, int R, int S, int stride, int pad, int 
     return n;
 }
 
-// Logical weight W[K][C][R][S]: rows 0..K_a-1 from w_a, the next K_b rows from w_b (two convs fused along K),
-// remaining rows up to K are zero (channel padding, e.g. 39 -> 40 detection outputs).  Packs it for `kind`.
-int hdy_conv_pack(const float* w_a, int K_a, const float* w_b, int K_b, int K, int C, int R, int S, int stride, int pad, int kind,
-                  int dtype, void* out, void* stream) {
-    HDY_ARG(w_a && out && K_a > 0 && K_b >= 0 && K >= K_a + K_b && C > 0 && R > 0 && S > 0, "conv_pack: bad args");
+static hdy_pack_desc make_desc(const float* w_a, int K_a, const float* w_b, int K_b, void* out, int Kl, int C, int R, int S, int transpose,
+                               int TH, int TW, int rbase, int rstep, int sbase, int sstep, int stem, int rows_total, int Kdp, int dtype,
+                               int first_block) {
+    hdy_pack_desc d = {};
+    d.w_a = w_a; d.w_b = w_b; d.out = out; d.K_a = K_a; d.K_b = K_b; d.Kl = Kl; d.C = C; d.R = R; d.S = S; d.transpose = transpose;
+    d.TH = TH; d.TW = TW; d.rbase = rbase; d.rstep = rstep; d.sbase = sbase; d.sstep = sstep; d.stem = stem; d.rows_total = rows_total;
+    d.Kdp = Kdp; d.dtype = dtype; d.first_block = first_block;
+    d.nblocks = cdiv((long long)rows_total * Kdp, 256);
+    return d;
+}
+
+// Logical weight W[K][C][R][S]: rows 0..K_a-1 from w_a, the next K_b rows from w_b (two convs fused along K), remaining rows up to
+// K are zero (channel padding, e.g. 39 -> 40 detection outputs).  Describes the packing job(s) for `kind`; returns their number.
+int hdy_conv_pack_describe(const float* w_a, int K_a, const float* w_b, int K_b, int K, int C, int R, int S, int stride, int pad, int kind,
+                           int dtype, void* out, hdy_pack_desc* descs, int first_block) {
+    HDY_ARG(w_a && out && descs && K_a > 0 && K_b >= 0 && K >= K_a + K_b && C > 0 && R > 0 && S > 0, "conv_pack: bad args");
     HDY_ARG((K_b == 0) == (w_b == nullptr), "conv_pack: w_b / K_b mismatch");
     HDY_ARG(stride == 1 || stride == 2, "conv_pack: stride %d unsupported", stride);
     HDY_ARG(dtype == HDY_BF16 || dtype == HDY_F32, "conv_pack: unknown dtype %d", dtype);
-    hipStream_t st = (hipStream_t)stream;
     if (kind == KIND_FWD || kind == KIND_STEM) {
         const int stem = kind == KIND_STEM;
         HDY_ARG(!stem || (C == 3 && K_b == 0), "conv_pack: stem expects C == 3 and a single weight");
         const int kd = stem ? R * S * 4 : R * S * C;
         const int Kdp = round_up(kd, bke(dtype));
         const int rows_total = round_up(K, hdy_conv_bn_tile(K));
-        return hdy_pack_weight_launch(w_a, K_a, w_b, K_b, out, K, C, R, S, 0, R, stem ? 1 : S, 0, 1, 0, 1, stem, rows_total, Kdp, dtype, st);
+        descs[0] = make_desc(w_a, K_a, w_b, K_b, out, K, C, R, S, 0, R, stem ? 1 : S, 0, 1, 0, 1, stem, rows_total, Kdp, dtype, first_block);
+        return 1;
     }
     HDY_ARG(kind == KIND_DGRAD, "conv_pack: unknown kind %d", kind);
     const int rows_total = round_up(C, hdy_conv_bn_tile(C));
     if (stride == 1) {
         const int Kdp = round_up(R * S * K, bke(dtype));
-        return hdy_pack_weight_launch(w_a, K_a, w_b, K_b, out, K, C, R, S, 1, R, S, R - 1, -1, S - 1, -1, 0, rows_total, Kdp, dtype, st);
+        descs[0] = make_desc(w_a, K_a, w_b, K_b, out, K, C, R, S, 1, R, S, R - 1, -1, S - 1, -1, 0, rows_total, Kdp, dtype, first_block);
+        return 1;
     }
     size_t off = 0;
+    int n = 0;
     for (int a = 0; a < 2; ++a)
         for (int b = 0; b < 2; ++b) {
             const Axis ah = class_axis(R, pad, a), aw = class_axis(S, pad, b);
             if (!ah.taps || !aw.taps) continue;
             const int Kdp = round_up(ah.taps * aw.taps * K, bke(dtype));
-            int rc = hdy_pack_weight_launch(w_a, K_a, w_b, K_b, (char*)out + off * esize(dtype), K, C, R, S, 1, ah.taps, aw.taps, ah.rmax, -2,
-                                            aw.rmax, -2, 0, rows_total, Kdp, dtype, st);
-            if (rc) return rc;
+            descs[n] = make_desc(w_a, K_a, w_b, K_b, (char*)out + off * esize(dtype), K, C, R, S, 1, ah.taps, aw.taps, ah.rmax, -2, aw.rmax,
+                                 -2, 0, rows_total, Kdp, dtype, first_block);
+            first_block += descs[n].nblocks;
             off += (size_t)rows_total * Kdp;
+            ++n;
         }
+    return n;
+}
+
+int hdy_conv_pack(const float* w_a, int K_a, const float* w_b, int K_b, int K, int C, int R, int S, int stride, int pad, int kind,
+                  int dtype, void* out, void* stream) {
+    hdy_pack_desc d[4];
+    const int n = hdy_conv_pack_describe(w_a, K_a, w_b, K_b, K, C, R, S, stride, pad, kind, dtype, out, d, 0);
+    if (n < 0) return n;
+    for (int i = 0; i < n; ++i) {
+        const int rc = hdy_pack_weight_launch(d[i], (hipStream_t)stream);
+        if (rc) return rc;
+    }
     return HDY_OK;
+}
+
+int hdy_conv_pack_run(const hdy_pack_desc* descs_device, int ndesc, int total_blocks, void* stream) {
+    HDY_ARG(descs_device && ndesc > 0 && total_blocks > 0, "conv_pack_run: bad args");
+    return hdy_pack_batch_launch(descs_device, ndesc, total_blocks, (hipStream_t)stream);
 }
 
 // y = act(scale * conv(x, w) + shift) [+= y]; NHWC with pixel pitches; optional BatchNorm slabs in `stats`.

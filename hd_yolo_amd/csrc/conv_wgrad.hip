@@ -18,6 +18,7 @@
 // yolo_head.py:112 (reached from train.py:472).
 #include "common.h"
 #include "hdyolo_internal.h"
+#include "hdyolo.h"
 
 __device__ uint4 g_hdy_zero16_w[4];   // zero page for masked 16-byte fetches
 
@@ -26,17 +27,21 @@ namespace {
 __device__ __forceinline__ int fsw(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 1); }
 
 template <typename T> struct WT;
-template <> struct WT<bf16_t> { static constexpr int VE = 8, TK = 64, WTL = 2; };   // tiles per wave side
+template <> struct WT<bf16_t> { static constexpr int VE = 8, TK = 64, WTL = 2; };   // channels per 128-byte sub-tile row, MFMA tiles per 32 ch
 template <> struct WT<float> { static constexpr int VE = 4, TK = 32, WTL = 1; };
 
 constexpr int PB = 64;   // pixels per LDS stage
 
-template <typename T>
+// Output tile of a workgroup = (SD x TK dy-channels) x (SX x TK tap-channels); SD, SX in {1, 2}.  Each operand tile is SD
+// (SX) sub-tiles of [64 pixels][128 B]; with SD = SX = 2 every staged byte feeds twice as many MFMAs and each dy / x element
+// is fetched by half as many workgroups as with 64x64 tiles (the wgrad of the 128+-channel layers was L2-fetch bound).
+template <typename T, int SD, int SX>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     constexpr int VE = WT<T>::VE, TK = WT<T>::TK, WTL = WT<T>::WTL;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * PB * 128];
-    unsigned char* sD = smem;                   // dy tiles  [2][PB][128]
-    unsigned char* sX = smem + 2 * PB * 128;    // x tiles   [2][PB][128]
+    constexpr int MTW = WTL * SD, NTW = WTL * SX;            // 16x16 MFMA tiles per wave along k / q
+    constexpr int SUB = PB * 128;                              // bytes of one sub-tile
+    constexpr int STAGE = (SD + SX) * SUB;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -44,28 +49,36 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     const int split = blockIdx.x / tiles;
     const int tile = blockIdx.x - split * tiles;
     const int kt = tile / p.qtiles, qt = tile - kt * p.qtiles;
-    const int k0 = kt * TK, q0 = qt * TK;
+    const int k0 = kt * TK * SD, q0 = qt * TK * SX;
     const int pbeg = split * p.pix_per_split;
     const int pend = min(pbeg + p.pix_per_split, p.P);
 
     const T* __restrict__ x = (const T*)p.x;
     const T* __restrict__ dy = (const T*)p.dy;
+    const unsigned char* zero = (const unsigned char*)g_hdy_zero16_w;
 
     const int r0 = tid >> 3;
-    // LDS-DMA writes linearly (wave base + lane*16): this thread fills physical slot (row, tid&7) of both tiles, so it
+    // LDS-DMA writes linearly (wave base + lane*16): this thread fills physical slot (row, tid&7) of every sub-tile, so it
     // fetches the LOGICAL 16-byte chunk that the 32-byte-block swizzle places there (row bits 1,3 are the same for its 2 rows)
     const int c8 = ((((tid & 7) >> 1) ^ fsw(r0)) << 1) | (tid & 1);
-    // fixed per thread: dy channel of its chunk, x (tap, channel) of its chunk
-    const int kch = k0 + c8 * VE;
-    const bool k_ok = kch < p.K;
-    const int q = q0 + c8 * VE;
-    const bool q_ok = q < p.Q;
-    int th = 0, tw = 0, cch = 0;
-    if (q_ok) {
-        const int tap = q / p.C;
-        cch = q - tap * p.C;
-        th = tap / p.TW;
-        tw = tap - th * p.TW;
+    int kch[SD], xth[SX], xtw[SX], xc[SX];
+    bool k_ok[SD], q_ok[SX];
+#pragma unroll
+    for (int u = 0; u < SD; ++u) {
+        kch[u] = k0 + u * TK + c8 * VE;
+        k_ok[u] = kch[u] < p.K;
+    }
+#pragma unroll
+    for (int u = 0; u < SX; ++u) {
+        const int q = q0 + u * TK + c8 * VE;
+        q_ok[u] = q < p.Q;
+        xth[u] = xtw[u] = xc[u] = 0;
+        if (q_ok[u]) {
+            const int tap = q / p.C;
+            xc[u] = q - tap * p.C;
+            xth[u] = tap / p.TW;
+            xtw[u] = tap - xth[u] * p.TW;
+        }
     }
     const int HoWo = p.Ho * p.Wo;
     int pn[2], pi[2], pj[2], pp[2];
@@ -79,24 +92,31 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
         pj[i] = rem - pi[i] * p.Wo;
     }
 
-    const unsigned char* zero = (const unsigned char*)g_hdy_zero16_w;
     auto stage = [&](int buf) {
+        unsigned char* sD = smem + buf * STAGE;
+        unsigned char* sX = sD + SD * SUB;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const bool live = pp[i] < pend;
-            const void* sd = zero;
-            const void* sx = zero;
-            if (live && k_ok) sd = dy + (size_t)pp[i] * p.lddy + kch;
-            if (live && q_ok) {
-                const int hi = pi[i] * p.ih_mul + p.dh0 + th, wi = pj[i] * p.iw_mul + p.dw0 + tw;
-                if ((unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win)
-                    sx = x + ((size_t)(pn[i] * p.Hin + hi) * p.Win + wi) * p.ldx + cch;
-            }
             const int woff = (wave * 64 + 256 * i) * 16;
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)sd,
-                                             (void __attribute__((address_space(3)))*)(sD + buf * PB * 128 + woff), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)sx,
-                                             (void __attribute__((address_space(3)))*)(sX + buf * PB * 128 + woff), 16, 0, 0);
+#pragma unroll
+            for (int u = 0; u < SD; ++u) {
+                const void* src = zero;
+                if (live && k_ok[u]) src = dy + (size_t)pp[i] * p.lddy + kch[u];
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                                 (void __attribute__((address_space(3)))*)(sD + u * SUB + woff), 16, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < SX; ++u) {
+                const void* src = zero;
+                if (live && q_ok[u]) {
+                    const int hi = pi[i] * p.ih_mul + p.dh0 + xth[u], wi = pj[i] * p.iw_mul + p.dw0 + xtw[u];
+                    if ((unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win)
+                        src = x + ((size_t)(pn[i] * p.Hin + hi) * p.Win + wi) * p.ldx + xc[u];
+                }
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                                 (void __attribute__((address_space(3)))*)(sX + u * SUB + woff), 16, 0, 0);
+            }
             // advance this row by one stage
             pp[i] += PB;
             pj[i] += PB;
@@ -107,61 +127,78 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
         }
     };
 
-    f32x4 acc[WTL][WTL];
+    f32x4 acc[MTW][NTW];
 #pragma unroll
-    for (int a = 0; a < WTL; ++a)
+    for (int a = 0; a < MTW; ++a)
 #pragma unroll
-        for (int b = 0; b < WTL; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < NTW; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nst = (pend - pbeg + PB - 1) / PB;
     if (nst > 0) stage(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int g = lane >> 4, i16 = lane & 15;
+    // channel offset of this wave's tile a (b) inside the workgroup tile -> (sub-tile, column)
+    constexpr int WCH_M = TK * SD / 2, WCH_N = TK * SX / 2;
     for (int s = 0; s < nst; ++s) {
         const int cur = s & 1;
         if (s + 1 < nst) stage(cur ^ 1);
-        const unsigned char* d_s = sD + cur * PB * 128;
-        const unsigned char* x_s = sX + cur * PB * 128;
+        const unsigned char* d_s = smem + cur * STAGE;
+        const unsigned char* x_s = d_s + SD * SUB;
         if constexpr (sizeof(T) == 2) {
             const int q4 = i16 >> 2, p4 = i16 & 3;
 #pragma unroll
             for (int ks = 0; ks < PB / 32; ++ks) {
-                V16 af[WTL], bf[WTL];
+                V16 af[MTW], bf[NTW];
                 const int ra = ks * 32 + 8 * g + q4, rb = ra + 4;
 #pragma unroll
-                for (int a = 0; a < WTL; ++a) {
-                    const int cb = (wm * 32 + a * 16) >> 4;
+                for (int a = 0; a < MTW; ++a) {
+                    const int cm = wm * WCH_M + a * 16;
+                    const unsigned char* base = d_s + (cm / TK) * SUB;
+                    const int cb = (cm % TK) >> 4;
                     const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (bf16x4 __attribute__((address_space(3)))*)(d_s + ra * 128 + ((cb ^ fsw(ra)) << 5) + p4 * 8));
+                        (bf16x4 __attribute__((address_space(3)))*)(base + ra * 128 + ((cb ^ fsw(ra)) << 5) + p4 * 8));
                     const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (bf16x4 __attribute__((address_space(3)))*)(d_s + rb * 128 + ((cb ^ fsw(rb)) << 5) + p4 * 8));
+                        (bf16x4 __attribute__((address_space(3)))*)(base + rb * 128 + ((cb ^ fsw(rb)) << 5) + p4 * 8));
                     af[a].h = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 }
 #pragma unroll
-                for (int b = 0; b < WTL; ++b) {
-                    const int cb = (wn * 32 + b * 16) >> 4;
+                for (int b = 0; b < NTW; ++b) {
+                    const int cn = wn * WCH_N + b * 16;
+                    const unsigned char* base = x_s + (cn / TK) * SUB;
+                    const int cb = (cn % TK) >> 4;
                     const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (bf16x4 __attribute__((address_space(3)))*)(x_s + ra * 128 + ((cb ^ fsw(ra)) << 5) + p4 * 8));
+                        (bf16x4 __attribute__((address_space(3)))*)(base + ra * 128 + ((cb ^ fsw(ra)) << 5) + p4 * 8));
                     const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (bf16x4 __attribute__((address_space(3)))*)(x_s + rb * 128 + ((cb ^ fsw(rb)) << 5) + p4 * 8));
+                        (bf16x4 __attribute__((address_space(3)))*)(base + rb * 128 + ((cb ^ fsw(rb)) << 5) + p4 * 8));
                     bf[b].h = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 }
 #pragma unroll
-                for (int a = 0; a < WTL; ++a)
+                for (int a = 0; a < MTW; ++a)
 #pragma unroll
-                    for (int b = 0; b < WTL; ++b)
+                    for (int b = 0; b < NTW; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a].h, bf[b].h, acc[a][b], 0, 0, 0);
             }
         } else {
             // fp32: A[k-channel = lane&15][pixel = lane>>4] straight from the [pixel][channel] image
-            const int ca = wm * 16 + i16, cb_ = wn * 16 + i16;
-#pragma unroll 4
+#pragma unroll 2
             for (int ks = 0; ks < PB / 4; ++ks) {
                 const int row = ks * 4 + g;
-                const float av = *(const float*)(d_s + row * 128 + (((ca >> 3) ^ fsw(row)) << 5) + (ca & 7) * 4);
-                const float bv = *(const float*)(x_s + row * 128 + (((cb_ >> 3) ^ fsw(row)) << 5) + (cb_ & 7) * 4);
-                acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[0][0], 0, 0, 0);
+                float av[MTW], bv[NTW];
+#pragma unroll
+                for (int a = 0; a < MTW; ++a) {
+                    const int cm = wm * WCH_M + a * 16 + i16;
+                    av[a] = *(const float*)(d_s + (cm / TK) * SUB + row * 128 + ((((cm % TK) >> 3) ^ fsw(row)) << 5) + (cm & 7) * 4);
+                }
+#pragma unroll
+                for (int b = 0; b < NTW; ++b) {
+                    const int cn = wn * WCH_N + b * 16 + i16;
+                    bv[b] = *(const float*)(x_s + (cn / TK) * SUB + row * 128 + ((((cn % TK) >> 3) ^ fsw(row)) << 5) + (cn & 7) * 4);
+                }
+#pragma unroll
+                for (int a = 0; a < MTW; ++a)
+#pragma unroll
+                    for (int b = 0; b < NTW; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -170,14 +207,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
 
     float* out = p.partial + (size_t)split * p.K * p.Q;
 #pragma unroll
-    for (int a = 0; a < WTL; ++a)
+    for (int a = 0; a < MTW; ++a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int k = k0 + wm * (TK / 2) + a * 16 + g * 4 + r;
+            const int k = k0 + wm * WCH_M + a * 16 + g * 4 + r;
             if (k >= p.K) continue;
 #pragma unroll
-            for (int b = 0; b < WTL; ++b) {
-                const int qq = q0 + wn * (TK / 2) + b * 16 + i16;
+            for (int b = 0; b < NTW; ++b) {
+                const int qq = q0 + wn * WCH_N + b * 16 + i16;
                 if (qq < p.Q) out[(size_t)k * p.Q + qq] = acc[a][b][r];
             }
         }
@@ -223,43 +260,71 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
 //   transpose == 1: row = c, cdim = k (dgrad geometry)
 //   tap t = (tr, ts) in a TH x TW window reads source (r, s) = (rbase + rstep*tr, sbase + sstep*ts)
 //   stem == 1: forward only, cdim = s*4 + c over a [R][S*4] window (TH = R, TW = 1), c == 3 is zero
-template <typename T>
-__global__ void pack_weight_kernel(const float* __restrict__ w_a, int K_a, const float* __restrict__ w_b, int K_b, T* __restrict__ out,
-                                   int Kl, int C, int R, int S, int transpose, int TH, int TW, int rbase, int rstep, int sbase,
-                                   int sstep, int stem, int rows_total, int Kdp) {
+__device__ __forceinline__ float pack_value(const hdy_pack_desc& d, long long idx) {
     // logical weight W[k][c][r][s], k < Kl: rows of w_a, then rows of w_b, then zeros (channel padding)
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)rows_total * Kdp) return;
-    const int row = (int)(idx / Kdp), col = (int)(idx - (long long)row * Kdp);
+    const int row = (int)(idx / d.Kdp), col = (int)(idx - (long long)row * d.Kdp);
     int k = -1, c = 0, r = 0, s = 0;
-    if (stem) {
-        r = col / (S * 4);
-        const int rem = col - r * (S * 4);
+    if (d.stem) {
+        r = col / (d.S * 4);
+        const int rem = col - r * (d.S * 4);
         s = rem >> 2;
         c = rem & 3;
-        if (r < R && c < C) k = row;
+        if (r < d.R && c < d.C) k = row;
     } else {
-        const int cd = transpose ? Kl : C;
+        const int cd = d.transpose ? d.Kl : d.C;
         const int t = col / cd, ci = col - t * cd;
-        if (t < TH * TW) {
-            const int tr = t / TW, ts = t - tr * TW;
-            r = rbase + rstep * tr;
-            s = sbase + sstep * ts;
-            c = transpose ? row : ci;
-            if (r >= 0 && r < R && s >= 0 && s < S && c < C) k = transpose ? ci : row;
+        if (t < d.TH * d.TW) {
+            const int tr = t / d.TW, ts = t - tr * d.TW;
+            r = d.rbase + d.rstep * tr;
+            s = d.sbase + d.sstep * ts;
+            c = d.transpose ? row : ci;
+            if (r >= 0 && r < d.R && s >= 0 && s < d.S && c < d.C) k = d.transpose ? ci : row;
         }
     }
     float v = 0.f;
-    if (k >= 0 && k < K_a) v = w_a[(((size_t)k * C + c) * R + r) * S + s];
-    else if (k >= K_a && k < K_a + K_b) v = w_b[(((size_t)(k - K_a) * C + c) * R + r) * S + s];
-    out[idx] = from_f32<T>(v);
+    if (k >= 0 && k < d.K_a) v = d.w_a[(((size_t)k * d.C + c) * d.R + r) * d.S + s];
+    else if (k >= d.K_a && k < d.K_a + d.K_b) v = d.w_b[(((size_t)(k - d.K_a) * d.C + c) * d.R + r) * d.S + s];
+    return v;
+}
+
+// one job per launch (descriptor by value)
+__global__ __launch_bounds__(256) void pack_weight_kernel(const hdy_pack_desc d) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)d.rows_total * d.Kdp) return;
+    const float v = pack_value(d, idx);
+    if (d.dtype == HDY_BF16) ((bf16_t*)d.out)[idx] = (bf16_t)v;
+    else ((float*)d.out)[idx] = v;
+}
+
+// every job of a plan in one launch: block -> descriptor by binary search over first_block
+__global__ __launch_bounds__(256) void pack_batch_kernel(const hdy_pack_desc* __restrict__ table, int n) {
+    int lo = 0, hi = n - 1;
+    const int b = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid].first_block <= b) lo = mid; else hi = mid - 1;
+    }
+    const hdy_pack_desc d = table[lo];
+    const long long idx = (long long)(b - d.first_block) * blockDim.x + threadIdx.x;
+    if (idx >= (long long)d.rows_total * d.Kdp) return;
+    const float v = pack_value(d, idx);
+    if (d.dtype == HDY_BF16) ((bf16_t*)d.out)[idx] = (bf16_t)v;
+    else ((float*)d.out)[idx] = v;
 }
 
 }  // namespace
 
+static inline void wgrad_tile(int K, int Q, int dtype, int* sd, int* sx) {
+    const int TK = dtype == HDY_BF16 ? 64 : 32;
+    *sd = K > TK ? 2 : 1;
+    *sx = Q > TK ? 2 : 1;
+}
+
 int hdy_wgrad_plan(int K, int Q, long long P, int dtype, int* splits, int* pix_per_split) {
     const int TK = dtype == HDY_BF16 ? 64 : 32;
-    const int tiles = cdiv(K, TK) * cdiv(Q, TK);
+    int sd, sx;
+    wgrad_tile(K, Q, dtype, &sd, &sx);
+    const int tiles = cdiv(K, TK * sd) * cdiv(Q, TK * sx);
     int s = cdiv(1024, tiles);
     if (s > 512) s = 512;
     const int maxs = cdiv(P, 256);
@@ -272,6 +337,14 @@ int hdy_wgrad_plan(int K, int Q, long long P, int dtype, int* splits, int* pix_p
     return HDY_OK;
 }
 
+template <typename T>
+static void wgrad_dispatch(const WgradArgs& a, int sd, int sx, int grid, hipStream_t st) {
+    if (sd == 2 && sx == 2) hipLaunchKernelGGL((wgrad_kernel<T, 2, 2>), dim3(grid), dim3(256), 0, st, a);
+    else if (sd == 2) hipLaunchKernelGGL((wgrad_kernel<T, 2, 1>), dim3(grid), dim3(256), 0, st, a);
+    else if (sx == 2) hipLaunchKernelGGL((wgrad_kernel<T, 1, 2>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((wgrad_kernel<T, 1, 1>), dim3(grid), dim3(256), 0, st, a);
+}
+
 int hdy_wgrad_launch(WgradArgs a, int dtype, hipStream_t st) {
     const int VE = dtype == HDY_BF16 ? 8 : 4, TK = dtype == HDY_BF16 ? 64 : 32;
     HDY_ARG(a.x && a.dy && a.partial, "wgrad: null pointer");
@@ -281,14 +354,14 @@ int hdy_wgrad_launch(WgradArgs a, int dtype, hipStream_t st) {
     HDY_ARG((long long)a.N * a.Hin * a.Win < (1LL << 31) && (long long)a.N * a.Ho * a.Wo < (1LL << 31), "wgrad: too many pixels");
     a.Q = a.TH * a.TW * a.C;
     a.P = a.N * a.Ho * a.Wo;
-    a.ktiles = cdiv(a.K, TK);
-    a.qtiles = cdiv(a.Q, TK);
+    int sd, sx;
+    wgrad_tile(a.K, a.Q, dtype, &sd, &sx);
+    a.ktiles = cdiv(a.K, TK * sd);
+    a.qtiles = cdiv(a.Q, TK * sx);
     HDY_ARG(a.splits >= 1 && a.pix_per_split % PB == 0 && (long long)a.splits * a.pix_per_split >= a.P, "wgrad: bad split plan");
     const int grid = a.splits * a.ktiles * a.qtiles;
-    if (dtype == HDY_BF16)
-        hipLaunchKernelGGL(wgrad_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, a);
-    else
-        hipLaunchKernelGGL(wgrad_kernel<float>, dim3(grid), dim3(256), 0, st, a);
+    if (dtype == HDY_BF16) wgrad_dispatch<bf16_t>(a, sd, sx, grid, st);
+    else wgrad_dispatch<float>(a, sd, sx, grid, st);
     HDY_LAUNCH_CHECK("wgrad");
     return HDY_OK;
 }
@@ -303,17 +376,14 @@ int hdy_wgrad_reduce_launch(const float* partial, int splits, size_t slab_stride
     return HDY_OK;
 }
 
-int hdy_pack_weight_launch(const float* w_a, int K_a, const float* w_b, int K_b, void* out, int Kl, int C, int R, int S, int transpose,
-                           int TH, int TW, int rbase, int rstep, int sbase, int sstep, int stem, int rows_total, int Kdp, int dtype,
-                           hipStream_t st) {
-    const long long n = (long long)rows_total * Kdp;
-    const int grid = cdiv(n, 256);
-    if (dtype == HDY_BF16)
-        hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, w_a, K_a, w_b, K_b, (bf16_t*)out, Kl, C, R, S,
-                           transpose, TH, TW, rbase, rstep, sbase, sstep, stem, rows_total, Kdp);
-    else
-        hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(grid), dim3(256), 0, st, w_a, K_a, w_b, K_b, (float*)out, Kl, C, R, S, transpose,
-                           TH, TW, rbase, rstep, sbase, sstep, stem, rows_total, Kdp);
+int hdy_pack_weight_launch(const hdy_pack_desc& d, hipStream_t st) {
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(d.nblocks), dim3(256), 0, st, d);
     HDY_LAUNCH_CHECK("pack_weight");
+    return HDY_OK;
+}
+
+int hdy_pack_batch_launch(const hdy_pack_desc* table, int n, int total_blocks, hipStream_t st) {
+    hipLaunchKernelGGL(pack_batch_kernel, dim3(total_blocks), dim3(256), 0, st, table, n);
+    HDY_LAUNCH_CHECK("pack_batch");
     return HDY_OK;
 }

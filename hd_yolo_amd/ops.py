@@ -131,6 +131,39 @@ def rec_conv_wgrad(x, dy, grad_a, grad_b, R, S, stride, pad, ws, accumulate=Fals
                                ptr(ws), ws.numel() * ws.element_size(), dcode(x.dtype), stem))
 
 
+class PackTable:
+    """All weight re-packing jobs of a plan as ONE launch: descriptors are built once (hdy_conv_pack_describe), live in a small
+    device table, and hdy_conv_pack_run replays them after every optimizer step."""
+
+    def __init__(self, device):
+        self.device, self.descs, self.blocks, self.keep, self.table = device, [], 0, [], None
+
+    def add(self, w_a, w_b, stride, pad, kind, out, K=None):
+        K_a, C, R, S = w_a.shape
+        K_b = 0 if w_b is None else w_b.shape[0]
+        K = K_a + K_b if K is None else K
+        assert w_a.is_contiguous() and w_a.dtype == torch.float32 and (w_b is None or (w_b.is_contiguous() and w_b.shape[1:] == w_a.shape[1:]))
+        buf = (_lib.PackDesc * 4)()
+        n = _lib.query('hdy_conv_pack_describe', ptr(w_a), K_a, ptr(w_b), K_b, K, C, R, S, stride, pad, kind, dcode(out.dtype), ptr(out),
+                       ctypes.cast(buf, ctypes.c_void_p), self.blocks)
+        if n <= 0:
+            raise _lib.HdyError(f'hdy_conv_pack_describe failed: {_lib.load().hdy_last_error().decode()}')
+        for i in range(n):
+            d = _lib.PackDesc.from_buffer_copy(bytes(buf[i]))
+            self.descs.append(d)
+            self.blocks += d.nblocks
+        self.keep += [w_a, w_b, out]
+        self.table = None
+
+    def run(self):
+        if not self.descs:
+            return
+        if self.table is None:
+            raw = b''.join(bytes(d) for d in self.descs)
+            self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+        _lib.call('hdy_conv_pack_run', self.table.data_ptr(), len(self.descs), self.blocks, stream_ptr())
+
+
 # ------------------------------------------------------------------------------------------ BN / act
 def rec_bn_finalize(stats, mtiles, K, count, gamma, beta, rmean, rvar, scale, shift, save_mean, save_invstd,
                     eps=BN_EPS, momentum=BN_MOMENTUM, stats_ld=None, ws=None):

@@ -105,6 +105,7 @@ class Plan:
         self._order = 0
         self._trace(backbone, neck, head)
         self._allocate()
+        self.packs = ops.PackTable(device)          # every weight re-pack of the plan, one launch per step
         self.fwd = self._compile_forward()
         self.bwd = self._compile_backward() if training else None
         # the two launch lists have fixed pointers and shapes: after one eager run each they are captured into hipGraphs and
@@ -351,7 +352,7 @@ class Plan:
                 o0 = u.outs[0]
                 if t:
                     wb = u.mods[1].conv.weight if len(u.mods) > 1 else None
-                    recs.append(ops.rec_pack(u.mods[0].conv.weight, wb, u.s, u.p, kind, u.wp))
+                    self.packs.add(u.mods[0].conv.weight, wb, u.s, u.p, kind, u.wp)
                     M = o0.n * o0.h * o0.w
                     stats = self.stats[:u.mtiles * 2 * u.K].view(u.mtiles, 2, u.K)
                     recs.append(ops.rec_conv_fwd(x, u.wp, u.yraw, u.K, u.k, u.k, u.s, u.p, stats=stats, stem_hw=stem_hw))
@@ -366,7 +367,7 @@ class Plan:
                         k0 += K
                 else:
                     m, o = u.mods[0], u.outs[0]
-                    recs.append(ops.rec_pack(m.conv.weight, None, u.s, u.p, kind, u.wp))
+                    self.packs.add(m.conv.weight, None, u.s, u.p, kind, u.wp)
                     if u.has_bn:
                         g, b, rm, rv = self._bn(m)
                         recs.append(ops.rec_bn_eval_coeffs(g, b, rm, rv, u.scale, u.shift))
@@ -382,7 +383,7 @@ class Plan:
             elif isinstance(u, UpUnit):
                 recs.append(ops.rec_upsample_fwd(u.x.t(), u.out.t()))
             elif isinstance(u, DetUnit):
-                recs.append(ops.rec_pack(u.conv.weight, None, 1, 0, ops.PACK_FWD, u.wp))
+                self.packs.add(u.conv.weight, None, 1, 0, ops.PACK_FWD, u.wp)
                 recs.append(ops.rec_conv_fwd(u.x.t(), u.wp, u.logits[..., :u.K], u.K, 1, 1, 1, 0, shift=u.conv.bias))
         return recs
 
@@ -414,6 +415,7 @@ class Plan:
             ops.run([ops.rec_stem_prep(images, self.prep)])
         else:
             ops.run([ops.rec_nchw_to_nhwc(images, self.input.t())])
+        self.packs.run()
         self._replay('fwd', self.fwd)
         if self.training:
             torch._foreach_add_(self.bn_counters(), 1)
@@ -454,7 +456,7 @@ class Plan:
                 gw, gb = self._grad_views(u.conv.weight), self._grad_views(u.conv.bias)
                 recs.append(ops.rec_colsum(u.gdet, self._det_bias_tmp(u), self.bn_ws))
                 recs.append(ops.rec_conv_wgrad(x.t(), u.gdet, gw, None, 1, 1, 1, 0, self.wg_ws))
-                recs.append(ops.rec_pack(u.conv.weight, None, 1, 0, ops.PACK_DGRAD, u.wpd, K=u.Kp))
+                self.packs.add(u.conv.weight, None, 1, 0, ops.PACK_DGRAD, u.wpd, K=u.Kp)
                 recs.append(ops.rec_conv_dgrad(u.gdet, u.wpd, x.g(), 1, 1, 1, 0, accumulate=self._contrib(x)))
                 u.gb = gb
             elif isinstance(u, UpUnit):
@@ -480,7 +482,7 @@ class Plan:
                 recs.append(ops.rec_conv_wgrad(x, dy, ga, gb, u.k, u.k, u.s, u.p, self.wg_ws, stem_hw=stem_hw))
                 if not u.stem and u.x is not self.input:
                     wb = u.mods[1].conv.weight if len(u.mods) > 1 else None
-                    recs.append(ops.rec_pack(u.mods[0].conv.weight, wb, u.s, u.p, ops.PACK_DGRAD, u.wpd))
+                    self.packs.add(u.mods[0].conv.weight, wb, u.s, u.p, ops.PACK_DGRAD, u.wpd)
                     xv = u.x
                     if xv.parts is not None:
                         # writing the whole concat gradient: no part may already hold a partial contribution

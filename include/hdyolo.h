@@ -54,6 +54,22 @@ size_t hdy_conv_pack_elems(int K, int C, int R, int S, int stride, int pad, int 
 int hdy_conv_pack(const float* w_a, int K_a, const float* w_b, int K_b, int K, int C, int R, int S, int stride, int pad, int kind,
                   int dtype, void* out, void* stream);
 
+/* Batched packing: one launch re-packs every layer's weights after an optimizer step.  hdy_conv_pack_describe fills 1 (or 4:
+ * stride-2 dgrad parity classes) descriptors on the HOST for the same arguments as hdy_conv_pack and returns how many it wrote
+ * (first_block = running block count of the batch; each descriptor reports its nblocks); the caller copies all descriptors into
+ * device memory once and replays hdy_conv_pack_run(table, n, total_blocks) every step. */
+typedef struct hdy_pack_desc {
+    const float* w_a;
+    const float* w_b;
+    void* out;
+    int K_a, K_b, Kl, C, R, S, transpose, TH, TW, rbase, rstep, sbase, sstep, stem, rows_total, Kdp, dtype;
+    int first_block, nblocks;
+    int pad_;
+} hdy_pack_desc;
+int hdy_conv_pack_describe(const float* w_a, int K_a, const float* w_b, int K_b, int K, int C, int R, int S, int stride, int pad, int kind,
+                           int dtype, void* out, hdy_pack_desc* descs_host, int first_block);
+int hdy_conv_pack_run(const hdy_pack_desc* descs_device, int ndesc, int total_blocks, void* stream);
+
 /* y = act(scale[k] * conv(x, w)[.., k] + shift[k]) + res (+= y when accumulate).  scale/shift/res may be NULL (1 / 0 / none).
  * stats (optional, train-mode BN): [hdy_conv_mtiles(N*Ho*Wo)][2][K] floats, per-tile sum and sum of squares of
  * the raw convolution (before scale/shift/act).  out_f32: write fp32 even when dtype is bf16 (detection logits).
