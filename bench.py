@@ -71,7 +71,7 @@ def conv_roofline(device, iters=30):
     w = torch.randn((K, C, 3, 3), device=device) * 0.05
     y = torch.empty((N, H, W, K), dtype=dt, device=device)
     wp = ops.pack_alloc(K, C, 3, 3, 1, 1, ops.PACK_FWD, dt, device)
-    mt = (N * H * W + 127) // 128
+    mt = ops.stat_slabs(N, H, W, C, K, 3, 3, 1, 1, dt)
     stats = torch.empty((mt, 2, K), dtype=torch.float32, device=device)
     ops.run([ops.rec_pack(w, None, 1, 1, ops.PACK_FWD, wp)])
     rec = [ops.rec_conv_fwd(x, wp, y, K, 3, 3, 1, 1, stats=stats)]

@@ -24,6 +24,7 @@ SIGNATURES = {
     'hdy_version': (_I, []),
     'hdy_conv_out_dim': (_I, [_I, _I, _I, _I]),
     'hdy_conv_mtiles': (_I, [_L]),
+    'hdy_conv_stat_slabs': (_I, [_I] * 10),
     'hdy_conv_pack_elems': (_Z, [_I, _I, _I, _I, _I, _I, _I, _I]),
     'hdy_conv_pack': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     'hdy_conv_pack_describe': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I]),

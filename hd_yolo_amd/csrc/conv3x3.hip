@@ -40,16 +40,16 @@ __device__ __forceinline__ void glds16(const void* g, unsigned char* lds_wave_ba
 __global__ __launch_bounds__(NTHR) void conv3x3_c64_kernel(const ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sW = smem;                    // [9][64][128 B]
-    unsigned char* sP = smem + W_B;              // [2][180][128 B]
+    unsigned char* sP = smem + W_B;              // [2][324][128 B]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int fr = lane & 15, fq = lane >> 4;
     const int tiles_w = p.Wo / TW, tiles_h = p.Ho / TH;
-    const int tiles_img = tiles_w * tiles_h;
-    const int tiles_total = p.N * tiles_img;
+    const int tiles_total = p.N * tiles_w * tiles_h;
     const int tpb = (tiles_total + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int tile_begin = xcd_remap(blockIdx.x, gridDim.x) * tpb;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);       // logical workgroup: owns tiles [wg*tpb, ..) and statistics slab wg
+    const int tile_begin = wg * tpb;
     const int tile_end = min(tile_begin + tpb, tiles_total);
     if (tile_begin >= tile_end) return;
 
@@ -68,30 +68,50 @@ __global__ __launch_bounds__(NTHR) void conv3x3_c64_kernel(const ConvArgs p) {
         glds16(src, sW + (wave * 64 + NTHR * i) * 16);
     }
 
-    auto issue_patch = [&](int t, int buf) {
-        const int n = t / tiles_img, rem = t - n * tiles_img;
-        const int th_ = rem / tiles_w, tw_ = rem - th_ * tiles_w;
-        const int h0 = th_ * TH - 1, w0 = tw_ * TW - 1;
+    // ---- patch loader: each thread's 6 (pixel, chunk) slots of the 18x18 patch are the same for every tile; only the tile
+    // origin and the image-border test change, so the per-tile issue is a compare + select + add per DMA
+    int prel[6], pyx[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {                          // 2592 chunks / 512 threads (last pass partial)
+        const int pos = tid + NTHR * i;
+        const int pix = pos >> 3;
+        const int py = pix / PW, px = pix - py * PW;
+        const int lcp = (tid & 7) ^ ((px >> 1) & 7);      // patch swizzle keys on the COLUMN (see the fragment reads)
+        prel[i] = (py * p.Win + px) * p.ldx + lcp * 8;
+        pyx[i] = pos < PPIX * 8 ? (py | (px << 8)) : (1 << 20);   // out-of-range slot: fails every border test
+    }
+    struct TileAt { int n, th, tw; };
+    auto tile_at = [&](int t) {
+        const int per = tiles_w * tiles_h;
+        TileAt c;
+        c.n = t / per;
+        const int rem = t - c.n * per;
+        c.th = rem / tiles_w;
+        c.tw = rem - c.th * tiles_w;
+        return c;
+    };
+    auto advance = [&](TileAt& c) {
+        if (++c.tw == tiles_w) {
+            c.tw = 0;
+            if (++c.th == tiles_h) { c.th = 0; ++c.n; }
+        }
+    };
+    auto issue_patch = [&](const TileAt& c, int buf) {
+        const int h0 = c.th * TH - 1, w0 = c.tw * TW - 1;
+        const bf16_t* org = x + (((long long)c.n * p.Hin + h0) * p.Win + w0) * p.ldx;
         unsigned char* dst = sP + buf * PATCH_B;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {                      // 2592 chunks / 512 threads (last pass partial)
-            const int pos = tid + NTHR * i;
-            if (pos < PPIX * 8) {
-                const int pix = pos >> 3;
-                const int py = pix / PW, px = pix - py * PW;
-                const int h = h0 + py, ww = w0 + px;
-                const int lcp = (tid & 7) ^ ((px >> 1) & 7);      // patch swizzle keys on the COLUMN (see the fragment reads)
-                const void* src = zero;
-                if ((unsigned)h < (unsigned)p.Hin && (unsigned)ww < (unsigned)p.Win)
-                    src = x + (((size_t)n * p.Hin + h) * p.Win + ww) * p.ldx + lcp * 8;
-                glds16(src, dst + (wave * 64 + NTHR * i) * 16);
-            }
+        for (int i = 0; i < 6; ++i) {
+            if (i == 5 && tid >= PPIX * 8 - 5 * NTHR) break;                 // only the first 32 threads have a 6th slot
+            const int h = h0 + (pyx[i] & 255), ww = w0 + (pyx[i] >> 8);
+            const void* src = ((unsigned)h < (unsigned)p.Hin && (unsigned)ww < (unsigned)p.Win) ? (const void*)(org + prel[i]) : (const void*)zero;
+            glds16(src, dst + (wave * 64 + NTHR * i) * 16);
         }
     };
 
     // Per-lane LDS byte offsets, computed once: with the patch swizzle keyed on the patch column (fr + s) and the filter
     // swizzle on the filter row, every fragment address is lane_offset + compile-time constant, so the 108 reads per tile
-    // carry no address VALU at all (they were ~25 % of the issue slots of the MFMA loop).
+    // carry no address VALU at all.
     int aoff[3][2], boff[2][2];
 #pragma unroll
     for (int s = 0; s < 3; ++s)
@@ -108,14 +128,41 @@ __global__ __launch_bounds__(NTHR) void conv3x3_c64_kernel(const ConvArgs p) {
             boff[b][ks] = k * 128 + (((ks * 4 + fq) ^ ((k >> 1) & 7)) << 4);
         }
 
+    // The MFMAs run with the FILTER as the row operand, so a lane's 4 accumulator values are 4 consecutive output channels
+    // (wn*32 + b*16 + fq*4 + r) of ONE pixel ((wm*4 + a)*16 + fr): 8 packed bytes per (a, b) for the epilogue instead of four
+    // 2-byte scatters, and BatchNorm sums that stay in registers across all of the workgroup's tiles.
+    float sc[2][4], sh[2][4], s1[2][4], s2[2][4];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = wn * 32 + b * 16 + fq * 4 + r;
+            sc[b][r] = (p.scale && c < p.K) ? p.scale[c] : 1.0f;
+            sh[b][r] = (p.shift && c < p.K) ? p.shift[c] : 0.0f;
+            s1[b][r] = 0.f;
+            s2[b][r] = 0.f;
+        }
+    // epilogue staging: tile pixel row -> 128 bytes; 8-byte slot XOR (row & 14) makes the 16 lanes of a write hit 16 different
+    // slots (rows of equal slot differ in parity = in 128-byte half of the bank line); the 16-byte read-back sees whole chunks
+    const int st_ch = tid & 7, st_rr = tid >> 3;                              // store phase: chunk, first row (rows + 64 j)
+    const int st_lds = st_rr * 128 + ((st_ch ^ ((st_rr >> 1) & 7)) << 4);
+    const long long st_off = ((long long)(st_rr >> 4) * p.Wo + (st_rr & 15)) * p.ldy + st_ch * 8;
+    const long long st_step = (long long)4 * p.Wo * p.ldy;
+    const long long rs_off = ((long long)(st_rr >> 4) * p.Wo + (st_rr & 15)) * p.ldr + st_ch * 8;
+    const long long rs_step = (long long)4 * p.Wo * p.ldr;
+    int ep_off[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) ep_off[b] = (wm * 4 * 16 + fr) * 128 + (((wn * 8 + b * 4 + fq) ^ (fr & 14)) << 3);
+
     f32x4 acc[4][2];
-    const int HoWo = p.Ho * p.Wo;
-    issue_patch(tile_begin, 0);
+    TileAt cur_t = tile_at(tile_begin), nxt_t = cur_t;
+    advance(nxt_t);
+    issue_patch(cur_t, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cur = 0;
     for (int t = tile_begin; t < tile_end; ++t) {
-        if (t + 1 < tile_end) issue_patch(t + 1, cur ^ 1);
+        if (t + 1 < tile_end) issue_patch(nxt_t, cur ^ 1);
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -135,95 +182,65 @@ __global__ __launch_bounds__(NTHR) void conv3x3_c64_kernel(const ConvArgs p) {
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a].h, bf[b].h, acc[a][b], 0, 0, 0);
+                    for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[b].h, af[a].h, acc[a][b], 0, 0, 0);
             }
         }
         __syncthreads();                                   // everyone is done with patch `cur`: it becomes scratch
         unsigned char* scratch = sP + cur * PATCH_B;
-        const int n = t / tiles_img, rem = t - n * tiles_img;
-        const int th_ = rem / tiles_w, tw_ = rem - th_ * tiles_w;
         if (p.stats) {
-            float* red = (float*)scratch;                  // [4 (wm)][64][2]
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                float s1 = 0.f, s2 = 0.f;
+            for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float v = acc[a][b][r];
-                        s1 += v;
-                        s2 += v * v;
+                        s1[b][r] += v;
+                        s2[b][r] += v * v;
                     }
-                s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
-                s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-                if (lane < 16) {
-                    const int col = wn * 32 + b * 16 + lane;
-                    red[(wm * 64 + col) * 2 + 0] = s1;
-                    red[(wm * 64 + col) * 2 + 1] = s2;
-                }
-            }
-            __syncthreads();
-            if (tid < 128 && (tid & 63) < p.K) {
-                // one slab per 128 output pixels (the caller sized the slab array as M / 128): rows 0-7 and 8-15 of the tile
-                const int half = tid >> 6, c = tid & 63;
-                const size_t slab = (size_t)t * 2 + half;
-                p.stats[(slab * 2 + 0) * p.K + c] = red[((2 * half) * 64 + c) * 2] + red[((2 * half + 1) * 64 + c) * 2];
-                p.stats[(slab * 2 + 1) * p.K + c] = red[((2 * half) * 64 + c) * 2 + 1] + red[((2 * half + 1) * 64 + c) * 2 + 1];
-            }
-            __syncthreads();
         }
-        // ---- epilogue: scale/shift/act -> bf16 tile in LDS ([128 pixels][64 ch], 32-byte blocks XORed) -> 16-byte row stores
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int col = wn * 32 + b * 16 + fr;
-            const bool okk = col < p.K;
-            const float sc = (p.scale && okk) ? p.scale[col] : 1.0f;
-            const float sh = (p.shift && okk) ? p.shift[col] : 0.0f;
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int b = 0; b < 2; ++b) {
+                float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = (wm * 4 + a) * 16 + fq * 4 + r;         // tile pixel index ty*16 + tx
-                    float v = acc[a][b][r] * sc + sh;
-                    if (p.act == 1) v = silu_f(v);
-                    const int chunk = (col >> 3) ^ (((row >> 2) & 3) << 1);
-                    *(bf16_t*)(scratch + row * 128 + chunk * 16 + (col & 7) * 2) = (bf16_t)v;
+                    v[r] = acc[a][b][r] * sc[b][r] + sh[b][r];
+                    if (p.act == 1) v[r] = silu_f(v[r]);
                 }
-        }
+                bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                *(bf16x4*)(scratch + ep_off[b] + a * 16 * 128) = o;
+            }
         __syncthreads();
-        {
-            const int ch = tid & 7, rr = tid >> 3;            // 8 chunks per row, 64 rows per pass
-            const int kc = ch * 8;
-            if (kc < p.K) {
+        if (st_ch * 8 < p.K) {
+            const long long org = (((long long)cur_t.n * p.Ho + cur_t.th * TH) * p.Wo + cur_t.tw * TW);
+            bf16_t* yb = (bf16_t*)p.y + org * p.ldy + st_off;
+            const bf16_t* rb = p.res ? (const bf16_t*)p.res + org * p.ldr + rs_off : nullptr;
 #pragma unroll
-                for (int row = rr; row < TH * TW; row += NTHR / 8) {
-                    const int ty = row >> 4, tx = row & 15;
-                    const size_t opix = ((size_t)n * p.Ho + th_ * TH + ty) * p.Wo + tw_ * TW + tx;
-                    const int chunk = ch ^ (((row >> 2) & 3) << 1);
-                    V16 v;
-                    v.i = *(const i32x4*)(scratch + row * 128 + chunk * 16);
-                    if (p.res || p.accumulate) {
-                        float f[8];
+            for (int j = 0; j < 4; ++j) {
+                V16 v;
+                v.i = *(const i32x4*)(scratch + st_lds + j * 64 * 128);
+                if (p.res || p.accumulate) {
+                    float f[8];
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) f[e] = (float)v.h[e];
-                        if (p.res) {
-                            V16 q;
-                            q.i = *(const i32x4*)((const bf16_t*)p.res + opix * p.ldr + kc);
+                    for (int e = 0; e < 8; ++e) f[e] = (float)v.h[e];
+                    if (p.res) {
+                        V16 q;
+                        q.i = *(const i32x4*)(rb + j * rs_step);
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) f[e] += (float)q.h[e];
-                        }
-                        if (p.accumulate) {
-                            V16 q;
-                            q.i = *(const i32x4*)((const bf16_t*)p.y + opix * p.ldy + kc);
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) f[e] += (float)q.h[e];
-                        }
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v.h[e] = (bf16_t)f[e];
+                        for (int e = 0; e < 8; ++e) f[e] += (float)q.h[e];
                     }
-                    *(i32x4*)((bf16_t*)p.y + opix * p.ldy + kc) = v.i;
+                    if (p.accumulate) {
+                        V16 q;
+                        q.i = *(const i32x4*)(yb + j * st_step);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] += (float)q.h[e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v.h[e] = (bf16_t)f[e];
                 }
+                *(i32x4*)(yb + j * st_step) = v.i;
             }
         }
         // the next patch's DMA was issued before this tile's 4 row stores, and vmcnt retires in issue order: leaving the 4
@@ -231,30 +248,80 @@ __global__ __launch_bounds__(NTHR) void conv3x3_c64_kernel(const ConvArgs p) {
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         __syncthreads();
         cur ^= 1;
+        cur_t = nxt_t;
+        advance(nxt_t);
     }
-    (void)HoWo;
+
+    if (p.stats) {
+        // one slab per workgroup: 16 pixel lanes -> 4 tile-row groups (waves) -> global
+        float* red = (float*)sP;                           // [4 (wm)][64][2]; every patch buffer is idle after the last barrier
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float u = s1[b][r], q = s2[b][r];
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) {
+                    u += __shfl_xor(u, m);
+                    q += __shfl_xor(q, m);
+                }
+                if (fr == 0) {
+                    const int c = wn * 32 + b * 16 + fq * 4 + r;
+                    red[(wm * 64 + c) * 2 + 0] = u;
+                    red[(wm * 64 + c) * 2 + 1] = q;
+                }
+            }
+        __syncthreads();
+        if (tid < 128 && (tid & 63) < p.K) {
+            const int which = tid >> 6, c = tid & 63;
+            float v = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) v += red[(g * 64 + c) * 2 + which];
+            p.stats[((size_t)wg * 2 + which) * p.K + c] = v;
+        }
+    }
 }
 
 }  // namespace
 
+// Shape test shared by the launcher and the statistics-slab query (the two must agree on who writes the slabs).
+static bool conv3x3_shape_ok(int C, int K, int R, int S, int stride, int pad, int H, int W, int dtype) {
+    static const bool disabled = getenv("HDY_NO_CONV3X3") != nullptr;      // tests: force the generic kernel for A/B comparison
+    return !disabled && dtype == HDY_BF16 && R == 3 && S == 3 && stride == 1 && pad == 1 && C == 64 && K <= 64 && K % 8 == 0 && H % TH == 0 &&
+           W % TW == 0;
+}
+
+static int conv3x3_grid(int tiles) { return tiles < 256 ? tiles : 256; }     // one 153 KB, 8-wave workgroup per CU
+
+// Number of statistic slabs the filter-resident kernel writes for this shape (one per workgroup that owns tiles), 0 = not eligible.
+int hdy_conv3x3_c64_slabs(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dtype) {
+    if (!conv3x3_shape_ok(C, K, R, S, stride, pad, H, W, dtype)) return 0;
+    const int tiles = N * (H / TH) * (W / TW), grid = conv3x3_grid(tiles);
+    const int tpb = (tiles + grid - 1) / grid;
+    return (tiles + tpb - 1) / tpb;
+}
+
 // Returns 1 and launches when the shape qualifies; 0 = not eligible (caller falls back to the generic kernel); <0 / >0 = error.
 int hdy_conv3x3_c64_try(const ConvArgs& a, int dtype, int out_f32, hipStream_t st, int* rc) {
     if (dtype != HDY_BF16 || out_f32) return 0;
-    static const bool disabled = getenv("HDY_NO_CONV3X3") != nullptr;      // tests: force the generic kernel for A/B comparison
-    if (disabled) return 0;
-    if (!(a.TH == 3 && a.TW == 3 && a.ih_mul == 1 && a.iw_mul == 1 && a.dh0 == -1 && a.dw0 == -1 && a.dense_out)) return 0;
-    if (!(a.C == 64 && a.K <= 64 && a.K % 8 == 0 && a.Hin == a.Ho && a.Win == a.Wo && a.Ho % TH == 0 && a.Wo % TW == 0)) return 0;
-    if (!(a.ldx % 8 == 0 && a.ldy % 8 == 0 && ((uintptr_t)a.y & 15) == 0 && ((uintptr_t)a.x & 15) == 0)) return 0;
-    if (a.res && !(a.ldr % 8 == 0 && ((uintptr_t)a.res & 15) == 0)) return 0;
-    if (a.span_pixels) return 0;
+    if (!(a.TH == 3 && a.TW == 3 && a.ih_mul == 1 && a.iw_mul == 1 && a.dh0 == -1 && a.dw0 == -1 && a.dense_out && !a.span_pixels)) return 0;
+    if (!(a.Hin == a.Ho && a.Win == a.Wo && conv3x3_shape_ok(a.C, a.K, 3, 3, 1, 1, a.Ho, a.Wo, dtype))) return 0;
+    const bool aligned = a.ldx % 8 == 0 && a.ldy % 8 == 0 && ((uintptr_t)a.y & 15) == 0 && ((uintptr_t)a.x & 15) == 0 &&
+                         (!a.res || (a.ldr % 8 == 0 && ((uintptr_t)a.res & 15) == 0));
+    if (!aligned) {
+        if (!a.stats) return 0;
+        // the caller sized the slab array with hdy_conv_stat_slabs for THIS kernel: falling back would write a different count
+        hdy_set_error("conv3x3_c64: statistics requested but x/y/res rows are not 16-byte aligned (ldx=%d ldy=%d)", a.ldx, a.ldy);
+        *rc = HDY_EINVAL;
+        return 1;
+    }
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)conv3x3_c64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B);
         attr_set = true;
     }
     const int tiles = a.N * (a.Ho / TH) * (a.Wo / TW);
-    int grid = 256;                                        // one 153 KB, 8-wave workgroup per CU
-    if (grid > tiles) grid = tiles;
+    const int grid = conv3x3_grid(tiles);
     hipLaunchKernelGGL(conv3x3_c64_kernel, dim3(grid), dim3(NTHR), SMEM_B, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

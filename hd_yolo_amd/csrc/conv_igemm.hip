@@ -32,6 +32,8 @@
 //
 // Reference semantics replaced: nn.Conv2d inside metayolo/models/layers.py:31 (Conv), :92-93 (Bottleneck),
 // :124-126 (C3), :179-180 (SPPF), yolo_head.py:112 (det conv), and autograd's conv backward-data.
+#include <stdlib.h>
+
 #include "common.h"
 #include "hdyolo_internal.h"
 
@@ -62,26 +64,33 @@ __device__ __forceinline__ void glds16(const void* g, unsigned char* lds_wave_ba
                                      (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
 }
 
-constexpr int BM = 128;
-
-template <typename T, typename OT, int BN>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
+// BM x BN output tile, NTHR = 2*BM threads (BM/64 x 2 waves, each 64 x BN/2), NS-deep LDS ring of (A | B) stages.
+//   <128, *, 2>  4 waves, 2 stages: many small workgroups per CU (K <= 64, small problems)
+//   <256, *, 3>  8 waves (2 per SIMD), 3 stages with counted vmcnt: half the filter re-fetch per output, two k-blocks of
+//                DMA in flight across the barrier, one workgroup per CU (the K >= 128 layers, which were L2-fetch bound)
+template <typename T, typename OT, int BM, int BN, int NS>
+__global__ __launch_bounds__(2 * BM) void conv_igemm_kernel(const ConvArgs p) {
+    constexpr int NTHR = 2 * BM;
     constexpr int VE = Traits<T>::VE;
     constexpr int BKE = 8 * VE;          // elements per 128-byte k-block
-    constexpr int MT = BM / 32;          // 16-row tiles per wave
+    constexpr int MT = 4;                // 16-row tiles per wave (64 rows)
     constexpr int NT = BN / 32;          // 16-col tiles per wave
-    constexpr int AR = BM / 32;          // A rows staged per thread
-    constexpr int BR = BN / 32;          // B rows staged per thread
+    constexpr int AR = 4;                // A rows staged per thread (BM*8 chunks / NTHR)
+    constexpr int BR = BN * 8 / NTHR;    // B rows staged per thread
+    constexpr int RSTEP = NTHR / 8;      // row distance between a thread's staged rows
+    constexpr int LPS = AR + BR;         // DMA instructions per wave per stage
     constexpr int ASZ = BM * 128, BSZ = BN * 128, STAGE = ASZ + BSZ;
     constexpr bool VEC_OUT = sizeof(OT) == 2;
+    static_assert(BR >= 1, "tile too narrow for this thread count");
 
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2][A | B]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [NS][A | B]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int fr = lane & 15, fq = lane >> 4;
     const int ntiles = p.ntiles;
-    const int tiles_total = p.mtiles * ntiles;
+    const int mtiles = (p.M + BM - 1) / BM;
+    const int tiles_total = mtiles * ntiles;
     const int tpb = (tiles_total + (int)gridDim.x - 1) / (int)gridDim.x;
     const int tile_begin = xcd_remap(blockIdx.x, gridDim.x) * tpb;
     const int tile_end = min(tile_begin + tpb, tiles_total);
@@ -92,7 +101,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     const T* __restrict__ w = (const T*)p.w;
     const unsigned char* zero = (const unsigned char*)g_hdy_zero16;
 
-    // ------------------------------------------------------------------ loader (runs one k-block ahead)
+    // ------------------------------------------------------------------ loader (runs NS-1 k-blocks ahead)
     const int r0 = tid >> 3;
     const int lc = (tid & 7) ^ ((tid >> 4) & 7);       // logical chunk fetched into physical slot (tid & 7)
     int rm[AR], rn[AR], ri[AR], rj[AR];                  // output pixel of each staged row (general path)
@@ -107,7 +116,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
             if (ld_mtile < 0 || p.pointwise) {
 #pragma unroll
                 for (int i = 0; i < AR; ++i) {
-                    rm[i] = mt * BM + r0 + 32 * i;
+                    rm[i] = mt * BM + r0 + RSTEP * i;
                     if (!p.pointwise) {
                         const int mc = min(rm[i], p.M - 1);
                         rn[i] = mc / HoWo;
@@ -131,7 +140,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
             ld_mtile = mt;
         }
 #pragma unroll
-        for (int i = 0; i < BR; ++i) wrow[i] = w + (size_t)(nt * BN + r0 + 32 * i) * p.Kdp + lc * VE;
+        for (int i = 0; i < BR; ++i) wrow[i] = w + (size_t)(nt * BN + r0 + RSTEP * i) * p.Kdp + lc * VE;
         cc = lc * VE; th = 0; tw = 0;
         while (cc >= p.C) {
             cc -= p.C;
@@ -152,10 +161,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
                 if (rm[i] < p.M && th < p.TH && (unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win)
                     src = x + (((size_t)rn[i] * p.Hin + hi) * p.Win + wi) * p.ldx + cc;
             }
-            glds16(src, sa + (wave * 64 + 256 * i) * 16);
+            glds16(src, sa + (wave * 64 + NTHR * i) * 16);
         }
 #pragma unroll
-        for (int i = 0; i < BR; ++i) glds16(wrow[i] + (size_t)ld_kb * BKE, sb + (wave * 64 + 256 * i) * 16);
+        for (int i = 0; i < BR; ++i) glds16(wrow[i] + (size_t)ld_kb * BKE, sb + (wave * 64 + NTHR * i) * 16);
         // advance to the next k-block, possibly of the next tile
         if (++ld_kb == nkb) {
             ld_kb = 0;
@@ -178,11 +187,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     };
 
     // ------------------------------------------------------------------ epilogue of one finished tile
-    auto epilogue = [&](int t, unsigned char* scratch) {
+    // returns true when the coalesced path issued its fixed number of row stores per wave (full tile)
+    auto epilogue = [&](int t, unsigned char* scratch) -> bool {
         const int mtile = t / ntiles, ntile = t - mtile * ntiles;
         const int m0 = mtile * BM, n0 = ntile * BN;
         if (p.stats) {
-            float* red = (float*)scratch;       // [2 (wm)][BN][2]
+            float* red = (float*)scratch;       // [BM/64][BN][2]
 #pragma unroll
             for (int b = 0; b < NT; ++b) {
                 float s = 0.f, ss = 0.f;
@@ -205,9 +215,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
                 }
             }
             __syncthreads();
-            if (tid < BN && n0 + tid < p.K) {
-                p.stats[((size_t)mtile * 2 + 0) * p.K + n0 + tid] = red[tid * 2] + red[(BN + tid) * 2];
-                p.stats[((size_t)mtile * 2 + 1) * p.K + n0 + tid] = red[tid * 2 + 1] + red[(BN + tid) * 2 + 1];
+            // one slab per 128 output rows (what the caller sized): pairs of wave rows
+            for (int j = tid; j < (BM / 128) * BN; j += NTHR) {
+                const int half = j / BN, c = j - half * BN;
+                const size_t slab = (size_t)mtile * (BM / 128) + half;
+                if (n0 + c < p.K && (long long)slab * 128 < p.M) {
+                    p.stats[(slab * 2 + 0) * p.K + n0 + c] = red[((2 * half) * BN + c) * 2] + red[((2 * half + 1) * BN + c) * 2];
+                    p.stats[(slab * 2 + 1) * p.K + n0 + c] = red[((2 * half) * BN + c) * 2 + 1] + red[((2 * half + 1) * BN + c) * 2 + 1];
+                }
             }
             __syncthreads();
         }
@@ -222,73 +237,78 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
         }
         OT* __restrict__ y = (OT*)p.y;
         if (VEC_OUT && p.vec_out) {
-            // stage the bf16 tile in LDS (32-byte column blocks XORed with (row>>2)&3 so the four 4-row groups of a
-            // store instruction land on different banks), then write full rows with 16-byte stores
+            // stage 128 rows of the bf16 tile at a time in LDS (32-byte column blocks XORed with (row>>2)&3 so the four 4-row
+            // groups of a store instruction land on different banks), then write full rows with 16-byte stores
             constexpr int ROWB = BN * 2;                  // bytes per staged row
             constexpr int CPR = ROWB / 16;                // 16-byte chunks per row
+            constexpr int RPI = NTHR / CPR;               // rows per pass
 #pragma unroll
-            for (int a = 0; a < MT; ++a)
+            for (int half = 0; half < BM / 128; ++half) {
+                if ((wm >> 1) == half) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = wm * (BM / 2) + a * 16 + fq * 4 + r;
+                    for (int a = 0; a < MT; ++a)
 #pragma unroll
-                    for (int b = 0; b < NT; ++b) {
-                        float v = acc[a][b][r] * sc[b] + sh[b];
-                        if (p.act == 1) v = silu_f(v);
-                        const int col = wn * (BN / 2) + b * 16 + fr;
-                        const int chunk = (col >> 3) ^ ((((row >> 2) & 3) << 1) & (CPR - 1));
-                        *(bf16_t*)(scratch + row * ROWB + chunk * 16 + (col & 7) * 2) = (bf16_t)v;
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = (wm & 1) * 64 + a * 16 + fq * 4 + r;
+#pragma unroll
+                            for (int b = 0; b < NT; ++b) {
+                                float v = acc[a][b][r] * sc[b] + sh[b];
+                                if (p.act == 1) v = silu_f(v);
+                                const int col = wn * (BN / 2) + b * 16 + fr;
+                                const int chunk = (col >> 3) ^ ((((row >> 2) & 3) << 1) & (CPR - 1));
+                                *(bf16_t*)(scratch + row * ROWB + chunk * 16 + (col & 7) * 2) = (bf16_t)v;
+                            }
+                        }
+                }
+                __syncthreads();
+                const int ch = tid % CPR, rr = tid / CPR;
+                const int kc = n0 + ch * 8;
+                if (kc < p.K) {
+                    for (int row = rr; row < 128; row += RPI) {
+                        const int m = m0 + half * 128 + row;
+                        if (m >= p.M) break;
+                        size_t opix;
+                        if (p.dense_out) {
+                            opix = (size_t)m;
+                        } else {
+                            const int n = m / HoWo, rem = m - n * HoWo;
+                            const int oi = rem / p.Wo, oj = rem - oi * p.Wo;
+                            opix = ((size_t)n * p.Hout + (p.oh_off + oi * p.oh_mul)) * p.Wout + (p.ow_off + oj * p.ow_mul);
+                        }
+                        const int chunk = ch ^ ((((row >> 2) & 3) << 1) & (CPR - 1));
+                        V16 v;
+                        v.i = *(const i32x4*)(scratch + row * ROWB + chunk * 16);
+                        if (p.res || p.accumulate) {
+                            float f[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) f[e] = (float)v.h[e];
+                            if (p.res) {
+                                V16 q;
+                                q.i = *(const i32x4*)((const bf16_t*)p.res + opix * p.ldr + kc);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) f[e] += (float)q.h[e];
+                            }
+                            if (p.accumulate) {
+                                V16 q;
+                                q.i = *(const i32x4*)((const bf16_t*)p.y + opix * p.ldy + kc);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) f[e] += (float)q.h[e];
+                            }
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v.h[e] = (bf16_t)f[e];
+                        }
+                        *(i32x4*)((bf16_t*)p.y + opix * p.ldy + kc) = v.i;
                     }
                 }
-            __syncthreads();
-            constexpr int RPI = 256 / CPR;                // rows per pass
-            const int ch = tid % CPR, rr = tid / CPR;
-            const int kc = n0 + ch * 8;
-            if (kc < p.K) {
-                for (int row = rr; row < BM; row += RPI) {
-                    const int m = m0 + row;
-                    if (m >= p.M) break;
-                    size_t opix;
-                    if (p.dense_out) {
-                        opix = (size_t)m;
-                    } else {
-                        const int n = m / HoWo, rem = m - n * HoWo;
-                        const int oi = rem / p.Wo, oj = rem - oi * p.Wo;
-                        opix = ((size_t)n * p.Hout + (p.oh_off + oi * p.oh_mul)) * p.Wout + (p.ow_off + oj * p.ow_mul);
-                    }
-                    const int chunk = ch ^ ((((row >> 2) & 3) << 1) & (CPR - 1));
-                    V16 v;
-                    v.i = *(const i32x4*)(scratch + row * ROWB + chunk * 16);
-                    if (p.res || p.accumulate) {
-                        float f[8];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) f[e] = (float)v.h[e];
-                        if (p.res) {
-                            V16 q;
-                            q.i = *(const i32x4*)((const bf16_t*)p.res + opix * p.ldr + kc);
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) f[e] += (float)q.h[e];
-                        }
-                        if (p.accumulate) {
-                            V16 q;
-                            q.i = *(const i32x4*)((const bf16_t*)p.y + opix * p.ldy + kc);
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) f[e] += (float)q.h[e];
-                        }
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v.h[e] = (bf16_t)f[e];
-                    }
-                    *(i32x4*)((bf16_t*)p.y + opix * p.ldy + kc) = v.i;
-                }
+                __syncthreads();
             }
-            __syncthreads();
-            return;
+            return (mtile + 1) * BM <= p.M;
         }
 #pragma unroll
         for (int a = 0; a < MT; ++a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm * (BM / 2) + a * 16 + fq * 4 + r;
+                const int m = m0 + wm * 64 + a * 16 + fq * 4 + r;
                 if (m >= p.M) continue;
                 size_t opix;
                 if (p.dense_out) {
@@ -311,25 +331,43 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
                 }
             }
         }
+        return false;
     };
 
-    // ------------------------------------------------------------------ main loop over (tile, k-block)
+    // ------------------------------------------------------------------ main loop over the flattened (tile, k-block) sequence
+    // stage s lives in ring slot s % NS.  Iteration `it`: wait until stage it has landed (counted vmcnt: only the stages issued
+    // after it may still be in flight; vmcnt retires in issue order), barrier (also: everyone is done with stage it-1), issue
+    // stage it+NS-1 into the slot stage it-1 just vacated, then the MFMAs of stage it.
+    const int total = (tile_end - tile_begin) * nkb;
+    int issued = 0;
     loader_set_tile(tile_begin);
-    loader_issue(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    for (; issued < NS - 1 && issued < total; ++issued) loader_issue(issued % NS);
     zero_acc();
-    int c_tile = tile_begin, c_kb = 0, cur = 0;
-    while (true) {
-        const bool more = ld_tile < tile_end;
-        if (more) loader_issue(cur ^ 1);
-        const unsigned char* a_s = smem + cur * STAGE;
+    int c_tile = tile_begin, c_kb = 0;
+    bool stores_pending = false;          // the previous epilogue left its row stores in flight (younger than every issued DMA)
+    for (int it = 0; it < total; ++it) {
+        const int ahead = issued - it - 1;
+        // epilogue stores (if any) are younger than all DMA issued so far: counting them in keeps them off the critical path
+        constexpr int NST = VEC_OUT ? 128 / (NTHR / (BN / 8)) * (BM / 128) : 0;
+        const bool keep_stores = stores_pending && NST + LPS * (NS - 2) <= 60;
+        if (ahead >= 2 && NS >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+        else if (ahead >= 1 && NS >= 3) {
+            if (keep_stores) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS + NST) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+        } else {
+            if (keep_stores && NS == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        stores_pending = false;
+        if (issued < total) { loader_issue(issued % NS); ++issued; }
+        const unsigned char* a_s = smem + (it % NS) * STAGE;
         const unsigned char* b_s = a_s + ASZ;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             V16 af[MT], bf[NT];
 #pragma unroll
-            for (int a = 0; a < MT; ++a) af[a].i = *(const i32x4*)(a_s + swz(wm * (BM / 2) + a * 16 + fr, ks * 4 + fq));
+            for (int a = 0; a < MT; ++a) af[a].i = *(const i32x4*)(a_s + swz(wm * 64 + a * 16 + fr, ks * 4 + fq));
 #pragma unroll
             for (int b = 0; b < NT; ++b) bf[b].i = *(const i32x4*)(b_s + swz(wn * (BN / 2) + b * 16 + fr, ks * 4 + fq));
 #pragma unroll
@@ -337,54 +375,44 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
                 for (int b = 0; b < NT; ++b) acc[a][b] = mma16<T>(af[a], bf[b], acc[a][b]);
         }
-        bool stored = false;
         if (++c_kb == nkb) {
-            __syncthreads();                       // every wave is done reading stage `cur`: reuse it as scratch
-            epilogue(c_tile, smem + cur * STAGE);
-            // full tiles on the vector path issue exactly BM / (256 / (BN/8)) row stores per wave, after the prefetch DMA
-            stored = VEC_OUT && p.vec_out && ((c_tile / ntiles) + 1) * BM <= p.M;
+            __syncthreads();                       // every wave is done reading stage `it`: its slot is scratch until the next barrier
+            stores_pending = epilogue(c_tile, smem + (it % NS) * STAGE);
             zero_acc();
             c_kb = 0;
             ++c_tile;
         }
-        if (!more) break;
-        // vmcnt retires in issue order and the prefetch was issued before the epilogue's stores: leave those stores in flight
-        if (stored) {
-            if (BN == 128) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (BN == 64) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();
-        cur ^= 1;
     }
 }
 
-template <typename T, typename OT, int BN>
+template <typename T, typename OT, int BM, int BN, int NS>
 int launch(const ConvArgs& a, hipStream_t st) {
-    const size_t smem = 2 * (BM * 128 + BN * 128);
+    const size_t smem = (size_t)NS * (BM * 128 + BN * 128);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, OT, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, OT, BM, BN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
     }
     // persistent grid: as many workgroups as stay resident (LDS-limited), never more than tiles
-    const int per_cu = BN == 128 ? 2 : (BN == 64 ? 3 : 4);
-    int grid = 256 * per_cu;
-    const int tiles = a.mtiles * a.ntiles;
+    const int per_cu = (int)(160 * 1024 / smem) > 4 ? 4 : (int)(160 * 1024 / smem);
+    int grid = 256 * (per_cu < 1 ? 1 : per_cu);
+    const int tiles = cdiv(a.M, BM) * a.ntiles;
     if (grid > tiles) grid = tiles;
-    hipLaunchKernelGGL((conv_igemm_kernel<T, OT, BN>), dim3(grid), dim3(256), smem, st, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, OT, BM, BN, NS>), dim3(grid), dim3(2 * BM), smem, st, a);
     HDY_LAUNCH_CHECK("conv_igemm");
     return HDY_OK;
 }
 
 template <typename T, typename OT>
 int launch_bn(const ConvArgs& a, hipStream_t st) {
+    // 256-row tiles pay where the filter is re-fetched many times per output (multi-tap, wide K) and there is enough work to
+    // give every CU one of them; the single-tap layers are HBM-bound and prefer many small workgroups in flight (measured)
+    static const bool no_big = getenv("HDY_NO_BIG_TILES") != nullptr;
+    const bool big = a.bn == 128 && a.TH * a.TW > 1 && (long long)cdiv(a.M, 256) * a.ntiles >= 256 && !no_big;
     switch (a.bn) {
-        case 32: return launch<T, OT, 32>(a, st);
-        case 64: return launch<T, OT, 64>(a, st);
-        default: return launch<T, OT, 128>(a, st);
+        case 32: return launch<T, OT, 128, 32, 2>(a, st);
+        case 64: return launch<T, OT, 128, 64, 2>(a, st);
+        default: return big ? launch<T, OT, 256, 128, 3>(a, st) : launch<T, OT, 128, 128, 2>(a, st);
     }
 }
 
@@ -408,7 +436,7 @@ int hdy_conv_igemm_launch(ConvArgs a, int dtype, int out_f32, hipStream_t st) {
     a.bn = hdy_conv_bn_tile(a.K);
     HDY_ARG(a.Kdp == round_up(a.Kd, BKE), "conv: packed weight pitch %d != %d", a.Kdp, round_up(a.Kd, BKE));
     a.M = a.N * a.Ho * a.Wo;
-    a.mtiles = cdiv(a.M, BM);
+    a.mtiles = cdiv(a.M, 128);
     a.ntiles = cdiv(a.K, a.bn);
     if (a.dense_out) HDY_ARG(a.oh_mul == 1 && a.ow_mul == 1 && a.oh_off == 0 && a.ow_off == 0 && a.Hout == a.Ho && a.Wout == a.Wo, "conv: dense_out geometry mismatch");
     // 1x1 / stride 1 / no padding: input pixel == output pixel, no coordinate arithmetic in the loader

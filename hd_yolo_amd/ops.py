@@ -30,6 +30,11 @@ def dcode(dtype):
     raise _lib.HdyError(f'unsupported arithmetic type {dtype}: use torch.float32 or torch.bfloat16')
 
 
+def stat_slabs(N, H, W, C, K, R, S, stride, pad, dtype):
+    """How many [2][K] statistic slabs hdy_conv_fwd writes for this layer (kernel-dependent)."""
+    return _lib.query('hdy_conv_stat_slabs', N, H, W, C, K, R, S, stride, pad, dcode(dtype))
+
+
 def require_gpu(t):
     if not t.is_cuda:
         raise _lib.HdyError('hd_yolo_amd runs on MI355X only: tensor is on CPU and there is no CPU fallback '

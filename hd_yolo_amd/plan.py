@@ -274,10 +274,10 @@ class Plan:
                         raise _lib.HdyError('training a fused (BN-folded) model is not supported: build the model unfused')
                     u.yraw = self._new(o.n, o.h, o.w, u.K)
                     u.mean, u.invstd = self._new(u.K, dtype=f32), self._new(u.K, dtype=f32)
-                    u.mtiles = _lib.query('hdy_conv_mtiles', M)
+                    hin, win = (self.H, self.W) if u.stem else (u.x.h, u.x.w)
+                    u.mtiles = ops.stat_slabs(o.n, hin, win, u.C, u.K, u.k, u.k, u.s, u.p, dt)
                     max_stats = max(max_stats, u.mtiles * 2 * u.K)
                     max_dy = max(max_dy, M * u.K)
-                    hin, win = (self.H, self.W) if u.stem else (u.x.h, u.x.w)
                     max_wg = max(max_wg, ops.wgrad_ws_bytes(o.n, hin, win, u.C, u.K, u.k, u.k, u.s, u.p, dt, stem=u.stem))
                     max_bnws = max(max_bnws, ops.bn_bwd_ws_floats(M, max(u.Ks)))
                     if not u.stem:

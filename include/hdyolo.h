@@ -47,7 +47,10 @@ int hdy_version(void);
  * :124-131 (C3), :179-189 (SPPF) and metayolo/models/yolo_head.py:112,142 (Detect's 1x1 conv with bias);
  * backward is what train.py:472 `scaler.scale(loss).backward()` reaches through autograd. */
 int hdy_conv_out_dim(int in, int k, int stride, int pad);
-int hdy_conv_mtiles(long long M); /* number of BatchNorm statistic slabs hdy_conv_fwd writes for M output pixels */
+int hdy_conv_mtiles(long long M); /* upper bound of the statistic slab count: one per 128 output pixels */
+/* Number of [2][K] BatchNorm statistic slabs hdy_conv_fwd writes for this layer (kernel-dependent: one per 128 output pixels in
+ * the generic kernel, one per workgroup in the filter-resident 3x3 kernel).  hdy_bn_finalize takes the same number. */
+int hdy_conv_stat_slabs(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dtype);
 
 size_t hdy_conv_pack_elems(int K, int C, int R, int S, int stride, int pad, int kind, int dtype);
 /* Logical weight [K][C][R][S] = rows of w_a, then rows of w_b (two convs fused along K; may be NULL/0), then zero rows up to K. */
@@ -71,7 +74,7 @@ int hdy_conv_pack_describe(const float* w_a, int K_a, const float* w_b, int K_b,
 int hdy_conv_pack_run(const hdy_pack_desc* descs_device, int ndesc, int total_blocks, void* stream);
 
 /* y = act(scale[k] * conv(x, w)[.., k] + shift[k]) + res (+= y when accumulate).  scale/shift/res may be NULL (1 / 0 / none).
- * stats (optional, train-mode BN): [hdy_conv_mtiles(N*Ho*Wo)][2][K] floats, per-tile sum and sum of squares of
+ * stats (optional, train-mode BN): [hdy_conv_stat_slabs(...)][2][K] floats, partial sums and sums of squares of
  * the raw convolution (before scale/shift/act).  out_f32: write fp32 even when dtype is bf16 (detection logits).
  * stem: x is the hdy_stem_prep buffer; requires C=3, R=S=6, stride=2, pad=2, ldx=4. */
 int hdy_conv_fwd(const void* x, int ldx, const void* w_packed, const float* scale, const float* shift, const void* res, int ldr, void* y,

@@ -27,7 +27,7 @@ def _conv(x, w, dtype, stats=False):
     K = w.shape[0]
     wp = ops.pack_alloc(K, C, 3, 3, 1, 1, ops.PACK_FWD, dtype, DEV)
     y = torch.empty((N, H, W, K), dtype=dtype, device=DEV)
-    st = torch.zeros(((N * H * W + 127) // 128, 2, K), dtype=torch.float32, device=DEV) if stats else None
+    st = torch.full((ops.stat_slabs(N, H, W, C, K, 3, 3, 1, 1, dtype), 2, K), float('nan'), dtype=torch.float32, device=DEV) if stats else None
     ops.run([ops.rec_pack(w, None, 1, 1, ops.PACK_FWD, wp), ops.rec_conv_fwd(x, wp, y, K, 3, 3, 1, 1, stats=st)])
     return y, st
 

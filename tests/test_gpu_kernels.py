@@ -80,8 +80,8 @@ def test_conv_fwd_dgrad_wgrad(case, dtype):
     wp = ops.pack_alloc(K, C, R, R, stride, pad, ops.PACK_FWD, dtype, DEV)
     ybuf = torch.full((N, Ho, Wo, K + 8), 5.0, dtype=dtype, device=DEV)
     y = ybuf[..., 8:]
-    mt = _lib.query('hdy_conv_mtiles', N * Ho * Wo)
-    stats = torch.zeros((mt, 2, K), dtype=torch.float32, device=DEV)
+    mt = ops.stat_slabs(N, H, W, C, K, R, R, stride, pad, dtype)
+    stats = torch.full((mt, 2, K), float('nan'), dtype=torch.float32, device=DEV)       # every slab must be written
     ops.run([ops.rec_pack(wdev, None, stride, pad, ops.PACK_FWD, wp),
              ops.rec_conv_fwd(xd, wp, y, K, R, R, stride, pad, stats=stats)])
     ref = F.conv2d(x, wq, None, stride, pad)
