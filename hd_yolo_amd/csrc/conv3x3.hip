@@ -37,6 +37,8 @@ __device__ __forceinline__ void glds16(const void* g, unsigned char* lds_wave_ba
                                      (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
 }
 
+// EPI: 0 = raw convolution out (train-mode forward, dgrad), 1 = scale/shift, 2 = scale/shift + SiLU
+template <int EPI>
 __global__ __launch_bounds__(NTHR) void conv3x3_c64_kernel(const ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sW = smem;                    // [9][64][128 B]
@@ -96,17 +98,23 @@ __global__ __launch_bounds__(NTHR) void conv3x3_c64_kernel(const ConvArgs p) {
             if (++c.th == tiles_h) { c.th = 0; ++c.n; }
         }
     };
-    auto issue_patch = [&](const TileAt& c, int buf) {
-        const int h0 = c.th * TH - 1, w0 = c.tw * TW - 1;
-        const bf16_t* org = x + (((long long)c.n * p.Hin + h0) * p.Win + w0) * p.ldx;
-        unsigned char* dst = sP + buf * PATCH_B;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            if (i == 5 && tid >= PPIX * 8 - 5 * NTHR) break;                 // only the first 32 threads have a 6th slot
-            const int h = h0 + (pyx[i] & 255), ww = w0 + (pyx[i] >> 8);
-            const void* src = ((unsigned)h < (unsigned)p.Hin && (unsigned)ww < (unsigned)p.Win) ? (const void*)(org + prel[i]) : (const void*)zero;
-            glds16(src, dst + (wave * 64 + NTHR * i) * 16);
-        }
+    // (issuing the next patch piecewise from inside the MFMA loop was measured slower: 45.1 / 43.5 us against 42.9 us per
+    // launch with all six DMAs at the top of the tile — the loads land later and an in-order wave cannot issue MFMAs past a
+    // DMA that is waiting for a queue slot)
+    const bf16_t* iss_org = x;
+    int iss_h0 = 0, iss_w0 = 0;
+    unsigned char* iss_dst = sP;
+    auto issue_begin = [&](const TileAt& c, int buf) {
+        iss_h0 = c.th * TH - 1;
+        iss_w0 = c.tw * TW - 1;
+        iss_org = x + (((long long)c.n * p.Hin + iss_h0) * p.Win + iss_w0) * p.ldx;
+        iss_dst = sP + buf * PATCH_B;
+    };
+    auto issue_one = [&](int i) {
+        if (i == 5 && tid >= PPIX * 8 - 5 * NTHR) return;                    // only the first 32 threads have a 6th slot
+        const int h = iss_h0 + (pyx[i] & 255), ww = iss_w0 + (pyx[i] >> 8);
+        const void* src = ((unsigned)h < (unsigned)p.Hin && (unsigned)ww < (unsigned)p.Win) ? (const void*)(iss_org + prel[i]) : (const void*)zero;
+        glds16(src, iss_dst + (wave * 64 + NTHR * i) * 16);
     };
 
     // Per-lane LDS byte offsets, computed once: with the patch swizzle keyed on the patch column (fr + s) and the filter
@@ -157,12 +165,19 @@ __global__ __launch_bounds__(NTHR) void conv3x3_c64_kernel(const ConvArgs p) {
     f32x4 acc[4][2];
     TileAt cur_t = tile_at(tile_begin), nxt_t = cur_t;
     advance(nxt_t);
-    issue_patch(cur_t, 0);
+    issue_begin(cur_t, 0);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) issue_one(i);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cur = 0;
     for (int t = tile_begin; t < tile_end; ++t) {
-        if (t + 1 < tile_end) issue_patch(nxt_t, cur ^ 1);
+        const bool more = t + 1 < tile_end;
+        if (more) {
+            issue_begin(nxt_t, cur ^ 1);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) issue_one(i);
+        }
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -196,7 +211,7 @@ __global__ __launch_bounds__(NTHR) void conv3x3_c64_kernel(const ConvArgs p) {
                     for (int r = 0; r < 4; ++r) {
                         const float v = acc[a][b][r];
                         s1[b][r] += v;
-                        s2[b][r] += v * v;
+                        s2[b][r] = __builtin_fmaf(v, v, s2[b][r]);
                     }
         }
 #pragma unroll
@@ -206,8 +221,9 @@ __global__ __launch_bounds__(NTHR) void conv3x3_c64_kernel(const ConvArgs p) {
                 float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    v[r] = acc[a][b][r] * sc[b][r] + sh[b][r];
-                    if (p.act == 1) v[r] = silu_f(v[r]);
+                    v[r] = acc[a][b][r];
+                    if (EPI >= 1) v[r] = v[r] * sc[b][r] + sh[b][r];
+                    if (EPI == 2) v[r] = v[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[r]));     // SiLU; 1 ulp, then rounded to bf16
                 }
                 bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
                 *(bf16x4*)(scratch + ep_off[b] + a * 16 * 128) = o;
@@ -317,12 +333,17 @@ int hdy_conv3x3_c64_try(const ConvArgs& a, int dtype, int out_f32, hipStream_t s
     }
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_c64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B);
+        (void)hipFuncSetAttribute((const void*)conv3x3_c64_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B);
+        (void)hipFuncSetAttribute((const void*)conv3x3_c64_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B);
+        (void)hipFuncSetAttribute((const void*)conv3x3_c64_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B);
         attr_set = true;
     }
     const int tiles = a.N * (a.Ho / TH) * (a.Wo / TW);
     const int grid = conv3x3_grid(tiles);
-    hipLaunchKernelGGL(conv3x3_c64_kernel, dim3(grid), dim3(NTHR), SMEM_B, st, a);
+    const int epi = a.act == 1 ? 2 : ((a.scale || a.shift) ? 1 : 0);
+    if (epi == 2) hipLaunchKernelGGL(conv3x3_c64_kernel<2>, dim3(grid), dim3(NTHR), SMEM_B, st, a);
+    else if (epi == 1) hipLaunchKernelGGL(conv3x3_c64_kernel<1>, dim3(grid), dim3(NTHR), SMEM_B, st, a);
+    else hipLaunchKernelGGL(conv3x3_c64_kernel<0>, dim3(grid), dim3(NTHR), SMEM_B, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         hdy_set_error("conv3x3_c64: launch failed: %s", hipGetErrorString(e));
