@@ -5,7 +5,7 @@
 // activation bytes from L2 per output tile, plus the 73 KB filter per tile.  At ~2 us of L2 latency and 64 KB in flight per
 // CU that caps it near 9 TB/s of L2->LDS traffic, i.e. ~350 TFLOP/s on this layer whatever the MFMA schedule does.
 // Here each workgroup
-//   * keeps the whole filter (9 taps x 64 x 64 bf16 = 72 KB) in LDS for its lifetime (persistent over ~12 tiles),
+//   * keeps the whole filter (9 taps x 64 x 64 bf16 = 72 KB) in LDS for its lifetime (persistent over ~6 tiles),
 //   * stages one (16+2) x (16+2) input patch (41 KB) per 16x16 output tile by LDS-DMA, double buffered across tiles,
 //   * and reads all 9 taps' A fragments out of that patch: L2->LDS traffic per 256 outputs drops from 440 KB to 41 KB;
 //   * runs 8 waves (2 per SIMD) so one wave's fragment reads / address VALU overlap the other's MFMAs.
@@ -13,11 +13,19 @@
 // 16 lanes of a fragment read 16 consecutive patch pixels, and chunk ^ ((patch column>>1)&7) spreads them over all 16
 // 16-byte slots of the 256-byte bank row (conflict-free ds_read_b128).  LDS-DMA writes linearly, so that XOR is applied to the
 // source address (rule: linear destination + permuted source + permuted read).
-// Epilogue, BatchNorm slabs and numerics are those of conv_igemm.hip (same 16x16x32 bf16 MFMA tiling, 2x2 waves).
+// The MFMAs run with the FILTER as the row operand, so a lane's 4 accumulator values are 4 consecutive output channels of ONE
+// pixel: the epilogue packs them into one 8-byte LDS write (instead of four 2-byte scatters) and the BatchNorm sums stay in
+// registers across all of the workgroup's tiles (one statistics slab per workgroup).
+// Work split: every workgroup gets floor(tiles / grid) whole tiles; the remaining tiles are cut into 2 or 4 row bands so that
+// they still spread over all CUs (1600 tiles on 256 CUs: 6 tiles + one 4-row band each, instead of 229 CUs x 7 tiles).
+// Measured per-tile phases (shader clocks, 16x16 tile): patch DMA issue ~1.1k, MFMA ~4.7k (at the MFMA rate for 2 waves per
+// SIMD), epilogue ~0.5k, row stores ~0.6k, barriers ~0.5k.
 //
 // Requirements (checked by the launcher, otherwise the generic kernel runs): bf16 in/out, C == 64, K <= 64, R = S = 3,
 // stride 1, pad 1, H % 16 == 0, W % 16 == 0, 16-byte aligned rows.
 #include <stdlib.h>
+
+#include <type_traits>
 
 #include "common.h"
 #include "hdyolo_internal.h"
@@ -37,6 +45,23 @@ __device__ __forceinline__ void glds16(const void* g, unsigned char* lds_wave_ba
                                      (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
 }
 
+// The split of `tiles` whole tiles over `grid` workgroups, computed identically on host and device.
+struct WorkSplit {
+    int per;      // whole tiles per workgroup: workgroup g owns tiles [g*per, (g+1)*per)
+    int bands;    // the `rest` tiles after those are cut into this many row bands each (1, 2 or 4)
+    int units;    // rest * bands; workgroup g < units also owns band g % bands of tile per*grid + g / bands
+};
+__host__ __device__ inline WorkSplit work_split(int tiles, int grid) {
+    WorkSplit s;
+    s.per = tiles / grid;
+    const int rest = tiles - s.per * grid;
+    s.bands = rest * 4 <= grid ? 4 : (rest * 2 <= grid ? 2 : 1);
+    s.units = rest * s.bands;
+    return s;
+}
+
+struct Item { int n, th, tw, row0, nrows; };   // rows [row0, row0 + nrows) of tile (n, th, tw); nrows in {16, 8, 4}
+
 // EPI: 0 = raw convolution out (train-mode forward, dgrad), 1 = scale/shift, 2 = scale/shift + SiLU
 template <int EPI>
 __global__ __launch_bounds__(NTHR) void conv3x3_c64_kernel(const ConvArgs p) {
@@ -49,11 +74,9 @@ __global__ __launch_bounds__(NTHR) void conv3x3_c64_kernel(const ConvArgs p) {
     const int fr = lane & 15, fq = lane >> 4;
     const int tiles_w = p.Wo / TW, tiles_h = p.Ho / TH;
     const int tiles_total = p.N * tiles_w * tiles_h;
-    const int tpb = (tiles_total + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);       // logical workgroup: owns tiles [wg*tpb, ..) and statistics slab wg
-    const int tile_begin = wg * tpb;
-    const int tile_end = min(tile_begin + tpb, tiles_total);
-    if (tile_begin >= tile_end) return;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);       // logical workgroup: owns statistics slab wg
+    const WorkSplit ws = work_split(tiles_total, (int)gridDim.x);
+    const int nitems = ws.per + (wg < ws.units ? 1 : 0);   // >= 1: the launcher never starts more workgroups than tiles
 
     const bf16_t* __restrict__ x = (const bf16_t*)p.x;
     const bf16_t* __restrict__ w = (const bf16_t*)p.w;
@@ -70,8 +93,11 @@ __global__ __launch_bounds__(NTHR) void conv3x3_c64_kernel(const ConvArgs p) {
         glds16(src, sW + (wave * 64 + NTHR * i) * 16);
     }
 
-    // ---- patch loader: each thread's 6 (pixel, chunk) slots of the 18x18 patch are the same for every tile; only the tile
-    // origin and the image-border test change, so the per-tile issue is a compare + select + add per DMA
+    // ---- patch loader: each thread's 6 (pixel, chunk) slots of the 18-wide patch are the same for every item; only the
+    // origin, the number of patch rows and the image-border test change: a compare + select + add per DMA.
+    // (Issuing the next patch piecewise from inside the MFMA loop was measured slower: 45.1 / 43.5 us against 42.9 us per
+    // launch with all DMAs at the top of the item — the loads land later, and an in-order wave cannot issue MFMAs past a DMA
+    // that is waiting for a queue slot.)
     int prel[6], pyx[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {                          // 2592 chunks / 512 threads (last pass partial)
@@ -80,53 +106,54 @@ __global__ __launch_bounds__(NTHR) void conv3x3_c64_kernel(const ConvArgs p) {
         const int py = pix / PW, px = pix - py * PW;
         const int lcp = (tid & 7) ^ ((px >> 1) & 7);      // patch swizzle keys on the COLUMN (see the fragment reads)
         prel[i] = (py * p.Win + px) * p.ldx + lcp * 8;
-        pyx[i] = pos < PPIX * 8 ? (py | (px << 8)) : (1 << 20);   // out-of-range slot: fails every border test
+        pyx[i] = py | (px << 8);
     }
-    struct TileAt { int n, th, tw; };
-    auto tile_at = [&](int t) {
-        const int per = tiles_w * tiles_h;
-        TileAt c;
-        c.n = t / per;
-        const int rem = t - c.n * per;
+    auto item_at = [&](int idx) {
+        Item c;
+        int t;
+        if (idx < ws.per) {
+            t = wg * ws.per + idx;
+            c.row0 = 0;
+            c.nrows = TH;
+        } else {
+            t = ws.per * (int)gridDim.x + wg / ws.bands;
+            c.nrows = TH / ws.bands;
+            c.row0 = (wg % ws.bands) * c.nrows;
+        }
+        const int per_img = tiles_w * tiles_h;
+        c.n = t / per_img;
+        const int rem = t - c.n * per_img;
         c.th = rem / tiles_w;
         c.tw = rem - c.th * tiles_w;
         return c;
     };
-    auto advance = [&](TileAt& c) {
-        if (++c.tw == tiles_w) {
-            c.tw = 0;
-            if (++c.th == tiles_h) { c.th = 0; ++c.n; }
+    auto issue_patch = [&](const Item& c, int buf) {
+        const int h0 = c.th * TH + c.row0 - 1, w0 = c.tw * TW - 1;
+        const int prow = c.nrows + 2;
+        const bf16_t* org = x + (((long long)c.n * p.Hin + h0) * p.Win + w0) * p.ldx;
+        unsigned char* dst = sP + buf * PATCH_B;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int py = pyx[i] & 255;
+            // wave-uniform cut: the patch is filled in pixel order, so whole 1 KB pieces beyond its last row are skipped
+            if (((wave * 64 + NTHR * i) >> 3) >= prow * PW) break;
+            if (py >= prow) continue;                      // lanes past the patch's last pixel stay masked: no LDS write at all
+            const int h = h0 + py, ww = w0 + (pyx[i] >> 8);
+            const void* src = ((unsigned)h < (unsigned)p.Hin && (unsigned)ww < (unsigned)p.Win) ? (const void*)(org + prel[i]) : (const void*)zero;
+            glds16(src, dst + (wave * 64 + NTHR * i) * 16);
         }
-    };
-    // (issuing the next patch piecewise from inside the MFMA loop was measured slower: 45.1 / 43.5 us against 42.9 us per
-    // launch with all six DMAs at the top of the tile — the loads land later and an in-order wave cannot issue MFMAs past a
-    // DMA that is waiting for a queue slot)
-    const bf16_t* iss_org = x;
-    int iss_h0 = 0, iss_w0 = 0;
-    unsigned char* iss_dst = sP;
-    auto issue_begin = [&](const TileAt& c, int buf) {
-        iss_h0 = c.th * TH - 1;
-        iss_w0 = c.tw * TW - 1;
-        iss_org = x + (((long long)c.n * p.Hin + iss_h0) * p.Win + iss_w0) * p.ldx;
-        iss_dst = sP + buf * PATCH_B;
-    };
-    auto issue_one = [&](int i) {
-        if (i == 5 && tid >= PPIX * 8 - 5 * NTHR) return;                    // only the first 32 threads have a 6th slot
-        const int h = iss_h0 + (pyx[i] & 255), ww = iss_w0 + (pyx[i] >> 8);
-        const void* src = ((unsigned)h < (unsigned)p.Hin && (unsigned)ww < (unsigned)p.Win) ? (const void*)(iss_org + prel[i]) : (const void*)zero;
-        glds16(src, iss_dst + (wave * 64 + NTHR * i) * 16);
     };
 
     // Per-lane LDS byte offsets, computed once: with the patch swizzle keyed on the patch column (fr + s) and the filter
-    // swizzle on the filter row, every fragment address is lane_offset + compile-time constant, so the 108 reads per tile
-    // carry no address VALU at all.
+    // swizzle on the filter row, every fragment address is lane_offset + compile-time constant, so the fragment reads carry no
+    // address VALU at all.  (The wave's first patch row, wm * rows-per-wave, is added to the wave-uniform base pointer.)
     int aoff[3][2], boff[2][2];
 #pragma unroll
     for (int s = 0; s < 3; ++s)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int px = fr + s;
-            aoff[s][ks] = (wm * 4 * PW + px) * 128 + (((ks * 4 + fq) ^ ((px >> 1) & 7)) << 4);
+            aoff[s][ks] = px * 128 + (((ks * 4 + fq) ^ ((px >> 1) & 7)) << 4);
         }
 #pragma unroll
     for (int b = 0; b < 2; ++b)
@@ -136,9 +163,6 @@ __global__ __launch_bounds__(NTHR) void conv3x3_c64_kernel(const ConvArgs p) {
             boff[b][ks] = k * 128 + (((ks * 4 + fq) ^ ((k >> 1) & 7)) << 4);
         }
 
-    // The MFMAs run with the FILTER as the row operand, so a lane's 4 accumulator values are 4 consecutive output channels
-    // (wn*32 + b*16 + fq*4 + r) of ONE pixel ((wm*4 + a)*16 + fr): 8 packed bytes per (a, b) for the epilogue instead of four
-    // 2-byte scatters, and BatchNorm sums that stay in registers across all of the workgroup's tiles.
     float sc[2][4], sh[2][4], s1[2][4], s2[2][4];
 #pragma unroll
     for (int b = 0; b < 2; ++b)
@@ -150,7 +174,7 @@ __global__ __launch_bounds__(NTHR) void conv3x3_c64_kernel(const ConvArgs p) {
             s1[b][r] = 0.f;
             s2[b][r] = 0.f;
         }
-    // epilogue staging: tile pixel row -> 128 bytes; 8-byte slot XOR (row & 14) makes the 16 lanes of a write hit 16 different
+    // epilogue staging: item pixel row -> 128 bytes; 8-byte slot XOR (row & 14) makes the 16 lanes of a write hit 16 different
     // slots (rows of equal slot differ in parity = in 128-byte half of the bank line); the 16-byte read-back sees whole chunks
     const int st_ch = tid & 7, st_rr = tid >> 3;                              // store phase: chunk, first row (rows + 64 j)
     const int st_lds = st_rr * 128 + ((st_ch ^ ((st_rr >> 1) & 7)) << 4);
@@ -160,42 +184,30 @@ __global__ __launch_bounds__(NTHR) void conv3x3_c64_kernel(const ConvArgs p) {
     const long long rs_step = (long long)4 * p.Wo * p.ldr;
     int ep_off[2];
 #pragma unroll
-    for (int b = 0; b < 2; ++b) ep_off[b] = (wm * 4 * 16 + fr) * 128 + (((wn * 8 + b * 4 + fq) ^ (fr & 14)) << 3);
+    for (int b = 0; b < 2; ++b) ep_off[b] = fr * 128 + (((wn * 8 + b * 4 + fq) ^ (fr & 14)) << 3);
 
-    f32x4 acc[4][2];
-    TileAt cur_t = tile_at(tile_begin), nxt_t = cur_t;
-    advance(nxt_t);
-    issue_begin(cur_t, 0);
+    // ---- one item: AR = tile rows per wave (the item has 4*AR rows, wave wm owns rows wm*AR .. wm*AR + AR-1)
+    auto compute = [&](auto ar_c, const Item& it, int cur) {
+        constexpr int AR = decltype(ar_c)::value;
+        f32x4 acc[AR][2];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) issue_one(i);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int cur = 0;
-    for (int t = tile_begin; t < tile_end; ++t) {
-        const bool more = t + 1 < tile_end;
-        if (more) {
-            issue_begin(nxt_t, cur ^ 1);
-#pragma unroll
-            for (int i = 0; i < 6; ++i) issue_one(i);
-        }
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < AR; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const unsigned char* pb = sP + cur * PATCH_B;
+        const unsigned char* pb = sP + cur * PATCH_B + wm * AR * PW * 128;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int r = tap / 3, s = tap - 3 * r;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                V16 af[4], bf[2];
+                V16 af[AR], bf[2];
 #pragma unroll
-                for (int a = 0; a < 4; ++a)      // tile row wm*4 + a, patch row + r: a compile-time offset from the lane base
+                for (int a = 0; a < AR; ++a)     // item row wm*AR + a, patch row + r: a compile-time offset from the lane base
                     af[a].i = *(const i32x4*)(pb + aoff[s][ks] + (a + r) * PW * 128);
 #pragma unroll
                 for (int b = 0; b < 2; ++b) bf[b].i = *(const i32x4*)(sW + boff[b][ks] + tap * 64 * 128);
 #pragma unroll
-                for (int a = 0; a < 4; ++a)
+                for (int a = 0; a < AR; ++a)
 #pragma unroll
                     for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[b].h, af[a].h, acc[a][b], 0, 0, 0);
             }
@@ -206,7 +218,7 @@ __global__ __launch_bounds__(NTHR) void conv3x3_c64_kernel(const ConvArgs p) {
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int a = 0; a < 4; ++a)
+                for (int a = 0; a < AR; ++a)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float v = acc[a][b][r];
@@ -215,7 +227,7 @@ __global__ __launch_bounds__(NTHR) void conv3x3_c64_kernel(const ConvArgs p) {
                     }
         }
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < AR; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 float v[4];
@@ -226,15 +238,15 @@ __global__ __launch_bounds__(NTHR) void conv3x3_c64_kernel(const ConvArgs p) {
                     if (EPI == 2) v[r] = v[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[r]));     // SiLU; 1 ulp, then rounded to bf16
                 }
                 bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-                *(bf16x4*)(scratch + ep_off[b] + a * 16 * 128) = o;
+                *(bf16x4*)(scratch + ep_off[b] + (wm * AR + a) * 16 * 128) = o;
             }
         __syncthreads();
         if (st_ch * 8 < p.K) {
-            const long long org = (((long long)cur_t.n * p.Ho + cur_t.th * TH) * p.Wo + cur_t.tw * TW);
+            const long long org = (((long long)it.n * p.Ho + it.th * TH + it.row0) * p.Wo + it.tw * TW);
             bf16_t* yb = (bf16_t*)p.y + org * p.ldy + st_off;
             const bf16_t* rb = p.res ? (const bf16_t*)p.res + org * p.ldr + rs_off : nullptr;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < AR; ++j) {                 // 64 pixel rows of 128 bytes per pass
                 V16 v;
                 v.i = *(const i32x4*)(scratch + st_lds + j * 64 * 128);
                 if (p.res || p.accumulate) {
@@ -259,13 +271,28 @@ __global__ __launch_bounds__(NTHR) void conv3x3_c64_kernel(const ConvArgs p) {
                 *(i32x4*)(yb + j * st_step) = v.i;
             }
         }
-        // the next patch's DMA was issued before this tile's 4 row stores, and vmcnt retires in issue order: leaving the 4
+        // the next patch's DMA was issued before this item's AR row stores, and vmcnt retires in issue order: leaving the
         // stores in flight (instead of vmcnt(0)) keeps their ~2 us write latency off the critical path
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AR) : "memory");
         __syncthreads();
+    };
+
+    Item cur_it = item_at(0);
+    issue_patch(cur_it, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    for (int idx = 0; idx < nitems; ++idx) {
+        Item nxt_it = cur_it;
+        if (idx + 1 < nitems) {
+            nxt_it = item_at(idx + 1);
+            issue_patch(nxt_it, cur ^ 1);
+        }
+        if (cur_it.nrows == 16) compute(std::integral_constant<int, 4>{}, cur_it, cur);
+        else if (cur_it.nrows == 8) compute(std::integral_constant<int, 2>{}, cur_it, cur);
+        else compute(std::integral_constant<int, 1>{}, cur_it, cur);
         cur ^= 1;
-        cur_t = nxt_t;
-        advance(nxt_t);
+        cur_it = nxt_it;
     }
 
     if (p.stats) {
@@ -307,14 +334,15 @@ static bool conv3x3_shape_ok(int C, int K, int R, int S, int stride, int pad, in
            W % TW == 0;
 }
 
-static int conv3x3_grid(int tiles) { return tiles < 256 ? tiles : 256; }     // one 153 KB, 8-wave workgroup per CU
+static int conv3x3_grid(int tiles) {
+    static const int g = getenv("HDY_C3_GRID") ? atoi(getenv("HDY_C3_GRID")) : 256;
+    return tiles < g ? tiles : g;
+}     // one 153 KB, 8-wave workgroup per CU
 
-// Number of statistic slabs the filter-resident kernel writes for this shape (one per workgroup that owns tiles), 0 = not eligible.
+// Number of statistic slabs the filter-resident kernel writes for this shape (one per workgroup), 0 = not eligible.
 int hdy_conv3x3_c64_slabs(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dtype) {
     if (!conv3x3_shape_ok(C, K, R, S, stride, pad, H, W, dtype)) return 0;
-    const int tiles = N * (H / TH) * (W / TW), grid = conv3x3_grid(tiles);
-    const int tpb = (tiles + grid - 1) / grid;
-    return (tiles + tpb - 1) / tpb;
+    return conv3x3_grid(N * (H / TH) * (W / TW));
 }
 
 // Returns 1 and launches when the shape qualifies; 0 = not eligible (caller falls back to the generic kernel); <0 / >0 = error.

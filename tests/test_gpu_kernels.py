@@ -64,6 +64,10 @@ CONV_CASES = [
     (3, 40, 40, 256, 512, 1, 1, 0),
     (2, 16, 32, 64, 64, 3, 1, 1),        # qualifies for the filter-resident 3x3 kernel (bf16): C=64, H%16==0, W%16==0
     (3, 32, 48, 64, 32, 3, 1, 1),
+    # filter-resident kernel, more tiles than CUs: 320 tiles = 1 whole + a 4-row band per workgroup; 352 -> 8-row bands; 416 -> whole
+    (5, 128, 128, 64, 64, 3, 1, 1),
+    (2, 176, 256, 64, 48, 3, 1, 1),
+    (2, 208, 256, 64, 64, 3, 1, 1),
 ]
 
 
