@@ -90,6 +90,7 @@ struct NmsArgs {
     int max_det;
     float min_wh;
     int class_aware;
+    int xyxy;                     // rows are (x1, y1, x2, y2, score): torchvision.ops.nms on explicit boxes
     unsigned long long* ws;       // [B][P] sort workspace (global)
     int P;
     long long* keep;              // [B][max_det]
@@ -118,14 +119,19 @@ __device__ __forceinline__ bool iou_gt(float ax1, float ay1, float ax2, float ay
 
 struct Cand { float x1, y1, x2, y2, area, score; int cls; };
 
-__device__ __forceinline__ Cand make_cand(const float* p, int nc, int class_aware) {
+__device__ __forceinline__ Cand make_cand(const float* p, int nc, int class_aware, int xyxy = 0) {
     Cand c;
+    c.cls = 0;
+    if (xyxy) {
+        c.x1 = p[0]; c.y1 = p[1]; c.x2 = p[2]; c.y2 = p[3];
+        c.score = p[4];
+        return c;
+    }
     const float hw = p[2] / 2.0f, hh = p[3] / 2.0f;
     c.x1 = __fsub_rn(p[0], hw);
     c.y1 = __fsub_rn(p[1], hh);
     c.x2 = __fadd_rn(p[0], hw);
     c.y2 = __fadd_rn(p[1], hh);
-    c.cls = 0;
     c.score = p[4];
     if (class_aware) {
         float best = __fmul_rn(p[5], p[4]);
@@ -160,8 +166,9 @@ __global__ __launch_bounds__(NT) void nms_kernel(const NmsArgs p) {
         unsigned long long key = 0;
         if (i < p.N) {
             const float* r = rows + (size_t)i * p.row;
-            const Cand c = make_cand(r, p.nc, p.class_aware);
-            if (p.class_aware) ok = (r[4] > p.conf) && (c.score > p.conf);
+            const Cand c = make_cand(r, p.nc, p.class_aware, p.xyxy);
+            if (p.xyxy) ok = true;
+            else if (p.class_aware) ok = (r[4] > p.conf) && (c.score > p.conf);
             else ok = (__fsub_rn(c.x2, c.x1) >= p.min_wh) && (__fsub_rn(c.y2, c.y1) >= p.min_wh) && (c.score > p.conf);
             key = ((unsigned long long)(~__float_as_uint(c.score)) << 32) | (unsigned)i;
         }
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(NT) void nms_kernel(const NmsArgs p) {
         int src = 0;
         if (alive) {
             src = (int)(keys[s] & 0xFFFFFFFFull);
-            c = make_cand(rows + (size_t)src * p.row, p.nc, p.class_aware);
+            c = make_cand(rows + (size_t)src * p.row, p.nc, p.class_aware, p.xyxy);
             if (p.class_aware) {
                 const float off = (float)c.cls * 7680.0f;
                 c.x1 = __fadd_rn(c.x1, off); c.y1 = __fadd_rn(c.y1, off); c.x2 = __fadd_rn(c.x2, off); c.y2 = __fadd_rn(c.y2, off);
@@ -274,6 +281,7 @@ __global__ __launch_bounds__(NT) void nms_kernel(const NmsArgs p) {
     const int nsc = 1 + p.nc, nex = p.row - 5 - p.nc;
     for (int k = tid; k < p.max_det; k += NT) {
         if (k >= nk) { keep[k] = -1; continue; }
+        if (!p.out_boxes) continue;
         const float* r = rows + (size_t)keep[k] * p.row;
         const Cand c = make_cand(r, p.nc, p.class_aware);
         float* ob = p.out_boxes + ((size_t)b * p.max_det + k) * 4;
@@ -345,13 +353,34 @@ int hdy_nms_batched(const float* preds, int B, int N, int row, int nc, float con
     HDY_ARG(row == 5 + nc || out_extra, "nms: out_extra required when rows carry extra columns");
     NmsArgs a;
     a.preds = preds; a.B = B; a.N = N; a.row = row; a.nc = nc; a.conf = conf; a.iou = iou; a.max_det = max_det; a.min_wh = min_wh;
-    a.class_aware = class_aware; a.ws = (unsigned long long*)workspace; a.P = next_pow2(N > 1 ? N : 1);
+    a.class_aware = class_aware; a.xyxy = 0; a.ws = (unsigned long long*)workspace; a.P = next_pow2(N > 1 ? N : 1);
     a.keep = keep; a.n_keep = n_keep; a.out_boxes = out_boxes; a.out_scores = out_scores; a.out_extra = out_extra; a.out_conf = out_conf;
     a.out_cls = out_cls;
     const size_t smem = (size_t)LDS_KEYS * 8 + (size_t)MAX_KEEP * 16 + (size_t)MAX_KEEP * 4;
     (void)hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(NT), smem, (hipStream_t)stream, a);
     HDY_LAUNCH_CHECK("nms");
+    return HDY_OK;
+}
+
+int hdy_nms_boxes(const float* boxes_scores, int B, int N, float iou, int max_det, long long* keep, int* n_keep, void* workspace,
+                  size_t ws_bytes, void* stream) {
+    HDY_ARG(B >= 0 && N >= 0, "nms_boxes: negative size");
+    if (B == 0) return HDY_OK;
+    HDY_ARG(keep && n_keep, "nms_boxes: null output pointer");
+    HDY_ARG(N == 0 || boxes_scores, "nms_boxes: null input");
+    HDY_ARG(iou >= 0.f && iou <= 1.f, "nms_boxes: iou threshold must be in [0,1]");
+    HDY_ARG(max_det >= 1 && max_det <= MAX_KEEP, "nms_boxes: max_det=%d outside 1..%d", max_det, MAX_KEEP);
+    HDY_ARG(workspace && ws_bytes >= hdy_nms_workspace_bytes(B, N), "nms_boxes: workspace too small");
+    NmsArgs a;
+    a.preds = boxes_scores; a.B = B; a.N = N; a.row = 5; a.nc = 0; a.conf = 0.f; a.iou = iou; a.max_det = max_det; a.min_wh = 0.f;
+    a.class_aware = 0; a.xyxy = 1; a.ws = (unsigned long long*)workspace; a.P = next_pow2(N > 1 ? N : 1);
+    a.keep = keep; a.n_keep = n_keep; a.out_boxes = nullptr; a.out_scores = nullptr; a.out_extra = nullptr; a.out_conf = nullptr;
+    a.out_cls = nullptr;
+    const size_t smem = (size_t)LDS_KEYS * 8 + (size_t)MAX_KEEP * 16 + (size_t)MAX_KEEP * 4;
+    (void)hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(NT), smem, (hipStream_t)stream, a);
+    HDY_LAUNCH_CHECK("nms_boxes");
     return HDY_OK;
 }
 

@@ -99,6 +99,14 @@ class Engine:
         self.hook = None
         self.grad_hooks = []          # callables run after every backward, before publish (data-parallel all-reduce)
 
+    # An engine is a cache of device buffers and marshalled launch records for the module OBJECTS it was traced from: a copied or
+    # unpickled module (ModelEMA, Deploy(fuse=True), torch.save of a whole model) gets none and builds its own on first use.
+    def __deepcopy__(self, memo):
+        return None
+
+    def __reduce__(self):
+        return (type(None), ())
+
     def _params(self):
         seen, out = set(), []
         for part in self.parts:
@@ -117,9 +125,21 @@ class Engine:
         fused = tuple(hasattr(m, 'bn') for part in (b, n) if part is not None for m in part.modules() if type(m).__name__ == 'Conv')
         return hash(fused)
 
+    def _check_parameters(self):
+        """Plans and the flat gradient store hold the parameter OBJECTS they were traced with: when a caller swaps some (e.g.
+        manipulate_header_label_order replaces the header's detection convs) everything is rebuilt."""
+        ids = tuple(id(p) for p in self._params())
+        if ids != self.__dict__.get('_param_ids'):
+            if '_param_ids' in self.__dict__:
+                self.plans.clear()
+                self.store = None
+                self.hook = None
+            self._param_ids = ids
+
     def plan_for(self, x, training, dtype):
         ops.require_gpu(x)
         _lib.load()
+        self._check_parameters()
         key = (tuple(x.shape), dtype, bool(training), x.device.index, self._signature())
         plan = self.plans.get(key)
         if plan is None:

@@ -1,6 +1,6 @@
 """Detection metrics for the validation entry point (reference: metayolo/models/metrics.py:19-84 ap_per_class,
 :86-110 compute_ap, :251-408 APMeter).  Host-side numpy on at most max_det rows per tile: not a kernel target
-(SURVEY.md §2 row 5g); re-authored compactly with the same call surface (APMeter.add / ap_per_class)."""
+(SURVEY.md §2 row 5g); APMeter keeps the reference's matching rules and stats dictionary (pinned by tests/golden/apmeter.npz)."""
 import numpy as np
 import torch
 
@@ -13,7 +13,8 @@ def compute_ap(recall, precision):
     mpre = np.concatenate(([1.0], precision, [0.0]))
     mpre = np.flip(np.maximum.accumulate(np.flip(mpre)))
     x = np.linspace(0, 1, 101)
-    return np.trapz(np.interp(x, mrec, mpre), x), mpre, mrec
+    y = np.interp(x, mrec, mpre)
+    return float(np.sum((y[1:] + y[:-1]) * np.diff(x)) / 2.0), mpre, mrec     # trapezoid rule
 
 
 def ap_per_class(tp, conf, pred_cls, target_cls, eps=1e-16):
@@ -37,7 +38,16 @@ def ap_per_class(tp, conf, pred_cls, target_cls, eps=1e-16):
 
 
 class APMeter:
-    """Accumulates (detections, ground truth) per image; one-to-one greedy matching by IoU, class-aware AP."""
+    """Dataset-level detection AP with the reference's accumulation and matching rules (metayolo/models/metrics.py:251-375).
+
+    add(): per image, predictions are put in descending score order; every (prediction, truth) pair with IoU >= 0.5 is recorded
+    with dataset-global indices, the image's pairs in descending IoU order.
+    ap_per_class(): pairs touching an ignored label are dropped; each prediction keeps its first (= best-IoU) pair, then each
+    truth keeps the pair of its lowest-index (= best-score) prediction; a pair counts only when the two labels agree; a
+    prediction is a true positive at threshold t when its pair's IoU >= t.  Predictions whose only pairs were with ignored
+    truths are removed from the precision/recall curves.  Returns the reference's stats dict:
+    'labels', 'counts', 'px', 'py' (n_cls, 1000), 'ap' (n_cls, n_iou), 'p', 'r', 'f1' (n_cls, 1000).
+    Host-side numpy on <= max_det rows per tile (not a kernel target)."""
 
     def __init__(self, labels_text={}):
         self.iouv = np.linspace(0.5, 0.95, 10)
@@ -45,37 +55,101 @@ class APMeter:
         self.reset()
 
     def reset(self):
-        self.tp, self.scores, self.y_pred, self.y_true = [], [], [], []
+        self.n_pred = self.n_true = 0
+        self._scores, self._y_pred, self._y_true = [], [], []
+        self._m_pred, self._m_true, self._ious = [], [], []
+
+    # the reference exposes these as tensors; keep the names readable from outside
+    @property
+    def scores(self):
+        return np.concatenate(self._scores) if self._scores else np.zeros(0, np.float32)
+
+    @property
+    def y_pred(self):
+        return np.concatenate(self._y_pred) if self._y_pred else np.zeros(0, np.int64)
+
+    @property
+    def y_true(self):
+        return np.concatenate(self._y_true) if self._y_true else np.zeros(0, np.int64)
+
+    @property
+    def n_match(self):
+        return int(sum(len(v) for v in self._ious))
 
     def add(self, output, target, iou_type='boxes'):
-        scores, order = torch.sort(output['scores'].float(), descending=True)
-        boxes, labels = output['boxes'][order].float(), output['labels'][order]
-        tboxes, tlabels = target['boxes'].float().to(boxes.device), target['labels'].to(boxes.device)
-        n_pred, n_true = boxes.shape[0], tboxes.shape[0]
-        tp = np.zeros((n_pred, len(self.iouv)), dtype=bool)
-        if n_pred and n_true:
-            iou = box_iou(boxes, tboxes)
-            same = labels[:, None] == tlabels[None]
-            iou_np = (iou * same).cpu().numpy()
-            for j, thr in enumerate(self.iouv):
-                pi, ti = np.where(iou_np >= thr)
-                if len(pi):
-                    m = np.stack([pi, ti, iou_np[pi, ti]], 1)
-                    m = m[np.argsort(-m[:, 2])]
-                    m = m[np.unique(m[:, 0], return_index=True)[1]]
-                    m = m[np.argsort(-m[:, 2])]
-                    m = m[np.unique(m[:, 1], return_index=True)[1]]
-                    tp[m[:, 0].astype(int), j] = True
-        self.tp.append(tp)
-        self.scores.append(scores.cpu().numpy())
-        self.y_pred.append(labels.cpu().numpy())
-        self.y_true.append(tlabels.cpu().numpy())
+        if iou_type == 'masks' and 'masks' in output and 'masks' in target:
+            raise NotImplementedError('mask IoU belongs to the mask branch (SURVEY §8 row f2)')
+        scores, order = torch.sort(output['scores'].detach().float().cpu(), descending=True)
+        boxes = output['boxes'].detach().float().cpu()[order]
+        labels = output['labels'].detach().cpu()[order]
+        tboxes, tlabels = target['boxes'].detach().float().cpu(), target['labels'].detach().cpu()
+        iou = box_iou(boxes, tboxes).numpy() if len(boxes) and len(tboxes) else np.zeros((len(boxes), len(tboxes)), np.float32)
+        pi, ti = np.nonzero(iou >= self.iouv.min())
+        v = iou[pi, ti]
+        o = np.argsort(-v, kind='stable')
+        self._m_pred.append(pi[o] + self.n_pred)
+        self._m_true.append(ti[o] + self.n_true)
+        self._ious.append(v[o].astype(np.float32))
+        self._y_true.append(tlabels.numpy().astype(np.int64))
+        self._y_pred.append(labels.numpy().astype(np.int64))
+        self._scores.append(scores.numpy())
+        self.n_pred += len(boxes)
+        self.n_true += len(tboxes)
 
-    def ap_per_class(self, iouv=None, ignore=(-100, -1)):
-        tp = np.concatenate(self.tp) if self.tp else np.zeros((0, len(self.iouv)), dtype=bool)
-        conf = np.concatenate(self.scores) if self.scores else np.zeros(0)
-        pc = np.concatenate(self.y_pred) if self.y_pred else np.zeros(0)
-        tc = np.concatenate(self.y_true) if self.y_true else np.zeros(0)
-        keep_p, keep_t = ~np.isin(pc, ignore), ~np.isin(tc, ignore)
-        p, r, ap, f1, classes = ap_per_class(tp[keep_p], conf[keep_p], pc[keep_p], tc[keep_t])
-        return {'p': p, 'r': r, 'ap': ap, 'f1': f1, 'classes': classes, 'nt': np.bincount(tc[keep_t].astype(int))[classes] if len(classes) else np.zeros(0)}
+    def ap_per_class(self, iouv=None, ignore=(-100, -1), eps=1e-16):
+        # thresholds compare in fp32, as with the torch.linspace the reference's caller passes (val_nuclei.py:56)
+        iouv = np.asarray(self.iouv if iouv is None else iouv, dtype=np.float32)
+        cat = lambda parts, dt: np.concatenate(parts).astype(dt) if parts else np.zeros(0, dt)   # noqa: E731
+        m_pred, m_true, ious = cat(self._m_pred, np.int64), cat(self._m_true, np.int64), cat(self._ious, np.float32)
+        y_true, y_pred, scores = self.y_true, self.y_pred, self.scores
+        ignore = list(ignore) if ignore else []
+
+        ignored = (np.isin(y_true[m_true], ignore) | np.isin(y_pred[m_pred], ignore)) if ignore else np.zeros(len(m_pred), bool)
+        k_pred, k_true, k_iou = m_pred[~ignored], m_true[~ignored], ious[~ignored]
+        first = np.unique(k_pred, return_index=True)[1]            # one pair per prediction: its first = highest IoU
+        k_pred, k_true, k_iou = k_pred[first], k_true[first], k_iou[first]
+        first = np.unique(k_true, return_index=True)[1]            # one pair per truth: lowest prediction index
+        k_pred, k_true, k_iou = k_pred[first], k_true[first], k_iou[first]
+        agree = y_true[k_true] == y_pred[k_pred]
+        k_pred, k_iou = k_pred[agree], k_iou[agree]
+        hit = np.zeros((self.n_pred, len(iouv)), dtype=bool)
+        hit[k_pred] = k_iou[:, None] >= iouv[None]
+
+        if ignored.any():
+            live = np.ones(self.n_pred, dtype=bool)
+            live[np.setdiff1d(m_pred[ignored], k_pred)] = False
+            hit, scores, y_pred = hit[live], scores[live], y_pred[live]
+        order = np.argsort(-scores, kind='stable')
+        hit, scores, y_pred = hit[order], scores[order], y_pred[order]
+
+        px = np.linspace(0, 1, 1000)
+        out = {'labels': [], 'counts': [], 'px': px}
+        py, ap, p, r = [], [], [], []
+        for c, n_true in zip(*np.unique(y_true, return_counts=True)):
+            if c in ignore:
+                continue
+            out['labels'].append(c)
+            out['counts'].append(n_true)
+            sel = y_pred == c
+            if sel.sum() == 0 or n_true == 0:
+                ap.append(np.zeros(len(iouv)))
+                for curve in (r, p, py):
+                    curve.append(np.zeros(len(px)))
+                continue
+            tpc, fpc = hit[sel].cumsum(0), (~hit[sel]).cumsum(0)
+            # fp32 curves, as the reference's torch arithmetic produces them: with fp64 a recall of exactly k/n can land ON a
+            # knot of compute_ap's 101-point grid where the fp32 value falls just beside it, and the AP moves in the 4th digit
+            tp32 = tpc.astype(np.float32)
+            recall, precision = tp32 / np.float32(n_true + eps), tp32 / (tpc + fpc).astype(np.float32)
+            r.append(np.interp(-px, -scores[sel], recall[:, 0], left=0))
+            p.append(np.interp(-px, -scores[sel], precision[:, 0], left=1))
+            row = np.zeros(len(iouv))
+            for j in range(len(iouv)):
+                row[j], mpre, mrec = compute_ap(recall[:, j], precision[:, j])
+                if j == 0:
+                    py.append(np.interp(px, mrec, mpre))
+            ap.append(row)
+        stack = lambda rows, w: np.stack(rows) if rows else np.zeros((0, w))   # noqa: E731
+        out.update(py=stack(py, len(px)), ap=stack(ap, len(iouv)), p=stack(p, len(px)), r=stack(r, len(px)))
+        out['f1'] = 2 * out['p'] * out['r'] / (out['p'] + out['r'] + eps)
+        return out

@@ -188,6 +188,12 @@ def paired_box_iou(boxes1, boxes2):
 
 
 # ---------------------------------------------------------------------------------------------- NMS
+def nms(boxes, scores, iou_threshold):
+    """What the reference takes from torchvision.ops.nms (yolo.py:195): kept indices by descending score, IoU > threshold
+    suppressed, class-agnostic.  Runs on the MI355X (hdy_nms_boxes); at most 4096 boxes are kept."""
+    return _ops.nms(boxes, scores, iou_threshold)
+
+
 def _check_thresholds(conf_thres, iou_thres):
     assert 0 <= conf_thres <= 1, f'Invalid Confidence threshold {conf_thres}, valid values are between 0.0 and 1.0'
     assert 0 <= iou_thres <= 1, f'Invalid IoU {iou_thres}, valid values are between 0.0 and 1.0'

@@ -12,14 +12,14 @@ and leaves parameter gradients as views of one flat buffer.
 Arithmetic type: bf16 (fp32 accumulate) under torch autocast or after .half()/.bfloat16(); exact fp32 otherwise.
 """
 from copy import deepcopy
-from typing import Any
+from typing import Any, Dict, List, Union
 
 import torch
 import torch.nn as nn
 
 from .. import LOGGER, check_version, load_cfg  # noqa: F401
 from ... import engine as _engine
-from .utils_general import make_divisible  # noqa: F401
+from .utils_general import make_divisible, nms  # noqa: F401
 from .utils_torch import freeze_bn, freeze_params, fuse_conv_and_bn, initialize_weights, model_info, scale_img  # noqa: F401
 from .yolov5 import *  # noqa: F401,F403
 from .yolov5 import Conv, Detect, build_network
@@ -118,3 +118,76 @@ class Model(nn.Module):
         freeze_params(self, layers)
         freeze_bn(self, layers)
         return self
+
+
+class Deploy(nn.Module):
+    """Inference wrapper with the reference's call signature (reference: metayolo/models/yolo.py:110-142):
+    forward(x, compute_masks=True) -> (None, [ {task: {'boxes','scores','labels'}} per image ]).
+
+    The reference freezes backbone / neck / headers into TorchScript here; this build has nothing to script — the eval
+    launch list of the wrapped Model IS the deployed artefact (static HIP plan per input shape, BN folded into the conv
+    epilogue whether or not `fuse` is asked for).  `fuse=True` additionally folds the parameters themselves, as the reference
+    does, on a copy."""
+
+    def __init__(self, model, fuse=False):
+        super().__init__()
+        if fuse:
+            model = deepcopy(model).fuse()          # launch plans are per model object and are not copied (engine.Engine)
+        model.eval()
+        object.__setattr__(self, '_model', model)                # not a registered child: the module tree is the reference's
+        self.backbone, self.neck, self.headers = model.backbone, model.neck, model.headers
+
+    def half(self):
+        self._model.half()
+        return self
+
+    def float(self):
+        self._model.float()
+        return self
+
+    @torch.no_grad()
+    def forward(self, x: Union[List[torch.Tensor], torch.Tensor], compute_masks: bool = True):
+        if isinstance(x, (list, tuple)):
+            x = torch.stack(list(x))
+        _, outputs = self._model(x, compute_masks=compute_masks)
+        return None, self.post_processing(outputs)
+
+    def post_processing(self, x: Any):
+        return x
+
+
+class Ensemble(nn.ModuleList):
+    """Several models on the same tiles; per image and task their detections are pooled, thresholded and passed through one
+    class-agnostic NMS (reference: metayolo/models/yolo.py:145-204).  The NMS is the MI355X kernel (hdy_nms_boxes)."""
+
+    def __init__(self, models, nms_params: Dict[str, float] = {}):
+        super().__init__(models)
+        self.nms_params = self.get_nms_params(nms_params)
+
+    def get_nms_params(self, args={}):
+        defaults = {'conf_thres': 0.15, 'iou_thres': 0.45, 'max_det': 300}
+        return {k: float(args.get(k, v)) for k, v in defaults.items()}
+
+    @torch.no_grad()
+    def forward(self, x: Union[List[torch.Tensor], torch.Tensor], compute_masks: bool = True):
+        if isinstance(x, (list, tuple)):
+            x = torch.stack(list(x))
+        per_model = [m(x, compute_masks=compute_masks)[1] for m in self]
+        return None, [self.merge([o[i] for o in per_model]) for i in range(x.shape[0])]
+
+    def merge(self, x: List[Dict[str, Any]]):
+        res = {}
+        for task_id in sorted(set().union(*x)):
+            parts = [r[task_id] for r in x if task_id in r]
+            if any('masks' in q for q in parts):
+                raise NotImplementedError('mask branch (SURVEY §8 row f2) is not built yet')
+            boxes = torch.cat([q['boxes'] for q in parts])
+            scores = torch.cat([q['scores'] for q in parts])
+            labels = torch.cat([q['labels'] for q in parts])
+            sel = scores > self.nms_params['conf_thres']
+            boxes, scores, labels = boxes[sel], scores[sel], labels[sel]
+            if len(boxes):
+                keep = nms(boxes, scores, self.nms_params['iou_thres'])[:int(self.nms_params['max_det'])]
+                boxes, scores, labels = boxes[keep], scores[keep], labels[keep]
+            res[task_id] = {'boxes': boxes, 'scores': scores, 'labels': labels}
+        return res

@@ -313,6 +313,23 @@ def nms_batched(preds, nc, conf_thres, iou_thres, max_det, min_wh=2.0, class_awa
     return {'keep': keep, 'n_keep': n_keep, 'boxes': boxes, 'scores': scores, 'extra': extra[:, :, :nex], 'conf': conf, 'cls': cls}
 
 
+def nms(boxes, scores, iou_thres, max_det=4096):
+    """torchvision.ops.nms(boxes xyxy (N,4), scores (N,) >= 0, iou) on the GPU: kept indices (int64) in descending score order
+    (ties: lower index first), at most max_det <= 4096 of them."""
+    require_gpu(boxes)
+    N = boxes.shape[0]
+    if N == 0:
+        return torch.empty((0,), dtype=torch.int64, device=boxes.device)
+    bs = torch.cat([boxes.float(), scores.float().reshape(N, 1)], 1).contiguous()
+    keep = torch.empty((1, max_det), dtype=torch.int64, device=boxes.device)
+    n_keep = torch.empty((1,), dtype=torch.int32, device=boxes.device)
+    wsb = _lib.query('hdy_nms_workspace_bytes', 1, N)
+    ws = torch.empty((max(wsb, 8) // 8,), dtype=torch.int64, device=boxes.device)
+    _lib.call('hdy_nms_boxes', bs.data_ptr(), 1, N, float(iou_thres), int(max_det), keep.data_ptr(), n_keep.data_ptr(), ws.data_ptr(),
+              ws.numel() * 8, stream_ptr())
+    return keep[0, :int(n_keep.item())]
+
+
 # ------------------------------------------------------------------------------------------ fused detection loss
 class DetLossCall:
     """Pre-marshalled hdy_det_loss call for one plan (pointers and geometry are static; only the targets change)."""

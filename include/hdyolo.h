@@ -150,6 +150,12 @@ int hdy_nms_batched(const float* preds, int B, int N, int row, int nc, float con
                     long long* keep, int* n_keep, float* out_boxes, float* out_scores, float* out_extra, float* out_conf, int* out_cls,
                     void* workspace, size_t ws_bytes, void* stream);
 
+/* torchvision.ops.nms on explicit boxes, as the reference calls it outside nms_per_image (Ensemble.merge, metayolo/models/yolo.py:189-199):
+ * boxes_scores [B][N][5] = (x1, y1, x2, y2, score >= 0) fp32; every row is a candidate; keep[B][max_det] row indices in descending
+ * score order (stable), -1 padded; n_keep[B].  Same kernel, workspace and max_det limit as hdy_nms_batched. */
+int hdy_nms_boxes(const float* boxes_scores, int B, int N, float iou, int max_det, long long* keep, int* n_keep, void* workspace,
+                  size_t ws_bytes, void* stream);
+
 /* ---- fused detection loss --------------------------------------------------------------
  * Replaces Detect.matcher (metayolo/models/yolo_head.py:358-417), DetLoss.forward (metayolo/models/loss.py:190-244) with
  * bbox_iou(CIoU) (metayolo/models/utils_general.py:193-231) and their autograd backward: target assignment, CIoU box loss,

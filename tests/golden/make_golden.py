@@ -58,7 +58,18 @@ def install_shims():
             return yaml.safe_load(f)
 
     pkg.check_version, pkg.load_cfg = check_version, load_cfg
+    from pathlib import Path
+    pkg.ROOT, pkg.check_python = Path(REF) / 'metayolo', (lambda *a, **k: None)       # engines/general.py takes these too
     sys.modules['metayolo'] = pkg
+    eng = types.ModuleType('metayolo.engines')              # engines/__init__.py star-imports the training loop: skipped
+    eng.__path__ = [os.path.join(REF, 'metayolo', 'engines')]
+    sys.modules['metayolo.engines'] = eng
+    if 'cv2' not in sys.modules:            # engines/general.py imports cv2 at module level and aliases three GUI functions
+        cv2 = types.ModuleType('cv2')
+        cv2.imshow = cv2.imread = cv2.imwrite = cv2.imdecode = cv2.imencode = (lambda *a, **k: None)
+        cv2.IMREAD_COLOR = 1
+        cv2.setNumThreads = lambda n: None
+        sys.modules['cv2'] = cv2
 
     tv = types.ModuleType('torchvision')
     ops = types.ModuleType('torchvision.ops')
@@ -256,6 +267,101 @@ def gen_keys():
     print('wrote keys.npz', {k: int(v) for k, v in out.items() if k.endswith('nparams')})
 
 
+def synth_detections(seed=3):
+    """A small seeded validation set: per image ground truth (boxes px, labels in {1,2,3,-100}) and detections = jittered
+    copies of some truths + false positives, with a few wrong and a few -100 labels."""
+    g = torch.Generator().manual_seed(seed)
+    images = []
+    for n_true in (0, 3, 12, 20, 7, 15):
+        c = torch.rand((n_true, 2), generator=g) * 200 + 20
+        wh = torch.rand((n_true, 2), generator=g) * 30 + 10
+        tb = torch.cat([c - wh / 2, c + wh / 2], 1)
+        tl = torch.randint(1, 4, (n_true,), generator=g)
+        tl[torch.rand(n_true, generator=g) < 0.15] = -100
+        hit = torch.rand(n_true, generator=g) < 0.8
+        pb = tb[hit] + (torch.rand((int(hit.sum()), 4), generator=g) - 0.5) * 8
+        pl = tl[hit].clone()
+        wrong = torch.rand(len(pl), generator=g) < 0.2
+        pl[wrong] = torch.randint(1, 4, (int(wrong.sum()),), generator=g)
+        n_fp = int(torch.randint(0, 6, (1,), generator=g))
+        c = torch.rand((n_fp, 2), generator=g) * 200 + 20
+        wh = torch.rand((n_fp, 2), generator=g) * 30 + 10
+        pb = torch.cat([pb, torch.cat([c - wh / 2, c + wh / 2], 1)])
+        fl = torch.randint(1, 4, (n_fp,), generator=g)
+        fl[torch.rand(n_fp, generator=g) < 0.3] = -100
+        pl = torch.cat([pl, fl])
+        ps = torch.rand(len(pl), generator=g)
+        images.append(({'boxes': pb, 'scores': ps, 'labels': pl}, {'boxes': tb, 'labels': tl}))
+    return images
+
+
+def gen_f3():
+    """APMeter, Ensemble.merge, scale_coords, checkpoint re-keying and header label re-ordering."""
+    metrics = importlib.import_module('metayolo.models.metrics')
+    yolo = importlib.import_module('metayolo.models.yolo')
+    ug = importlib.import_module('metayolo.models.utils_general')
+    general = importlib.import_module('metayolo.engines.general')
+    out = {}
+    # --- APMeter
+    meter = metrics.APMeter({1: 'a', 2: 'b', 3: 'c'})
+    for i, (o, t) in enumerate(synth_detections()):
+        for k, v in o.items():
+            out[f'ap_in_{i}_o_{k}'] = npf(v)
+        for k, v in t.items():
+            out[f'ap_in_{i}_t_{k}'] = npf(v)
+        meter.add(o, t)
+    # iouv as the reference's caller passes it (val_nuclei.py:56): the np.linspace default does not run on this torch
+    for tag, kw in [('default', {}), ('noignore', {'ignore': []})]:
+        st = meter.ap_per_class(iouv=torch.linspace(0.5, 0.95, 10), **kw)
+        out[f'ap_{tag}_labels'] = np.array(st['labels'])
+        out[f'ap_{tag}_counts'] = np.array(st['counts'])
+        for k in ('py', 'ap', 'p', 'r', 'f1'):
+            out[f'ap_{tag}_{k}'] = np.asarray(st[k], dtype=np.float64)
+    # --- Ensemble.merge (NMS = the oracle's torchvision restatement)
+    ens = yolo.Ensemble([], {'conf_thres': 0.3, 'iou_thres': 0.4, 'max_det': 12})
+    parts = []
+    for j, (o, _) in enumerate(synth_detections(seed=8)[2:5]):
+        parts.append({'det': {k: v.clone() for k, v in o.items()}})
+        for k, v in o.items():
+            out[f'ens_in_{j}_{k}'] = npf(v)
+    merged = ens.merge(parts)['det']
+    for k, v in merged.items():
+        out[f'ens_out_{k}'] = npf(v)
+    # --- scale_coords
+    g = torch.Generator().manual_seed(4)
+    coords = torch.rand((9, 4), generator=g) * 640
+    out['sc_in'] = npf(coords)
+    out['sc_a'] = npf(ug.scale_coords((640, 640), coords.clone(), (480, 720)))
+    out['sc_b'] = npf(ug.scale_coords((512, 640), coords.clone(), (1000, 900), ratio_pad=((0.5, 0.5), (12.0, 7.0))))
+    # --- stock-YOLOv5 key conversion: keys only
+    model = ref_model('n', 2, synth.make_hyp())
+    nb, nn_ = len(model.backbone), len(model.neck)
+    stock = {}
+    for k, v in model.state_dict().items():
+        part, idx, rest = k.split('.', 2)
+        if part == 'backbone':
+            stock[f'model.{idx}.{rest}'] = v
+        elif part == 'neck':
+            stock[f'model.{int(idx) + nb}.{rest}'] = v
+        elif part == 'headers' and rest.startswith('m.'):
+            stock[f'model.{nb + nn_}.{rest}'] = v
+    conv = general.convert_yolo_weights(model, stock)
+    out['conv_in_keys'] = np.array(list(stock.keys()))
+    out['conv_out_keys'] = np.array(list(conv.keys()))
+    # --- header label re-ordering: new class i <- old class label_map[i]
+    model = ref_model('n', 3, synth.make_hyp())
+    head = model.headers['det']
+    for i, m in enumerate(head.m):
+        out[f'lm_in_w{i}'], out[f'lm_in_b{i}'] = npf(m.weight), npf(m.bias)
+    label_map = [2, 0, -1, 1]
+    general.manipulate_header_label_order(head, label_map)
+    out['lm_map'] = np.array(label_map)
+    for i, m in enumerate(head.m):
+        out[f'lm_out_w{i}'], out[f'lm_out_b{i}'] = npf(m.weight), npf(m.bias)
+    np.savez_compressed(os.path.join(HERE, 'f3.npz'), **out)
+    print('wrote f3.npz', out['ap_default_ap'].round(3).tolist(), out['ens_out_labels'].tolist(), out['conv_out_keys'][:2])
+
+
 def main():
     assert os.path.isdir(REF), 'the reference is only mounted in the build container'
     torch.set_num_threads(8)
@@ -267,6 +373,7 @@ def main():
     gen_stages('s_128', 's', 8, 1, 128, full=False)
     gen_train('n_64', 'n', 2, 2, 64, 3, 8)
     gen_train('s_128', 's', 8, 2, 128, 10, 30)
+    gen_f3()
 
 
 if __name__ == '__main__':

@@ -38,13 +38,23 @@ def flatten_onehot_objects(x):
 
 
 def summarize_stats(ap_meter, task_id, **kwargs):
-    stats = ap_meter.ap_per_class()
-    ap = stats['ap']
-    mp, mr = (float(stats['p'].mean()), float(stats['r'].mean())) if len(stats['p']) else (0.0, 0.0)
-    map50, map_ = (float(ap[:, 0].mean()), float(ap.mean())) if ap.size else (0.0, 0.0)
+    """Precision / recall / F1 at the best mean-F1 operating point, AP@.5 and AP@.5:.95 per class; the summary averages the
+    first four classes only, as the reference does for the NuCLS label set (val_nuclei.py:51-93)."""
+    stats = ap_meter.ap_per_class(iouv=torch.linspace(0.5, 0.95, 10), ignore=[-100, -1])
+    names = ap_meter.labels_text
     LOGGER.info(('%10s' * 2 + '%12s' * 5) % (task_id, 'Labels', 'P', 'R', 'F1', 'mAP@.5', 'mAP@.5:.95'))
-    LOGGER.info(('%10s' + '%10d' + '%12.3g' * 5) % ('all', int(np.sum(stats['nt'])), mp, mr, 2 * mp * mr / (mp + mr + 1e-16), map50, map_))
-    return {'fitness': 0.1 * map50 + 0.9 * map_, 'mp': mp, 'mr': mr, 'map50': map50, 'map': map_, 'per_class': stats}
+    if not len(stats['labels']):
+        return {'mp': 0.0, 'mr': 0.0, 'f1': 0.0, 'map50': 0.0, 'map': 0.0, 'fitness': 0.0}
+    idx = stats['f1'].mean(0).argmax()
+    p, r, f1 = stats['p'][:, idx], stats['r'][:, idx], stats['f1'][:, idx]
+    ap50, ap = stats['ap'][:, 0], stats['ap'].mean(1)
+    map50, map_ = float(ap50[:4].mean()), float(ap[:4].mean())
+    mp, mr, mf1 = float(p[:4].mean()), float(r[:4].mean()), float(f1[:4].mean())
+    pf = '%10s' + '%10i' + '%12.3g' * 5
+    LOGGER.info(pf % ('all', sum(stats['counts']), mp, mr, mf1, map50, map_))
+    for i, c in enumerate(stats['labels']):
+        LOGGER.info(pf % (names.get(c, str(c)), stats['counts'][i], p[i], r[i], f1[i], ap50[i], ap[i]))
+    return {'mp': mp, 'mr': mr, 'f1': mf1, 'map50': map50, 'map': map_, 'fitness': map50 * 0.1 + map_ * 0.9}
 
 
 @torch.no_grad()
