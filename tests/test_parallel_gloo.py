@@ -61,7 +61,8 @@ def _worker(rank, world, port, q):
         net.zero_grad()
         net(x_all).pow(2).sum().backward()
         ref = torch.cat([p.grad.reshape(-1) for p in params])
-        q.put((rank, same_start, [r[:ref.numel()] for r in results], ref, results[0][ref.numel():]))
+        # by value (numpy): a tensor on an mp.Queue is a shared-memory handle that dies with this process
+        q.put((rank, same_start, [r[:ref.numel()].numpy().copy() for r in results], ref.numpy().copy(), results[0][ref.numel():].numpy().copy()))
     finally:
         dist.destroy_process_group()
 
@@ -78,6 +79,7 @@ def test_two_rank_broadcast_and_sum_allreduce():
     for p in procs:
         p.join(30)
         assert p.exitcode == 0
+    out = [(r, s, [torch.from_numpy(a) for a in res], torch.from_numpy(ref), torch.from_numpy(tail)) for r, s, res, ref, tail in out]
     out.sort(key=lambda t: t[0])
     for rank, same_start, results, ref, tail in out:
         assert same_start, 'ranks did not start from rank 0 state'
