@@ -153,6 +153,21 @@ class Engine:
             self.plans[key] = plan
         return plan
 
+    def plan_for_features(self, feats, dtype):
+        """Eval plan of (neck, head) fed with bare feature maps {layer index: NCHW tensor} (FPN.forward / Detect.forward)."""
+        _lib.load()
+        self._check_parameters()
+        shapes = {k: tuple(v.shape) for k, v in feats.items() if isinstance(k, int) and k >= 0}
+        dev = next(iter(feats.values())).device
+        key = ('features', tuple(sorted(shapes.items())), dtype, dev.index, self._signature())
+        plan = self.plans.get(key)
+        if plan is None:
+            if len(self.plans) >= self.max_plans:
+                self.plans.pop(next(iter(self.plans)))
+            _, n, h = self.parts
+            plan = self.plans[key] = Plan(None, n, h, shapes, dtype, False, dev)
+        return plan
+
     def forward(self, x, training, dtype):
         """Returns (plan, det logits list).  With grad enabled in training mode the logits are attached to autograd."""
         plan = self.plan_for(x, training, dtype)

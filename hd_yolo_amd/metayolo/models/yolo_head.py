@@ -123,13 +123,19 @@ class Detect(nn.Module):
     # ------------------------------------------------------------------ forward
     def forward(self, x: Dict[int, torch.Tensor], targets=None, compute_masks: bool = True):
         """x: {layer index: NCHW feature map}.  Runs the level convs on a head-only HIP plan, then the shared tail."""
-        feats = [x[j] for j in self.f] if not isinstance(self.f, int) else [x[self.f]]
-        dets = self._det_convs(feats)
-        return self.forward_dets(dets, targets, compute_masks=compute_masks)
+        if self.training and torch.is_grad_enabled():
+            raise RuntimeError('Detect.forward on bare features is forward-only: train through Model (the det convs are part of '
+                               'the model plan and its backward)')
+        f = self.f if isinstance(self.f, (list, tuple)) else [self.f]
+        return self.forward_dets(self._det_convs({j: x[j] for j in f}), targets, compute_masks=compute_masks)
 
     def _det_convs(self, feats):
-        raise NotImplementedError('Detect on bare feature maps: run the head through Model (the det convs are part of the '
-                                  'model plan); a head-only plan is not wired yet')
+        eng = self.__dict__.get('_hdy_engine')
+        if eng is None:
+            eng = _engine.Engine(None, None, self)
+            object.__setattr__(self, '_hdy_engine', eng)
+        plan = eng.plan_for_features(feats, _engine.compute_dtype(self, next(iter(feats.values()))))
+        return list(plan.run_forward_features(feats))
 
     def forward_dets(self, dets: List[torch.Tensor], targets=None, compute_masks: bool = True):
         """Tail of Detect.forward given the per-level logits (bs, na, ny, nx, no) fp32."""

@@ -45,8 +45,22 @@ class FPN(nn.Sequential):
         self.save = return_layers or [len(self) - 1]
 
     def forward(self, x: Dict[int, torch.Tensor]) -> Dict[int, torch.Tensor]:
-        raise NotImplementedError('FPN on bare feature maps: the neck runs inside the Model plan (backbone + neck + det convs '
-                                  'are one launch list); call Model or Model.features instead')
+        """Neck on bare backbone features {layer index: NCHW} (eval statistics; training runs inside the Model plan).  Like the
+        reference (yolov5.py:68-77) the input dict is updated with the saved layers and `-1`."""
+        if self.training and torch.is_grad_enabled():
+            raise RuntimeError('FPN.forward on bare features is forward-only: train through Model (one launch list, one backward)')
+        eng = self.__dict__.get('_hdy_engine')
+        if eng is None:
+            eng = _engine.Engine(None, self, None)
+            object.__setattr__(self, '_hdy_engine', eng)
+        feats = {k: v for k, v in x.items() if isinstance(k, int) and k >= 0}
+        first = next(iter(feats.values()))
+        plan = eng.plan_for_features(feats, _engine.compute_dtype(self, first))
+        plan.run_forward_features(feats)
+        for k in self.save:
+            x[k] = plan.feature(k)
+        x[-1] = plan.feature(self[-1].i)
+        return {k: x[k] for k in self.save}
 
 
 def _resolve(name):

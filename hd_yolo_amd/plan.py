@@ -96,10 +96,19 @@ def _is(m, name):
 class Plan:
     def __init__(self, backbone, neck, head, shape, dtype, training, device, grad_store=None):
         """backbone / neck: the metayolo CSPDarkNet / FPN containers (neck, head may be None);
-        head: Detect module or None; shape = (B, 3, H, W)."""
+        head: Detect module or None; shape = (B, 3, H, W).
+        Feature-input plans (FPN.forward / Detect.forward called on bare feature maps): backbone is None and shape is
+        {layer index: (B, C, H, W)}; eval only."""
         self.dtype, self.training, self.device = dtype, training, device
-        self.B, self.Cin, self.H, self.W = shape
+        self.ext_shapes = dict(shape) if isinstance(shape, dict) else None
+        if self.ext_shapes is not None:
+            if backbone is not None or training:
+                raise _lib.HdyError('feature-input plans are neck/head-only and forward-only')
+            self.B, self.Cin, self.H, self.W = next(iter(self.ext_shapes.values()))[0], 0, 0, 0
+        else:
+            self.B, self.Cin, self.H, self.W = shape
         self.input = None
+        self.ext = {}
         self.vals, self.units = [], []
         self.grad_store = grad_store
         self._order = 0
@@ -205,11 +214,21 @@ class Plan:
 
     def _trace(self, backbone, neck, head):
         outs = {}
-        first = backbone[0]
+        if backbone is None:
+            for k, (b, c, h, w) in self.ext_shapes.items():
+                if c % 8:
+                    raise _lib.HdyError(f'feature map {k} has {c} channels: HIP plans take multiples of 8')
+                outs[k] = self._val(b, h, w, c, 'input')
+                outs[k].index = k
+            self.ext = dict(outs)
+            backbone = []
+        first = backbone[0] if len(backbone) else None
         is_stem = (type(first).__name__ == 'Conv' and self.Cin == 3 and first.conv.kernel_size == (6, 6)
                    and first.conv.stride == (2, 2) and first.conv.padding == (2, 2))
         if is_stem:
             x = None                       # the 6x6/s2 stem reads the padded 4-channel image directly
+        elif self.ext:
+            x = None
         else:
             if self.Cin % 8:
                 raise _lib.HdyError(f'input with {self.Cin} channels: only the 6x6/s2 RGB stem or channel counts that are '
@@ -219,7 +238,7 @@ class Plan:
             x = self._module(m, x)
             x.index = i
             outs[i] = x
-        self.feature_keys = list(getattr(backbone, 'save', [len(backbone) - 1]))
+        self.feature_keys = list(getattr(backbone, 'save', [len(backbone) - 1])) if len(backbone) else list(self.ext)
         if neck is not None:
             cur = None
             for m in neck:
@@ -404,6 +423,17 @@ class Plan:
 
     def bn_counters(self):
         return [m.bn.num_batches_tracked for u in self.units if isinstance(u, ConvUnit) and u.has_bn for m in u.mods]
+
+    def run_forward_features(self, feats):
+        """Feature-input plan: feats {layer index: NCHW tensor} -> det logits views (empty without a head)."""
+        for k, v in self.ext.items():
+            f = feats[k]
+            ops.require_gpu(f)
+            assert tuple(f.shape) == (v.n, v.c, v.h, v.w), (k, tuple(f.shape), (v.n, v.c, v.h, v.w))
+            ops.run([ops.rec_nchw_to_nhwc(f.float().contiguous(), v.t())])
+        self.packs.run()
+        self._replay('fwd', self.fwd)
+        return self.det_views()
 
     def run_forward(self, images):
         ops.require_gpu(images)

@@ -70,6 +70,34 @@ def test_eval_matches_reference_golden_fp32(golden_dir, tag, variant):
     assert total > 0
 
 
+def test_backbone_neck_head_called_separately_match_reference(golden_dir):
+    """CSPDarkNet.forward, FPN.forward (bare feature dict, mutated like the reference's) and Detect.forward as stand-alone calls
+    (reference: yolov5.py:47-77, yolo_head.py:132-183) against the same goldens as the whole-model run."""
+    g = np.load(os.path.join(golden_dir, 'stages_n_64.npz'))
+    batch, size, nc = (int(v) for v in g['meta'])
+    model = build('n', nc, synth.make_hyp(conf_thres=float(g['conf_thres']))).eval()
+    x = synth.synth_images(batch, size, seed=7).to(DEV)
+    with torch.no_grad():
+        feats = model.backbone(x)
+        assert sorted(feats) == sorted(model.backbone.save)
+        for k, v in feats.items():
+            assert relmax(v, g[f'backbone_{k}']) < 1e-4
+        fed = {k: v.clone() for k, v in feats.items()}
+        neck = model.neck(fed)
+        assert sorted(neck) == sorted(model.neck.save) and -1 in fed and all(k in fed for k in model.neck.save)
+        for k, v in neck.items():
+            assert relmax(v, g[f'neck_{k}']) < 1e-4
+        losses, outputs = model.headers['det'](neck)
+    assert losses == {}
+    for b in range(batch):
+        o = outputs[b]
+        np.testing.assert_allclose(o['boxes'].cpu().numpy(), g[f'out_{b}_boxes'], rtol=1e-4, atol=1e-3)
+        assert np.array_equal(o['labels'].cpu().numpy(), g[f'out_{b}_labels'])
+    model.train()
+    with pytest.raises(RuntimeError, match='forward-only'):
+        model.neck({k: v.clone() for k, v in feats.items()})
+
+
 def test_eval_nms_order_bit_exact_vs_oracle():
     """Same logits -> decode -> NMS on both sides: kept rows must be identical and in identical order."""
     from oracle.ref_net import RefNet
