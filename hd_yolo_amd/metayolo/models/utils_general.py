@@ -221,20 +221,49 @@ def nms_per_image(preds: torch.Tensor, nc: int, conf_thres: float = 0.25, iou_th
 
 def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
                         labels=(), max_det=300):
-    """Class-aware NMS on (B, N, 5+nc) predictions -> list of (n,6) [xyxy, conf, cls] per image, conf = obj*cls of the
-    best class, boxes of different classes never suppress each other (class offset 7680 px)."""
+    """Class-aware NMS on (B, N, 5+nc) predictions -> list of (n,6) [xyxy, conf, cls] per image (reference :423-523):
+    conf = obj*cls, best class per box (or one candidate per (box, class) above the threshold with multi_label), boxes of
+    different classes never suppress each other (class offset 7680 px) unless `agnostic`.
+    The default options run as ONE batched launch of the NMS kernel (filter + sort + greedy + gather); the rarely used ones
+    (multi_label, agnostic, classes, apriori labels) build the candidate list with tensor expressions per image and run the same
+    kernel on explicit boxes (hdy_nms_boxes)."""
     _check_thresholds(conf_thres, iou_thres)
     _ops.require_gpu(prediction)
-    if multi_label or labels or agnostic:
-        raise NotImplementedError('non_max_suppression: multi_label / apriori labels / agnostic are outside the hot path; '
-                                  'use nms_per_image for class-agnostic NMS')
     nc = prediction.shape[2] - 5
-    res = _ops.nms_batched(prediction.float().contiguous(), nc, conf_thres, iou_thres, int(max_det), class_aware=True)
-    n_keep = res['n_keep'].tolist()
+    multi_label = bool(multi_label) and nc > 1
+    has_labels = bool(len(labels)) and any(len(lb) for lb in labels)
+    if not (multi_label or agnostic or has_labels or classes is not None) and max_det <= 4096:
+        res = _ops.nms_batched(prediction.float().contiguous(), nc, conf_thres, iou_thres, int(max_det), class_aware=True)
+        n_keep = res['n_keep'].tolist()
+        return [torch.cat([res['boxes'][b, :n], res['conf'][b, :n, None], res['cls'][b, :n, None].float()], 1)
+                for b, n in enumerate(n_keep)]
     out = []
-    for b, n in enumerate(n_keep):
-        det = torch.cat([res['boxes'][b, :n], res['conf'][b, :n, None], res['cls'][b, :n, None].float()], 1)
-        if classes is not None:
-            det = det[(det[:, 5:6] == torch.tensor(classes, device=det.device)).any(1)]
+    for xi, x in enumerate(prediction.float()):
+        x = x[x[:, 4] > conf_thres]
+        if has_labels and len(labels[xi]):
+            lb = labels[xi].to(x.device, torch.float32)
+            v = torch.zeros((len(lb), nc + 5), device=x.device)
+            v[:, :4], v[:, 4] = lb[:, 1:5], 1.0
+            v[torch.arange(len(lb)), lb[:, 0].long() + 5] = 1.0
+            x = torch.cat((x, v), 0)
+        det = torch.zeros((0, 6), device=prediction.device)
+        if x.shape[0]:
+            x = x.clone()
+            x[:, 5:] *= x[:, 4:5]
+            box = xywh2xyxy(x[:, :4])
+            if multi_label:
+                i, j = (x[:, 5:] > conf_thres).nonzero(as_tuple=False).T
+                det = torch.cat((box[i], x[i, j + 5, None], j[:, None].float()), 1)
+            else:
+                conf, j = x[:, 5:].max(1, keepdim=True)
+                det = torch.cat((box, conf, j.float()), 1)[conf.view(-1) > conf_thres]
+            if classes is not None:
+                det = det[(det[:, 5:6] == torch.tensor(classes, device=det.device)).any(1)]
+        if det.shape[0] > 30000:
+            det = det[det[:, 4].argsort(descending=True, stable=True)[:30000]]
+        if det.shape[0]:
+            offs = det[:, 5:6] * (0.0 if agnostic else 7680.0)
+            keep = _ops.nms(det[:, :4] + offs, det[:, 4], iou_thres, max_det=min(int(max_det), 4096))
+            det = det[keep[:max_det]]
         out.append(det)
     return out

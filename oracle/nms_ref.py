@@ -99,6 +99,49 @@ def nms_per_image_numpy(preds, nc, conf_thres=0.25, iou_thres=0.45, max_det=300,
     return out
 
 
+def non_max_suppression_numpy(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
+                              labels=(), max_det=300):
+    """utils_general.py:423-523 with every option, on a (B, N, 5+nc) fp32 array -> list of (n, 6) [xyxy, conf, cls].
+    Follows the reference statement by statement (candidate filter obj > conf, apriori label rows, conf = obj*cls, best class
+    or multi-label expansion, class filter, 30000 pre-cut, class offset 7680 unless agnostic, greedy NMS, max_det)."""
+    prediction = np.asarray(prediction, dtype=np.float32)
+    nc = prediction.shape[2] - 5
+    multi_label = bool(multi_label) and nc > 1
+    out = []
+    for xi, x in enumerate(prediction):
+        x = x[x[:, 4] > np.float32(conf_thres)].copy()
+        if len(labels) and len(labels[xi]):
+            lb = np.asarray(labels[xi], dtype=np.float32)
+            v = np.zeros((len(lb), nc + 5), dtype=np.float32)
+            v[:, :4] = lb[:, 1:5]
+            v[:, 4] = 1.0
+            v[np.arange(len(lb)), lb[:, 0].astype(np.int64) + 5] = 1.0
+            x = np.concatenate([x, v], 0)
+        if not len(x):
+            out.append(np.zeros((0, 6), dtype=np.float32))
+            continue
+        x[:, 5:] *= x[:, 4:5]
+        box = xywh2xyxy_np(x[:, :4])
+        if multi_label:
+            i, j = np.nonzero(x[:, 5:] > np.float32(conf_thres))
+            det = np.concatenate([box[i], x[i, j + 5, None], j[:, None].astype(np.float32)], 1)
+        else:
+            j = x[:, 5:].argmax(1)
+            conf = x[np.arange(len(x)), j + 5]
+            det = np.concatenate([box, conf[:, None], j[:, None].astype(np.float32)], 1)[conf > np.float32(conf_thres)]
+        if classes is not None:
+            det = det[np.isin(det[:, 5], np.asarray(classes, dtype=np.float32))]
+        if not len(det):
+            out.append(np.zeros((0, 6), dtype=np.float32))
+            continue
+        if len(det) > 30000:
+            det = det[np.argsort(-det[:, 4], kind='stable')[:30000]]
+        c = det[:, 5:6] * np.float32(0 if agnostic else 7680)
+        keep = nms_numpy(det[:, :4] + c, det[:, 4], iou_thres)[:max_det]
+        out.append(det[keep])
+    return out
+
+
 def nms_batched_c(preds, nc, conf_thres, iou_thres, max_det, min_wh=2.0, class_aware=False):
     """C restatement on a (B, N, row) fp32 array -> (keep [B,max_det] int64, n_keep [B] int32, cls [B,max_det])."""
     preds = np.ascontiguousarray(preds, dtype=np.float32)

@@ -362,6 +362,40 @@ def gen_f3():
     print('wrote f3.npz', out['ap_default_ap'].round(3).tolist(), out['ens_out_labels'].tolist(), out['conv_out_keys'][:2])
 
 
+NMS_OPTION_CASES = {
+    'default': {},
+    'multi': {'multi_label': True},
+    'agnostic': {'agnostic': True},
+    'classes': {'classes': [0, 2]},
+    'multi_agnostic_top5': {'multi_label': True, 'agnostic': True, 'max_det': 5},
+    'apriori': {'labels': 'LABELS'},
+}
+
+
+def nms_option_inputs():
+    preds = synth.synth_nms_preds(2, 400, 3, seed=21, extra=200).numpy()[:, :, :8].copy()
+    g = np.random.default_rng(5)
+    labels = [np.concatenate([g.integers(0, 3, (4, 1)).astype(np.float32), g.uniform(40, 300, (4, 2)).astype(np.float32),
+                              g.uniform(10, 30, (4, 2)).astype(np.float32)], 1), np.zeros((0, 5), np.float32)]
+    return preds, labels
+
+
+def gen_nms_options():
+    """non_max_suppression (utils_general.py:423-523) with every option, NMS step = the oracle's torchvision restatement."""
+    ug = importlib.import_module('metayolo.models.utils_general')
+    preds, labels = nms_option_inputs()
+    out = {'preds': preds, 'labels_0': labels[0], 'labels_1': labels[1]}
+    for tag, kw in NMS_OPTION_CASES.items():
+        kw = dict(kw)
+        if kw.get('labels') == 'LABELS':
+            kw['labels'] = [torch.from_numpy(l) for l in labels]
+        res = ug.non_max_suppression(torch.from_numpy(preds.copy()), conf_thres=0.2, iou_thres=0.5, **kw)
+        for b, d in enumerate(res):
+            out[f'{tag}_{b}'] = npf(d)
+    np.savez_compressed(os.path.join(HERE, 'nms_options.npz'), **out)
+    print('wrote nms_options.npz', {k: v.shape for k, v in out.items() if k.endswith('_0')})
+
+
 def main():
     assert os.path.isdir(REF), 'the reference is only mounted in the build container'
     torch.set_num_threads(8)
@@ -374,6 +408,7 @@ def main():
     gen_train('n_64', 'n', 2, 2, 64, 3, 8)
     gen_train('s_128', 's', 8, 2, 128, 10, 30)
     gen_f3()
+    gen_nms_options()
 
 
 if __name__ == '__main__':

@@ -84,3 +84,17 @@ def test_header_reorder_rebuilds_plans():
     for a, b in zip(after, before):               # (bs, na, ny, nx, no): class columns permuted, box/objectness untouched
         assert torch.allclose(a[..., :5], b[..., :5], rtol=1e-5, atol=1e-6)
         assert torch.allclose(a[..., 5:], b[..., 5:][..., [2, 0, 1]], rtol=1e-5, atol=1e-6)
+
+
+def test_non_max_suppression_every_option_matches_reference():
+    """Class-aware entry point with all options against the reference's outputs (tests/golden/nms_options.npz)."""
+    from metayolo.models.utils_general import non_max_suppression
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'nms_options.npz'))
+    labels = [torch.from_numpy(g['labels_0']), torch.from_numpy(g['labels_1'])]
+    cases = {'default': {}, 'multi': {'multi_label': True}, 'agnostic': {'agnostic': True}, 'classes': {'classes': [0, 2]},
+             'multi_agnostic_top5': {'multi_label': True, 'agnostic': True, 'max_det': 5}, 'apriori': {'labels': labels}}
+    preds = torch.from_numpy(g['preds']).to(DEV)
+    for tag, kw in cases.items():
+        res = non_max_suppression(preds.clone(), conf_thres=0.2, iou_thres=0.5, **kw)
+        for b, d in enumerate(res):
+            np.testing.assert_array_equal(d.cpu().numpy(), g[f'{tag}_{b}'], err_msg=f'{tag} image {b}')

@@ -93,3 +93,17 @@ def test_numpy_and_c_agree_on_dense_tiles(m):
         assert np.all(s[:-1] >= s[1:])
         again = nms_ref.nms_numpy(ref[b]['boxes'], s, 0.45)
         assert again.tolist() == list(range(len(s)))
+
+
+def test_non_max_suppression_options_match_reference():
+    """The oracle's statement-by-statement non_max_suppression against the reference's own function run with every option
+    (tests/golden/nms_options.npz, make_golden.py:gen_nms_options; its greedy step there is this oracle's nms)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'nms_options.npz'))
+    labels = [g['labels_0'], g['labels_1']]
+    cases = {'default': {}, 'multi': {'multi_label': True}, 'agnostic': {'agnostic': True}, 'classes': {'classes': [0, 2]},
+             'multi_agnostic_top5': {'multi_label': True, 'agnostic': True, 'max_det': 5}, 'apriori': {'labels': labels}}
+    for tag, kw in cases.items():
+        res = nms_ref.non_max_suppression_numpy(g['preds'], conf_thres=0.2, iou_thres=0.5, **kw)
+        for b, d in enumerate(res):
+            np.testing.assert_array_equal(d, g[f'{tag}_{b}'], err_msg=f'{tag} image {b}')
