@@ -10,7 +10,8 @@ import torch  # noqa: F401  -- must come first: the library has to bind to the H
 #                              otherwise a second libamdhip64 gets mapped and sees no device
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'build', 'libhdyolo_hip.so')
+# HDY_LIB: load another build of the same ABI (kernel A/B experiments); it must still sit under csrc/build/
+LIB_PATH = os.path.join(_HERE, 'csrc', 'build', os.path.basename(os.environ.get('HDY_LIB', 'libhdyolo_hip.so')))
 
 F32, BF16 = 0, 1
 PACK_FWD, PACK_DGRAD, PACK_STEM = 0, 1, 2

@@ -102,45 +102,41 @@ __global__ __launch_bounds__(2 * BM) void conv_igemm_kernel(const ConvArgs p) {
     const unsigned char* zero = (const unsigned char*)g_hdy_zero16;
 
     // ------------------------------------------------------------------ loader (runs NS-1 k-blocks ahead)
+    // Address arithmetic is hoisted: per m-tile each staged row keeps a byte pointer to its tap-(0,0) pixel and that pixel's
+    // input coordinates; per k-block the thread derives ONE tap offset (its chunk's tap and channel), and a row costs two adds,
+    // two compares and a select.  (With the full 64-bit pixel address recomputed per row and k-block this issue phase took
+    // 42-52 % of the kernel's cycles on the 256->256 3x3 layer of yolov5l — more than twice the MFMA phase.)
     const int r0 = tid >> 3;
     const int lc = (tid & 7) ^ ((tid >> 4) & 7);       // logical chunk fetched into physical slot (tid & 7)
-    int rm[AR], rn[AR], ri[AR], rj[AR];                  // output pixel of each staged row (general path)
+    const unsigned char* rptr[AR];                       // &x[n][hi0][wi0][0] as bytes (never dereferenced when out of range)
+    unsigned hw0[AR];                                    // tap-(0,0) input coordinates, (hi0 + 4096) << 16 | (wi0 + 4096); rows >= M: 0xFFFF....
     int ld_tile = tile_begin, ld_kb = 0, ld_mtile = -1;
     int cc = 0, th = 0, tw = 0;
-    const T* wrow[BR];
+    const T* wrow0 = w;
+    const size_t wstep = (size_t)RSTEP * p.Kdp;          // distance between a thread's staged filter rows
     const int HoWo = p.Ho * p.Wo;
 
     auto loader_set_tile = [&](int t) {
         const int mt = t / ntiles, nt = t - mt * ntiles;
         if (mt != ld_mtile) {
-            if (ld_mtile < 0 || p.pointwise) {
 #pragma unroll
-                for (int i = 0; i < AR; ++i) {
-                    rm[i] = mt * BM + r0 + RSTEP * i;
-                    if (!p.pointwise) {
-                        const int mc = min(rm[i], p.M - 1);
-                        rn[i] = mc / HoWo;
-                        const int rem = mc - rn[i] * HoWo;
-                        ri[i] = rem / p.Wo;
-                        rj[i] = rem - ri[i] * p.Wo;
-                    }
-                }
-            } else {
-                const int dm = (mt - ld_mtile) * BM;
-#pragma unroll
-                for (int i = 0; i < AR; ++i) {
-                    rm[i] += dm;
-                    rj[i] += dm;
-                    while (rj[i] >= p.Wo) {
-                        rj[i] -= p.Wo;
-                        if (++ri[i] == p.Ho) { ri[i] = 0; ++rn[i]; }
-                    }
+            for (int i = 0; i < AR; ++i) {
+                const int m = mt * BM + r0 + RSTEP * i;
+                if (p.pointwise) {                       // input pixel == output pixel: no coordinates to recover
+                    rptr[i] = (const unsigned char*)(x + (long long)m * p.ldx);
+                    hw0[i] = m < p.M ? ((4096u << 16) | 4096u) : 0xFFFFFFFFu;
+                } else {
+                    const int mc = min(m, p.M - 1);
+                    const int n = mc / HoWo, rem = mc - n * HoWo;
+                    const int oi = rem / p.Wo, oj = rem - oi * p.Wo;
+                    const int h = oi * p.ih_mul + p.dh0, w_ = oj * p.iw_mul + p.dw0;
+                    rptr[i] = (const unsigned char*)(x + (((long long)n * p.Hin + h) * p.Win + w_) * p.ldx);
+                    hw0[i] = m < p.M ? (((unsigned)(h + 4096) << 16) | (unsigned)(w_ + 4096)) : 0xFFFFFFFFu;
                 }
             }
             ld_mtile = mt;
         }
-#pragma unroll
-        for (int i = 0; i < BR; ++i) wrow[i] = w + (size_t)(nt * BN + r0 + RSTEP * i) * p.Kdp + lc * VE;
+        wrow0 = w + (size_t)(nt * BN + r0) * p.Kdp + lc * VE;
         cc = lc * VE; th = 0; tw = 0;
         while (cc >= p.C) {
             cc -= p.C;
@@ -151,20 +147,16 @@ __global__ __launch_bounds__(2 * BM) void conv_igemm_kernel(const ConvArgs p) {
     auto loader_issue = [&](int buf) {
         unsigned char* sa = smem + buf * STAGE;
         unsigned char* sb = sa + ASZ;
+        const long long koff = (long long)(((th * p.Win + tw) * p.ldx + cc) * (int)sizeof(T));      // this chunk's tap and channel
+        const bool tap_ok = th < p.TH;                   // false only in the zero padding of the last k-block
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
-            const void* src = zero;
-            if (p.pointwise) {
-                if (rm[i] < p.M && th < 1) src = x + ((size_t)rm[i] * p.ldx + cc);
-            } else {
-                const int hi = ri[i] * p.ih_mul + p.dh0 + th, wi = rj[i] * p.iw_mul + p.dw0 + tw;
-                if (rm[i] < p.M && th < p.TH && (unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win)
-                    src = x + (((size_t)rn[i] * p.Hin + hi) * p.Win + wi) * p.ldx + cc;
-            }
-            glds16(src, sa + (wave * 64 + NTHR * i) * 16);
+            const int hi = (int)(hw0[i] >> 16) - 4096 + th, wi = (int)(hw0[i] & 0xFFFFu) - 4096 + tw;
+            const bool ok = tap_ok && (unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win;
+            glds16(ok ? (const void*)(rptr[i] + koff) : (const void*)zero, sa + (wave * 64 + NTHR * i) * 16);
         }
 #pragma unroll
-        for (int i = 0; i < BR; ++i) glds16(wrow[i] + (size_t)ld_kb * BKE, sb + (wave * 64 + NTHR * i) * 16);
+        for (int i = 0; i < BR; ++i) glds16(wrow0 + i * wstep + (size_t)ld_kb * BKE, sb + (wave * 64 + NTHR * i) * 16);
         // advance to the next k-block, possibly of the next tile
         if (++ld_kb == nkb) {
             ld_kb = 0;
@@ -430,6 +422,7 @@ int hdy_conv_igemm_launch(ConvArgs a, int dtype, int out_f32, hipStream_t st) {
     HDY_ARG(a.ldy >= a.K, "conv: ldy=%d < K=%d", a.ldy, a.K);
     HDY_ARG(((uintptr_t)a.x & 15) == 0 && ((uintptr_t)a.w & 15) == 0, "conv: x/w must be 16-byte aligned");
     HDY_ARG(a.TH > 0 && a.TW > 0, "conv: empty tap window");
+    HDY_ARG(a.Hin < 24000 && a.Win < 24000 && a.TH < 64 && a.TW < 64 && a.dh0 > -4000 && a.dw0 > -4000, "conv: image side beyond the loader's 16-bit coordinates");
     HDY_ARG((long long)a.N * a.Hin * a.Win < (1LL << 31) && (long long)a.N * a.Ho * a.Wo < (1LL << 31), "conv: too many pixels");
     a.Kd = a.TH * a.TW * a.C;
     const int BKE = 8 * VE;

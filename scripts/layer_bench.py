@@ -11,13 +11,20 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 640
 variant = sys.argv[3] if len(sys.argv) > 3 else 's'
 reps = 10
+EVAL = len(sys.argv) > 4 and sys.argv[4] == 'eval'     # time the eval launch list (BN folded, SiLU in the conv epilogue)
 m = Model(synth.make_cfg(variant, 8), synth.make_hyp())
 m.load_state_dict(synth.synth_state_dict(synth.shapes_of(m), seed=0), strict=False)
 m = m.to('cuda:0').train(); m.half()
 x = synth.synth_images(B, S, seed=0).to('cuda:0')
-t = synth.synth_targets(B, S, 8, seed=1)
-l, _ = m(x, t); l['det']['det_loss'].backward()
-plan = next(iter(m._eng().plans.values()))
+if EVAL:
+    m.eval()
+    with torch.no_grad():
+        plan = m._eng().plan_for(x, False, torch.bfloat16)
+        plan.run_forward(x)
+else:
+    t = synth.synth_targets(B, S, 8, seed=1)
+    l, _ = m(x, t); l['det']['det_loss'].backward()
+    plan = next(iter(m._eng().plans.values()))
 torch.cuda.synchronize()
 
 def describe(rec):
@@ -45,7 +52,7 @@ def describe(rec):
     return name[4:], 0.0, 0.0
 
 rows = []
-for phase, recs in (('F', plan.fwd), ('B', plan.bwd)):
+for phase, recs in (('F', plan.fwd), ('B', plan.bwd or [])):
     for rec in recs:
         for _ in range(2):
             ops.run([rec])
