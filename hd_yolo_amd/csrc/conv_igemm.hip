@@ -106,6 +106,9 @@ __global__ __launch_bounds__(2 * BM) void conv_igemm_kernel(const ConvArgs p) {
     // input coordinates; per k-block the thread derives ONE tap offset (its chunk's tap and channel), and a row costs two adds,
     // two compares and a select.  (With the full 64-bit pixel address recomputed per row and k-block this issue phase took
     // 42-52 % of the kernel's cycles on the 256->256 3x3 layer of yolov5l — more than twice the MFMA phase.)
+    // Measured and NOT adopted (same layer, same box): the two waves of a SIMD alternating as loader of a stage (1043 us vs 968 us);
+    // taps as the inner k-loop for L2 locality of the shifted re-reads (1107 us).  What bounds this kernel is the ~7 TB/s the
+    // CUs can fetch chip-wide: 85 FLOP per fetched byte at 256x128 tiles -> ~600 TFLOP/s, which is what it delivers.
     const int r0 = tid >> 3;
     const int lc = (tid & 7) ^ ((tid >> 4) & 7);       // logical chunk fetched into physical slot (tid & 7)
     const unsigned char* rptr[AR];                       // &x[n][hi0][wi0][0] as bytes (never dereferenced when out of range)
