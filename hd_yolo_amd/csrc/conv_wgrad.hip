@@ -16,6 +16,8 @@
 //
 // Replaces autograd's conv backward-weight for nn.Conv2d in metayolo/models/layers.py:31 and
 // yolo_head.py:112 (reached from train.py:472).
+#include <stdlib.h>
+
 #include "common.h"
 #include "hdyolo_internal.h"
 #include "hdyolo.h"
@@ -325,7 +327,8 @@ int hdy_wgrad_plan(int K, int Q, long long P, int dtype, int* splits, int* pix_p
     int sd, sx;
     wgrad_tile(K, Q, dtype, &sd, &sx);
     const int tiles = cdiv(K, TK * sd) * cdiv(Q, TK * sx);
-    int s = cdiv(1024, tiles);
+    static const int target = getenv("HDY_WGRAD_BLOCKS") ? atoi(getenv("HDY_WGRAD_BLOCKS")) : 512;     // = resident workgroups (2 per CU): one wave of blocks, half the slab traffic of 1024
+    int s = cdiv(target, tiles);
     if (s > 512) s = 512;
     const int maxs = cdiv(P, 256);
     if (s > maxs) s = maxs;
