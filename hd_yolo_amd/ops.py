@@ -63,12 +63,43 @@ def stream_ptr():
     return torch.cuda.current_stream().cuda_stream
 
 
+class SideStream:
+    """A second HIP stream for launch records that are off the critical path (weight gradients in the backward list): the
+    plan brackets them with ('@fork', side, records) — they start once everything issued so far on the main stream is done —
+    and ('@join', side, token) before a buffer they read is overwritten / at the end of the list."""
+
+    def __init__(self, device):
+        self.stream = torch.cuda.Stream(device=device)
+        self.done = {}                    # token -> event recorded on the side stream after that fork's records
+
+    def fork(self, records, token, main):
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self.stream.wait_event(ev)
+        run(records, stream=self.stream.cuda_stream)
+        done = torch.cuda.Event()
+        done.record(self.stream)
+        self.done[token] = done
+
+    def join(self, token, main):
+        done = self.done.pop(token, None)
+        if done is not None:
+            main.wait_event(done)
+
+
 def run(records, stream=None):
     """Execute launch records on `stream` (default: torch's current HIP stream)."""
     lib = _lib.load()
     s = stream_ptr() if stream is None else stream
     for rec in records:
         name, args = rec[0], rec[1]
+        if name[0] == '@':
+            side = rec[1]
+            if name == '@fork':
+                side.fork(rec[2], rec[3], torch.cuda.current_stream())
+            elif name == '@join':
+                side.join(rec[2], torch.cuda.current_stream())
+            continue
         rc = getattr(lib, name)(*args, s)
         if rc != 0:
             raise _lib.HdyError(f'{name} failed (status {rc}): {lib.hdy_last_error().decode()}')

@@ -26,6 +26,8 @@ import torch.nn as nn
 from . import _lib, ops
 
 USE_GRAPHS = os.environ.get('HDY_GRAPH', '0') == '1'   # hipGraph replay of ~400-node graphs measured slower than eager on ROCm 7.2
+SIDE_WGRAD = os.environ.get('HDY_SIDE_WGRAD', '1') == '1' and not USE_GRAPHS      # weight gradients on a second stream
+DY_RING = int(os.environ.get('HDY_DY_RING', '4'))
 
 
 class Val:
@@ -326,7 +328,10 @@ class Plan:
         self.loss_out = self._new(4, dtype=f32, zero=True)
         self.loss_call = None
         self.stats = self._new(max_stats, dtype=f32)
-        self.dy = self._new(max_dy)
+        # BN-backward output of the layer in flight; a small ring, so that the weight-gradient kernels of the previous layers
+        # (side stream) may still be reading theirs while the main stream moves on
+        self.dy_ring = [self._new(max_dy) for _ in range(DY_RING if SIDE_WGRAD else 1)]
+        self.dy = self.dy_ring[0]
         self.wg_ws = self._new(max_wg // 4 + 16, dtype=f32)
         self.bn_ws = self._new(max_bnws, dtype=f32)
         kmax = max(u.K for u in self.units if isinstance(u, ConvUnit))
@@ -480,12 +485,29 @@ class Plan:
         recs = []
         for v in self.vals:
             v.ginit = False
+        # Weight gradients are consumed only by the optimizer: with SIDE_WGRAD they run on a second stream beside the
+        # dgrad / BN-backward chain (which is what the next layer waits for), filling the CUs that the many small launches
+        # of the 20x20 and 40x40 layers leave idle.
+        side = ops.SideStream(self.device) if SIDE_WGRAD else None
+        nfork = [0]
+
+        def wgrad(rec, reads_dy_slot=None):
+            if side is None:
+                recs.append(rec)
+                return
+            recs.append(('@fork', side, [rec], nfork[0]))
+            if reads_dy_slot is not None:
+                slot_user[reads_dy_slot] = nfork[0]
+            nfork[0] += 1
+
+        slot_user = {}
+        nconv = 0
         for u in reversed(self.units):
             if isinstance(u, DetUnit):
                 x = u.x
                 gw, gb = self._grad_views(u.conv.weight), self._grad_views(u.conv.bias)
                 recs.append(ops.rec_colsum(u.gdet, self._det_bias_tmp(u), self.bn_ws))
-                recs.append(ops.rec_conv_wgrad(x.t(), u.gdet, gw, None, 1, 1, 1, 0, self.wg_ws))
+                wgrad(ops.rec_conv_wgrad(x.t(), u.gdet, gw, None, 1, 1, 1, 0, self.wg_ws))
                 self.packs.add(u.conv.weight, None, 1, 0, ops.PACK_DGRAD, u.wpd, K=u.Kp)
                 recs.append(ops.rec_conv_dgrad(u.gdet, u.wpd, x.g(), 1, 1, 1, 0, accumulate=self._contrib(x)))
                 u.gb = gb
@@ -497,7 +519,11 @@ class Plan:
                 recs.append(ops.rec_sppf_pool_bwd(gs[0], gs[1], gs[2], gs[3], u.idx, a.gfinal))
             elif isinstance(u, ConvUnit):
                 o0 = u.outs[0]
-                dy = self.dy[:o0.n * o0.h * o0.w * u.K].view(o0.n, o0.h, o0.w, u.K)
+                slot = nconv % len(self.dy_ring)
+                nconv += 1
+                if slot in slot_user:              # the weight gradient that last read this ring slot must be done
+                    recs.append(('@join', side, slot_user.pop(slot)))
+                dy = self.dy_ring[slot][:o0.n * o0.h * o0.w * u.K].view(o0.n, o0.h, o0.w, u.K)
                 k0 = 0
                 for m, o in zip(u.mods, u.outs):
                     K = m.conv.out_channels
@@ -509,7 +535,7 @@ class Plan:
                 stem_hw = (self.H, self.W) if u.stem else None
                 ga = self._grad_views(u.mods[0].conv.weight)
                 gb = self._grad_views(u.mods[1].conv.weight) if len(u.mods) > 1 else None
-                recs.append(ops.rec_conv_wgrad(x, dy, ga, gb, u.k, u.k, u.s, u.p, self.wg_ws, stem_hw=stem_hw))
+                wgrad(ops.rec_conv_wgrad(x, dy, ga, gb, u.k, u.k, u.s, u.p, self.wg_ws, stem_hw=stem_hw), reads_dy_slot=slot)
                 if not u.stem and u.x is not self.input:
                     wb = u.mods[1].conv.weight if len(u.mods) > 1 else None
                     self.packs.add(u.mods[0].conv.weight, wb, u.s, u.p, ops.PACK_DGRAD, u.wpd)
@@ -523,6 +549,8 @@ class Plan:
                     else:
                         acc = self._contrib(xv)
                     recs.append(ops.rec_conv_dgrad(dy, u.wpd, xv.g(), u.k, u.k, u.s, u.p, accumulate=acc))
+        if side is not None and nfork[0]:
+            recs.append(('@join', side, nfork[0] - 1))          # side-stream work is in order: the last fork covers all
         return recs
 
     def _det_bias_tmp(self, u):
