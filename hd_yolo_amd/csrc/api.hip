@@ -62,8 +62,12 @@ int hdy_conv_out_dim(int in, int k, int stride, int pad) { return (in + 2 * pad 
 int hdy_conv_mtiles(long long M) { return (int)((M + 127) / 128); }
 
 int hdy_conv_stat_slabs(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dtype) {
-    const int own = hdy_conv3x3_c64_slabs(N, H, W, C, K, R, S, stride, pad, dtype);
+    int own = hdy_conv3x3_c64_slabs(N, H, W, C, K, R, S, stride, pad, dtype);
     if (own > 0) return own;
+    if (C == 3 && R == 6 && S == 6 && stride == 2 && pad == 2) {
+        own = hdy_conv_stem_slabs(N, H, W, K, dtype);
+        if (own > 0) return own;
+    }
     return hdy_conv_mtiles((long long)N * hdy_conv_out_dim(H, R, stride, pad) * hdy_conv_out_dim(W, S, stride, pad));
 }
 

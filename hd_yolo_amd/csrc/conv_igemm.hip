@@ -248,7 +248,7 @@ __global__ __launch_bounds__(2 * BM) void conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
                             for (int b = 0; b < NT; ++b) {
                                 float v = acc[a][b][r] * sc[b] + sh[b];
-                                if (p.act == 1) v = silu_f(v);
+                                if (p.act == 1) v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));     // SiLU; 1 ulp, then rounded to bf16
                                 const int col = wn * (BN / 2) + b * 16 + fr;
                                 const int chunk = (col >> 3) ^ ((((row >> 2) & 3) << 1) & (CPR - 1));
                                 *(bf16_t*)(scratch + row * ROWB + chunk * 16 + (col & 7) * 2) = (bf16_t)v;
@@ -443,6 +443,7 @@ int hdy_conv_igemm_launch(ConvArgs a, int dtype, int out_f32, hipStream_t st) {
     a.vec_out = (bf16_out && a.K % 8 == 0 && a.ldy % 8 == 0 && ((uintptr_t)a.y & 15) == 0 &&
                  (!a.res || (a.ldr % 8 == 0 && ((uintptr_t)a.res & 15) == 0))) ? 1 : 0;
     int rc = 0;
+    if (hdy_conv_stem_try(a, dtype, out_f32, st, &rc)) return rc;         // patch-resident 6x6/s2 stem
     if (hdy_conv3x3_c64_try(a, dtype, out_f32, st, &rc)) return rc;      // filter-resident 3x3 kernel when the shape qualifies
     if (dtype == HDY_BF16) return out_f32 ? launch_bn<bf16_t, float>(a, st) : launch_bn<bf16_t, bf16_t>(a, st);
     return launch_bn<float, float>(a, st);

@@ -39,6 +39,8 @@ struct WgradArgs {
 int hdy_conv_bn_tile(int K);
 int hdy_conv3x3_c64_try(const ConvArgs& a, int dtype, int out_f32, hipStream_t st, int* rc);
 int hdy_conv3x3_c64_slabs(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dtype);
+int hdy_conv_stem_try(const ConvArgs& a, int dtype, int out_f32, hipStream_t st, int* rc);
+int hdy_conv_stem_slabs(int N, int H, int W, int K, int dtype);
 int hdy_conv_igemm_launch(ConvArgs a, int dtype, int out_f32, hipStream_t st);
 int hdy_wgrad_launch(WgradArgs a, int dtype, hipStream_t st);
 int hdy_wgrad_plan(int K, int Q, long long P, int dtype, int* splits, int* pix_per_split);

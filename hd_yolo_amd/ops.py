@@ -69,7 +69,7 @@ class SideStream:
     and ('@join', side, token) before a buffer they read is overwritten / at the end of the list."""
 
     def __init__(self, device):
-        self.stream = torch.cuda.Stream(device=device)
+        self.stream = torch.cuda.Stream(device=device)      # a low/high priority made no difference (18.0-18.3 ms either way)
         self.done = {}                    # token -> event recorded on the side stream after that fork's records
 
     def fork(self, records, token, main):

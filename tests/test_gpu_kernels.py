@@ -137,6 +137,34 @@ def test_stacked_pack_matches_cat(dtype):
     assert torch.equal(p1.float(), p2.float())
 
 
+@pytest.mark.parametrize('K', [16, 32, 48, 64])
+def test_stem_patch_kernel_bf16(K):
+    """Shapes the patch-resident stem kernel takes (bf16, Ho % 16 == 0, Wo % 32 == 0): raw output + statistic slabs (train mode),
+    scale/shift + SiLU (eval mode), against torch and against the generic kernel's path for an ineligible width."""
+    dtype = torch.bfloat16
+    N, H, W = 3, 64, 192                      # 3 x 2 x 3 = 18 tiles of 16 x 32 outputs
+    img = q(rnd((N, 3, H, W), 1).abs(), dtype)
+    w = rnd((K, 3, 6, 6), 2, 0.2)
+    wq = q(w, dtype)
+    prep = torch.empty((N, H + 4, W + 4, 4), dtype=dtype, device=DEV)
+    wp = ops.pack_alloc(K, 3, 6, 6, 2, 2, ops.PACK_STEM, dtype, DEV)
+    Ho, Wo = H // 2, W // 2
+    y = torch.empty((N, Ho, Wo, K), dtype=dtype, device=DEV)
+    slabs = ops.stat_slabs(N, H, W, 3, K, 6, 6, 2, 2, dtype)
+    assert slabs == 18                        # one per workgroup, not one per 128 pixels (72)
+    stats = torch.full((slabs, 2, K), float('nan'), dtype=torch.float32, device=DEV)
+    ops.run([ops.rec_stem_prep(img.to(DEV), prep), ops.rec_pack(w.to(DEV), None, 2, 2, ops.PACK_STEM, wp),
+             ops.rec_conv_fwd(prep, wp, y, K, 6, 6, 2, 2, stats=stats, stem_hw=(H, W))])
+    ref = F.conv2d(img, wq, None, 2, 2)
+    assert_close(from_dev_nhwc(y), ref, TOL[dtype], 'stem fwd')
+    s = stats.sum(0).cpu()
+    assert_close(s[0], ref.sum((0, 2, 3)), 1e-3, 'stats sum')
+    assert_close(s[1], (ref * ref).sum((0, 2, 3)), 1e-3, 'stats sumsq')
+    scale, shift = rnd((K,), 5).abs() + 0.5, rnd((K,), 6)
+    ops.run([ops.rec_conv_fwd(prep, wp, y, K, 6, 6, 2, 2, scale=scale.to(DEV), shift=shift.to(DEV), act=ops.ACT_SILU, stem_hw=(H, W))])
+    assert_close(from_dev_nhwc(y), F.silu(ref * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)), TOL[dtype], 'stem fwd + bn + silu')
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 def test_stem_conv(dtype):
     N, H, W, K = 2, 32, 48, 16
