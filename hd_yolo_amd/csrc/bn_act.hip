@@ -12,6 +12,11 @@
 //                     ->  bn_bwd_finalize: dgamma, dbeta, c1 = dbeta/M, c2 = dgamma/M
 //                     ->  bn_act_bwd_apply: dy = scale*(du - c1 - xhat*c2)        (recomputes du, xhat from dz, y)
 //
+// Measured and NOT adopted (round 1): a single cooperative launch for the backward of the <= 27 M-element layers that keeps the
+// (dz, y) vectors in registers + LDS between the reduce and the apply phase (2 reads + 1 write of HBM instead of 4 + 1).  It was
+// correct but slower: 73 us minimum per launch (two cooperative-groups grid syncs over 256 workgroups) against 30-63 us for the
+// three launches, and a grid that must own every CU serialises against the weight-gradient stream (step 17.6 -> 20.9 ms).
+//
 // Reference semantics replaced: nn.BatchNorm2d (eps 1e-3, momentum 0.03: metayolo/models/utils_torch.py:47-49)
 // and nn.SiLU inside Conv.forward (metayolo/models/layers.py:37-38), the Bottleneck residual add (:97),
 // and their autograd backward.
