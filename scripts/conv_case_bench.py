@@ -1,3 +1,5 @@
+"""Time one conv forward (bf16, scale/shift + SiLU epilogue) through the C ABI: python scripts/conv_case_bench.py N H W C K R.
+With HDY_LIB=<other .so under csrc/build/> the same case runs on another build of the library (kernel A/B on one box)."""
 import os, sys, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -19,13 +21,3 @@ for _ in range(10): ops.run(rec)
 e1.record(); torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 100
 print(f'{us:.1f} us  {2.0*N*H*W*K*C*R*R/us/1e6:.1f} TF')
-lib = _lib.load()
-if not hasattr(lib, 'hdy_debug_read2'):
-    sys.exit(0)
-buf = (ctypes.c_longlong * 16)()
-lib.hdy_debug_read2(buf)
-names = ['vmwait', 'barrier', 'issue', 'mfma', 'epilogue', 'loop']
-for wv in range(2):
-    v = [buf[i + 8 * wv] for i in range(6)]
-    tot = sum(v)
-    print('wave', wv * 7, ' '.join(f'{n}={x}({100*x/max(tot,1):.0f}%)' for n, x in zip(names, v)), 'total', tot)
