@@ -109,6 +109,9 @@ __global__ __launch_bounds__(2 * BM) void conv_igemm_kernel(const ConvArgs p) {
     // Measured and NOT adopted (same layer, same box): the two waves of a SIMD alternating as loader of a stage (1043 us vs 968 us);
     // taps as the inner k-loop for L2 locality of the shifted re-reads (1107 us).  What bounds this kernel is the ~7 TB/s the
     // CUs can fetch chip-wide: 85 FLOP per fetched byte at 256x128 tiles -> ~600 TFLOP/s, which is what it delivers.
+    // Also measured and not adopted for the single-tap layers: skipping the filter block once every ring slot holds it (+2 %), and a
+    // resident filter with a 7-deep activation-only ring in ONE 4-wave workgroup per CU (64->64 @160x160: 165 us vs 97 us): those
+    // layers are bound by the per-tile epilogue (~3k cycles per wave), which only co-resident workgroups overlap today.
     const int r0 = tid >> 3;
     const int lc = (tid & 7) ^ ((tid >> 4) & 7);       // logical chunk fetched into physical slot (tid & 7)
     const unsigned char* rptr[AR];                       // &x[n][hi0][wi0][0] as bytes (never dereferenced when out of range)
