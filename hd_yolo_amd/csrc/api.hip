@@ -64,11 +64,13 @@ int hdy_conv_mtiles(long long M) { return (int)((M + 127) / 128); }
 int hdy_conv_stat_slabs(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dtype) {
     int own = hdy_conv3x3_c64_slabs(N, H, W, C, K, R, S, stride, pad, dtype);
     if (own > 0) return own;
-    if (C == 3 && R == 6 && S == 6 && stride == 2 && pad == 2) {
+    const bool stem = C == 3 && R == 6 && S == 6 && stride == 2 && pad == 2;
+    if (stem) {
         own = hdy_conv_stem_slabs(N, H, W, K, dtype);
         if (own > 0) return own;
     }
-    return hdy_conv_mtiles((long long)N * hdy_conv_out_dim(H, R, stride, pad) * hdy_conv_out_dim(W, S, stride, pad));
+    const long long M = (long long)N * hdy_conv_out_dim(H, R, stride, pad) * hdy_conv_out_dim(W, S, stride, pad);
+    return hdy_conv_igemm_slabs(M, K, stem ? 6 : R * S);
 }
 
 size_t hdy_conv_pack_elems(int K, int C, int R, int S, int stride, int pad, int kind, int dtype) {

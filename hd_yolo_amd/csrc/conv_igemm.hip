@@ -69,7 +69,8 @@ __device__ __forceinline__ void glds16(const void* g, unsigned char* lds_wave_ba
 //   <256, *, 3>  8 waves (2 per SIMD), 3 stages with counted vmcnt: half the filter re-fetch per output, two k-blocks of
 //                DMA in flight across the barrier, one workgroup per CU (the K >= 128 layers, which were L2-fetch bound)
 template <typename T, typename OT, int BM, int BN, int NS>
-__global__ __launch_bounds__(2 * BM) void conv_igemm_kernel(const ConvArgs p) {
+// second bound = waves per SIMD the LDS footprint allows (2 / 3 / 4 co-resident 4-wave workgroups, 1 x 8 waves): caps the VGPRs there
+__global__ __launch_bounds__(2 * BM, (BM == 256 || BN == 128) ? 2 : (BN == 64 ? 3 : 4)) void conv_igemm_kernel(const ConvArgs p) {
     constexpr int NTHR = 2 * BM;
     constexpr int VE = Traits<T>::VE;
     constexpr int BKE = 8 * VE;          // elements per 128-byte k-block
@@ -185,85 +186,153 @@ __global__ __launch_bounds__(2 * BM) void conv_igemm_kernel(const ConvArgs p) {
     };
 
     // ------------------------------------------------------------------ epilogue of one finished tile
+    // The MFMAs run with the FILTER fragment as row operand, so lane (fr, fq) holds, for each (a, b), 4 consecutive output channels
+    // (column wn*BN/2 + b*16 + fq*4 + r) of ONE output row (wm*64 + a*16 + fr): 8 packed bytes per (a, b) into the staging tile
+    // instead of four 2-byte scatters, and per-channel sums that add up lane-locally.
+    // BatchNorm sums: with a single column tile (K <= 128, every large layer) they stay in registers for all of the workgroup's
+    // tiles and are written as ONE slab per workgroup at the end; otherwise each tile reduces its 16 pixel lanes and writes the
+    // slab rows of its 128-row groups.  (Per tile the single-tap layers spent more cycles here than in their MFMAs.)
+    const bool wg_stats = p.stats != nullptr && ntiles == 1;
+    // epilogue scale / shift of the current column tile: [2][BN] floats behind the ring — except for the 32-wide tile (always a single
+    // column tile, and 4 workgroups fill the LDS exactly), whose 4 + 4 values per lane are loaded once into registers
+    constexpr bool COEF_LDS = BN > 32;
+    float* const coef = (float*)(smem + NS * STAGE);
+    int coef_ntile = -1;
+    f32x4 sc_reg = {1.f, 1.f, 1.f, 1.f}, sh_reg = {0.f, 0.f, 0.f, 0.f};
+    if (!COEF_LDS) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int kc = wn * (BN / 2) + fq * 4 + r;
+            if (p.scale && kc < p.K) sc_reg[r] = p.scale[kc];
+            if (p.shift && kc < p.K) sh_reg[r] = p.shift[kc];
+        }
+    }
+    float s1[NT][4], s2[NT][4];
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s1[b][r] = s2[b][r] = 0.f;
+
+    // lane-local sums -> [BM/64 wave rows][BN][2] in `red` (16 pixel lanes by shuffles)
+    auto stats_to_lds = [&](float* red, float (&u1)[NT][4], float (&u2)[NT][4]) {
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float u = u1[b][r], q = u2[b][r];
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) {
+                    u += __shfl_xor(u, m);
+                    q += __shfl_xor(q, m);
+                }
+                if (fr == 0) {
+                    const int col = wn * (BN / 2) + b * 16 + fq * 4 + r;
+                    red[(wm * BN + col) * 2 + 0] = u;
+                    red[(wm * BN + col) * 2 + 1] = q;
+                }
+            }
+    };
+
     // returns true when the coalesced path issued its fixed number of row stores per wave (full tile)
     auto epilogue = [&](int t, unsigned char* scratch) -> bool {
         const int mtile = t / ntiles, ntile = t - mtile * ntiles;
         const int m0 = mtile * BM, n0 = ntile * BN;
         if (p.stats) {
-            float* red = (float*)scratch;       // [BM/64][BN][2]
+            if (wg_stats) {
 #pragma unroll
-            for (int b = 0; b < NT; ++b) {
-                float s = 0.f, ss = 0.f;
-#pragma unroll
-                for (int a = 0; a < MT; ++a)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float v = acc[a][b][r];
-                        s += v;
-                        ss += v * v;
-                    }
-                s += __shfl_xor(s, 16);
-                ss += __shfl_xor(ss, 16);
-                s += __shfl_xor(s, 32);
-                ss += __shfl_xor(ss, 32);
-                if (lane < 16) {
-                    const int col = wn * (BN / 2) + b * 16 + lane;
-                    red[(wm * BN + col) * 2 + 0] = s;
-                    red[(wm * BN + col) * 2 + 1] = ss;
-                }
-            }
-            __syncthreads();
-            // one slab per 128 output rows (what the caller sized): pairs of wave rows
-            for (int j = tid; j < (BM / 128) * BN; j += NTHR) {
-                const int half = j / BN, c = j - half * BN;
-                const size_t slab = (size_t)mtile * (BM / 128) + half;
-                if (n0 + c < p.K && (long long)slab * 128 < p.M) {
-                    p.stats[(slab * 2 + 0) * p.K + n0 + c] = red[((2 * half) * BN + c) * 2] + red[((2 * half + 1) * BN + c) * 2];
-                    p.stats[(slab * 2 + 1) * p.K + n0 + c] = red[((2 * half) * BN + c) * 2 + 1] + red[((2 * half + 1) * BN + c) * 2 + 1];
-                }
-            }
-            __syncthreads();
-        }
-        float sc[NT], sh[NT];
-        int kcol[NT];
-#pragma unroll
-        for (int b = 0; b < NT; ++b) {
-            kcol[b] = n0 + wn * (BN / 2) + b * 16 + fr;
-            const bool okk = kcol[b] < p.K;
-            sc[b] = (p.scale && okk) ? p.scale[kcol[b]] : 1.0f;
-            sh[b] = (p.shift && okk) ? p.shift[kcol[b]] : 0.0f;
-        }
-        OT* __restrict__ y = (OT*)p.y;
-        if (VEC_OUT && p.vec_out) {
-            // stage 128 rows of the bf16 tile at a time in LDS (32-byte column blocks XORed with (row>>2)&3 so the four 4-row
-            // groups of a store instruction land on different banks), then write full rows with 16-byte stores
-            constexpr int ROWB = BN * 2;                  // bytes per staged row
-            constexpr int CPR = ROWB / 16;                // 16-byte chunks per row
-            constexpr int RPI = NTHR / CPR;               // rows per pass
-#pragma unroll
-            for (int half = 0; half < BM / 128; ++half) {
-                if ((wm >> 1) == half) {
+                for (int b = 0; b < NT; ++b)
 #pragma unroll
                     for (int a = 0; a < MT; ++a)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const int row = (wm & 1) * 64 + a * 16 + fq * 4 + r;
-#pragma unroll
-                            for (int b = 0; b < NT; ++b) {
-                                float v = acc[a][b][r] * sc[b] + sh[b];
-                                if (p.act == 1) v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));     // SiLU; 1 ulp, then rounded to bf16
-                                const int col = wn * (BN / 2) + b * 16 + fr;
-                                const int chunk = (col >> 3) ^ ((((row >> 2) & 3) << 1) & (CPR - 1));
-                                *(bf16_t*)(scratch + row * ROWB + chunk * 16 + (col & 7) * 2) = (bf16_t)v;
-                            }
+                            const float v = acc[a][b][r];
+                            s1[b][r] += v;
+                            s2[b][r] = __builtin_fmaf(v, v, s2[b][r]);
                         }
+            } else {
+                float t1[NT][4], t2[NT][4];
+#pragma unroll
+                for (int b = 0; b < NT; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float u = 0.f, q = 0.f;
+#pragma unroll
+                        for (int a = 0; a < MT; ++a) {
+                            const float v = acc[a][b][r];
+                            u += v;
+                            q = __builtin_fmaf(v, v, q);
+                        }
+                        t1[b][r] = u;
+                        t2[b][r] = q;
+                    }
+                float* red = (float*)scratch;       // [BM/64][BN][2]
+                stats_to_lds(red, t1, t2);
+                __syncthreads();
+                // one slab per 128 output rows (what the caller sized): pairs of wave rows
+                for (int j = tid; j < (BM / 128) * BN; j += NTHR) {
+                    const int half = j / BN, c = j - half * BN;
+                    const size_t slab = (size_t)mtile * (BM / 128) + half;
+                    if (n0 + c < p.K && (long long)slab * 128 < p.M) {
+                        p.stats[(slab * 2 + 0) * p.K + n0 + c] = red[((2 * half) * BN + c) * 2] + red[((2 * half + 1) * BN + c) * 2];
+                        p.stats[(slab * 2 + 1) * p.K + n0 + c] = red[((2 * half) * BN + c) * 2 + 1] + red[((2 * half + 1) * BN + c) * 2 + 1];
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        const bool affine = p.scale != nullptr || p.shift != nullptr;
+        if (COEF_LDS && affine && ntile != coef_ntile) {       // per-channel epilogue coefficients of this column tile -> LDS (once per workgroup
+            __syncthreads();                       // when the layer has a single column tile)
+            for (int j = tid; j < BN; j += NTHR) {
+                coef[j] = (p.scale && n0 + j < p.K) ? p.scale[n0 + j] : 1.0f;
+                coef[BN + j] = (p.shift && n0 + j < p.K) ? p.shift[n0 + j] : 0.0f;
+            }
+            __syncthreads();
+            coef_ntile = ntile;
+        }
+        OT* __restrict__ y = (OT*)p.y;
+        if (VEC_OUT && p.vec_out) {
+            // stage RPP rows of the bf16 tile at a time in the A part of the finished stage; 8-byte slots XORed with (row & 14) keep
+            // the 16 pixel lanes of a write on different slots; then full rows leave with 16-byte stores
+            constexpr int ROWB = BN * 2;                  // bytes per staged row
+            constexpr int CPR = ROWB / 16;                // 16-byte chunks per row
+            constexpr int RPI = NTHR / CPR;               // rows per store instruction of the workgroup
+            constexpr int RPP = ASZ / ROWB >= 128 ? 128 : ASZ / ROWB;      // rows per pass
+            static_assert(RPP % 64 == 0 && BM % RPP == 0, "epilogue passes must be whole wave row groups");
+            constexpr int SWM = (2 * CPR - 1) & 14;       // slot swizzle mask (even bits only: 16-byte pairs stay together)
+#pragma unroll
+            for (int pass = 0; pass < BM / RPP; ++pass) {
+                if ((wm * 64) / RPP == pass) {
+#pragma unroll
+                    for (int b = 0; b < NT; ++b) {
+                        const int col = wn * (BN / 2) + b * 16 + fq * 4;
+                        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+                        if (affine) {
+                            sc = COEF_LDS ? *(const f32x4*)(coef + col) : sc_reg;
+                            sh = COEF_LDS ? *(const f32x4*)(coef + BN + col) : sh_reg;
+                        }
+                        const int slot = wn * (BN / 8) + b * 4 + fq;
+#pragma unroll
+                        for (int a = 0; a < MT; ++a) {
+                            const int row = (wm * 64) % RPP + a * 16 + fr;
+                            float v[4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                v[r] = acc[a][b][r];
+                                if (affine) v[r] = v[r] * sc[r] + sh[r];
+                                if (p.act == 1) v[r] = v[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[r]));   // SiLU; 1 ulp, then bf16
+                            }
+                            bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                            *(bf16x4*)(scratch + row * ROWB + ((slot ^ (row & SWM)) << 3)) = o;
+                        }
+                    }
                 }
                 __syncthreads();
                 const int ch = tid % CPR, rr = tid / CPR;
                 const int kc = n0 + ch * 8;
                 if (kc < p.K) {
-                    for (int row = rr; row < 128; row += RPI) {
-                        const int m = m0 + half * 128 + row;
+                    for (int row = rr; row < RPP; row += RPI) {
+                        const int m = m0 + pass * RPP + row;
                         if (m >= p.M) break;
                         size_t opix;
                         if (p.dense_out) {
@@ -273,7 +342,7 @@ __global__ __launch_bounds__(2 * BM) void conv_igemm_kernel(const ConvArgs p) {
                             const int oi = rem / p.Wo, oj = rem - oi * p.Wo;
                             opix = ((size_t)n * p.Hout + (p.oh_off + oi * p.oh_mul)) * p.Wout + (p.ow_off + oj * p.ow_mul);
                         }
-                        const int chunk = ch ^ ((((row >> 2) & 3) << 1) & (CPR - 1));
+                        const int chunk = ch ^ ((row & SWM) >> 1);
                         V16 v;
                         v.i = *(const i32x4*)(scratch + row * ROWB + chunk * 16);
                         if (p.res || p.accumulate) {
@@ -302,32 +371,34 @@ __global__ __launch_bounds__(2 * BM) void conv_igemm_kernel(const ConvArgs p) {
             }
             return (mtile + 1) * BM <= p.M;
         }
+        // direct path (fp32 outputs, ragged K, unaligned rows): each lane writes its 4 consecutive channels of each of its rows
 #pragma unroll
         for (int a = 0; a < MT; ++a) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm * 64 + a * 16 + fq * 4 + r;
-                if (m >= p.M) continue;
-                size_t opix;
-                if (p.dense_out) {
-                    opix = (size_t)m;
-                } else {
-                    const int n = m / HoWo, rem = m - n * HoWo;
-                    const int oi = rem / p.Wo, oj = rem - oi * p.Wo;
-                    opix = ((size_t)n * p.Hout + (p.oh_off + oi * p.oh_mul)) * p.Wout + (p.ow_off + oj * p.ow_mul);
-                }
-                OT* yrow = y + opix * p.ldy;
-                const OT* rrow = p.res ? (const OT*)p.res + opix * p.ldr : nullptr;
-#pragma unroll
-                for (int b = 0; b < NT; ++b) {
-                    if (kcol[b] >= p.K) continue;
-                    float v = acc[a][b][r] * sc[b] + sh[b];
-                    if (p.act == 1) v = silu_f(v);
-                    if (rrow) v += to_f32<OT>(rrow[kcol[b]]);
-                    if (p.accumulate) v += to_f32<OT>(yrow[kcol[b]]);
-                    yrow[kcol[b]] = from_f32<OT>(v);
-                }
+            const int m = m0 + wm * 64 + a * 16 + fr;
+            if (m >= p.M) continue;
+            size_t opix;
+            if (p.dense_out) {
+                opix = (size_t)m;
+            } else {
+                const int n = m / HoWo, rem = m - n * HoWo;
+                const int oi = rem / p.Wo, oj = rem - oi * p.Wo;
+                opix = ((size_t)n * p.Hout + (p.oh_off + oi * p.oh_mul)) * p.Wout + (p.ow_off + oj * p.ow_mul);
             }
+            OT* yrow = y + opix * p.ldy;
+            const OT* rrow = p.res ? (const OT*)p.res + opix * p.ldr : nullptr;
+#pragma unroll
+            for (int b = 0; b < NT; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kc = n0 + wn * (BN / 2) + b * 16 + fq * 4 + r;
+                    if (kc >= p.K) continue;
+                    float v = acc[a][b][r];
+                    if (affine) v = COEF_LDS ? v * coef[kc - n0] + coef[BN + kc - n0] : v * sc_reg[r] + sh_reg[r];
+                    if (p.act == 1) v = silu_f(v);
+                    if (rrow) v += to_f32<OT>(rrow[kc]);
+                    if (p.accumulate) v += to_f32<OT>(yrow[kc]);
+                    yrow[kc] = from_f32<OT>(v);
+                }
         }
         return false;
     };
@@ -371,7 +442,7 @@ __global__ __launch_bounds__(2 * BM) void conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
             for (int a = 0; a < MT; ++a)
 #pragma unroll
-                for (int b = 0; b < NT; ++b) acc[a][b] = mma16<T>(af[a], bf[b], acc[a][b]);
+                for (int b = 0; b < NT; ++b) acc[a][b] = mma16<T>(bf[b], af[a], acc[a][b]);
         }
         if (++c_kb == nkb) {
             __syncthreads();                       // every wave is done reading stage `it`: its slot is scratch until the next barrier
@@ -381,21 +452,50 @@ __global__ __launch_bounds__(2 * BM) void conv_igemm_kernel(const ConvArgs p) {
             ++c_tile;
         }
     }
+    if (wg_stats) {
+        // one slab per workgroup (index = its position in the XCD-aware order): 16 pixel lanes -> wave rows -> global
+        float* red = (float*)smem;                 // every stage has been consumed
+        __syncthreads();
+        stats_to_lds(red, s1, s2);
+        __syncthreads();
+        const size_t slab = (size_t)(tile_begin / tpb);
+        for (int j = tid; j < 2 * BN; j += NTHR) {
+            const int which = j / BN, c = j - which * BN;
+            if (c < p.K) {
+                float v = 0.f;
+#pragma unroll
+                for (int g = 0; g < BM / 64; ++g) v += red[(g * BN + c) * 2 + which];
+                p.stats[(slab * 2 + which) * p.K + c] = v;
+            }
+        }
+    }
+}
+
+// Persistent grid of a tile configuration: as many workgroups as stay resident (LDS-limited), never more than tiles.
+inline int igemm_grid(long long M, int ntiles, int BM, int BN, int NS) {
+    const size_t smem = (size_t)NS * (BM * 128 + BN * 128) + (BN > 32 ? 2 * BN * sizeof(float) : 0);
+    const int per_cu = (int)(160 * 1024 / smem) > 4 ? 4 : (int)(160 * 1024 / smem);
+    long long grid = 256 * (per_cu < 1 ? 1 : per_cu);
+    const long long tiles = (M + BM - 1) / BM * ntiles;
+    return (int)(grid > tiles ? tiles : grid);
+}
+
+// 256-row tiles pay where the filter is re-fetched many times per output (multi-tap, wide K) and there is enough work to
+// give every CU one of them; the single-tap layers prefer many small workgroups in flight (measured)
+inline bool igemm_big(long long M, int bn, int ntiles, int taps) {
+    static const bool no_big = getenv("HDY_NO_BIG_TILES") != nullptr;
+    return bn == 128 && taps > 1 && (M + 255) / 256 * ntiles >= 256 && !no_big;
 }
 
 template <typename T, typename OT, int BM, int BN, int NS>
 int launch(const ConvArgs& a, hipStream_t st) {
-    const size_t smem = (size_t)NS * (BM * 128 + BN * 128);
+    const size_t smem = (size_t)NS * (BM * 128 + BN * 128) + (BN > 32 ? 2 * BN * sizeof(float) : 0);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, OT, BM, BN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
     }
-    // persistent grid: as many workgroups as stay resident (LDS-limited), never more than tiles
-    const int per_cu = (int)(160 * 1024 / smem) > 4 ? 4 : (int)(160 * 1024 / smem);
-    int grid = 256 * (per_cu < 1 ? 1 : per_cu);
-    const int tiles = cdiv(a.M, BM) * a.ntiles;
-    if (grid > tiles) grid = tiles;
+    const int grid = igemm_grid(a.M, a.ntiles, BM, BN, NS);
     hipLaunchKernelGGL((conv_igemm_kernel<T, OT, BM, BN, NS>), dim3(grid), dim3(2 * BM), smem, st, a);
     HDY_LAUNCH_CHECK("conv_igemm");
     return HDY_OK;
@@ -403,10 +503,7 @@ int launch(const ConvArgs& a, hipStream_t st) {
 
 template <typename T, typename OT>
 int launch_bn(const ConvArgs& a, hipStream_t st) {
-    // 256-row tiles pay where the filter is re-fetched many times per output (multi-tap, wide K) and there is enough work to
-    // give every CU one of them; the single-tap layers are HBM-bound and prefer many small workgroups in flight (measured)
-    static const bool no_big = getenv("HDY_NO_BIG_TILES") != nullptr;
-    const bool big = a.bn == 128 && a.TH * a.TW > 1 && (long long)cdiv(a.M, 256) * a.ntiles >= 256 && !no_big;
+    const bool big = igemm_big(a.M, a.bn, a.ntiles, a.TH * a.TW);
     switch (a.bn) {
         case 32: return launch<T, OT, 128, 32, 2>(a, st);
         case 64: return launch<T, OT, 128, 64, 2>(a, st);
@@ -417,6 +514,19 @@ int launch_bn(const ConvArgs& a, hipStream_t st) {
 }  // namespace
 
 int hdy_conv_bn_tile(int K) { return K <= 32 ? 32 : (K <= 64 ? 64 : 128); }
+
+// Statistic slabs the generic kernel writes for M output pixels, K channels, `taps` filter taps: one per workgroup when the layer
+// has a single column tile (sums stay in registers across the workgroup's tiles), else one per 128 output rows.
+int hdy_conv_igemm_slabs(long long M, int K, int taps) {
+    const int bn = hdy_conv_bn_tile(K), ntiles = cdiv(K, bn);
+    if (ntiles > 1) return (int)((M + 127) / 128);
+    const bool big = igemm_big(M, bn, ntiles, taps);
+    const int BM = big ? 256 : 128;
+    const int grid = igemm_grid(M, ntiles, BM, bn, big ? 3 : 2);
+    const long long tiles = (M + BM - 1) / BM;
+    const long long tpb = (tiles + grid - 1) / grid;
+    return (int)((tiles + tpb - 1) / tpb);
+}
 
 // Host-side validation + dispatch shared by the C-ABI entry points (api.hip).
 int hdy_conv_igemm_launch(ConvArgs a, int dtype, int out_f32, hipStream_t st) {

@@ -37,6 +37,7 @@ struct WgradArgs {
 };
 
 int hdy_conv_bn_tile(int K);
+int hdy_conv_igemm_slabs(long long M, int K, int taps);
 int hdy_conv3x3_c64_try(const ConvArgs& a, int dtype, int out_f32, hipStream_t st, int* rc);
 int hdy_conv3x3_c64_slabs(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dtype);
 int hdy_conv_stem_try(const ConvArgs& a, int dtype, int out_f32, hipStream_t st, int* rc);
