@@ -188,24 +188,25 @@ class Detect(nn.Module):
         else:
             flat = preds
         conf = self.nms_params['conf_thres']
-        kept = nms_per_image(flat, nc=self.nc, conf_thres=conf, iou_thres=self.nms_params['iou_thres'],
-                             max_det=int(self.nms_params['max_det']))
-        results = []
-        for r in kept:
-            scores = self.hierarchical_scores(r['scores'].clone())
-            out = {'boxes': r['boxes']}
-            if self.multi_label:
-                out['scores'], out['labels'] = scores, scores > conf
-            else:
-                obj = scores[..., 0]
-                if scores.shape[0]:
-                    cls_scores, cls_labels = scores[..., 1:].max(1)
-                else:
-                    cls_scores, cls_labels = obj, torch.zeros_like(obj, dtype=torch.long)
-                out['scores'] = torch.where(cls_scores > conf, cls_scores, obj)
-                out['labels'] = torch.where(cls_scores > conf, cls_labels + 1, torch.full_like(cls_labels, -100))
-            results.append(out)
-        return results
+        max_det = int(self.nms_params['max_det'])
+        # one NMS launch for the batch, then the score / label logic ONCE on the padded (bs * max_det, 1 + nc) rows (rows past an
+        # image's count are scratch and sliced away): the reference's per-image loop (yolo_head.py:313-353) costs ~10 tiny launches
+        # per tile, 17 ms of a 96 ms batch of 128 1024x1024 tiles
+        bs = flat.shape[0]
+        if bs == 0:
+            return []
+        res = _ops.nms_batched(flat.float().contiguous(), self.nc, conf, self.nms_params['iou_thres'], max_det, min_wh=2.0, class_aware=False)
+        n_keep = res['n_keep'].tolist()                    # the one D2H sync of the batch
+        scores = self.hierarchical_scores(res['scores'].reshape(bs * max_det, 1 + self.nc))
+        if self.multi_label:
+            out_scores, out_labels = scores.view(bs, max_det, -1), (scores > conf).view(bs, max_det, -1)
+        else:
+            obj = scores[:, 0]
+            cls_scores, cls_labels = scores[:, 1:].max(1)
+            hit = cls_scores > conf
+            out_scores = torch.where(hit, cls_scores, obj).view(bs, max_det)
+            out_labels = torch.where(hit, cls_labels + 1, torch.full_like(cls_labels, -100)).view(bs, max_det)
+        return [{'boxes': res['boxes'][b, :n], 'scores': out_scores[b, :n], 'labels': out_labels[b, :n]} for b, n in enumerate(n_keep)]
 
     # ------------------------------------------------------------------ training side
     def fused_loss_ok(self):
