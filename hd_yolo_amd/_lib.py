@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'build', os.path.basename(os.environ.get(
 
 F32, BF16 = 0, 1
 PACK_FWD, PACK_DGRAD, PACK_STEM = 0, 1, 2
-ACT_NONE, ACT_SILU = 0, 1
+ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
 
 _P, _I, _L, _F, _Z = c_void_p, c_int, c_longlong, c_float, c_size_t
 
@@ -56,6 +56,10 @@ SIGNATURES = {
     'hdy_nms_workspace_bytes': (_Z, [_I, _I]),
     'hdy_nms_batched': (_I, [_P, _I, _I, _I, _I, _F, _F, _I, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     'hdy_nms_boxes': (_I, [_P, _I, _I, _F, _I, _P, _P, _P, _Z, _P]),
+    'hdy_roi_align_fwd': (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _F, _I, _I, _I, _P, _I, _P]),
+    'hdy_roi_align_bwd': (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _F, _I, _I, _I, _I, _P]),
+    'hdy_relu_bwd': (_I, [_P, _P, _P, _L, _I, _P]),
+    'hdy_cast_store': (_I, [_P, _P, _I, _L, _I, _I, _I, _P]),
 }
 
 

@@ -174,6 +174,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
             for (int i = 0; i < VE; ++i) {
                 float u = v[i] * sc[i] + sh[i];
                 if (act == 1) u = fast_silu(u);
+                else if (act == 2) u = fmaxf(u, 0.0f);
                 if (res) u += r[i];
                 v[i] = u;
             }

@@ -347,7 +347,7 @@ int hdy_conv3x3_c64_slabs(int N, int H, int W, int C, int K, int R, int S, int s
 
 // Returns 1 and launches when the shape qualifies; 0 = not eligible (caller falls back to the generic kernel); <0 / >0 = error.
 int hdy_conv3x3_c64_try(const ConvArgs& a, int dtype, int out_f32, hipStream_t st, int* rc) {
-    if (dtype != HDY_BF16 || out_f32) return 0;
+    if (dtype != HDY_BF16 || out_f32 || a.act > 1) return 0;
     if (!(a.TH == 3 && a.TW == 3 && a.ih_mul == 1 && a.iw_mul == 1 && a.dh0 == -1 && a.dw0 == -1 && a.dense_out && !a.span_pixels)) return 0;
     if (!(a.Hin == a.Ho && a.Win == a.Wo && conv3x3_shape_ok(a.C, a.K, 3, 3, 1, 1, a.Ho, a.Wo, dtype))) return 0;
     const bool aligned = a.ldx % 8 == 0 && a.ldy % 8 == 0 && ((uintptr_t)a.y & 15) == 0 && ((uintptr_t)a.x & 15) == 0 &&

@@ -322,6 +322,7 @@ __global__ __launch_bounds__(2 * BM, (BM == 256 || BN == 128) ? 2 : (BN == 64 ? 
                                 v[r] = acc[a][b][r];
                                 if (affine) v[r] = v[r] * sc[r] + sh[r];
                                 if (p.act == 1) v[r] = v[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[r]));   // SiLU; 1 ulp, then bf16
+                                else if (p.act == 2) v[r] = fmaxf(v[r], 0.0f);
                             }
                             bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
                             *(bf16x4*)(scratch + row * ROWB + ((slot ^ (row & SWM)) << 3)) = o;
@@ -396,6 +397,7 @@ __global__ __launch_bounds__(2 * BM, (BM == 256 || BN == 128) ? 2 : (BN == 64 ? 
                     float v = acc[a][b][r];
                     if (affine) v = COEF_LDS ? v * coef[kc - n0] + coef[BN + kc - n0] : v * sc_reg[r] + sh_reg[r];
                     if (p.act == 1) v = silu_f(v);
+                    else if (p.act == 2) v = fmaxf(v, 0.0f);
                     if (rrow) v += to_f32<OT>(rrow[kc]);
                     if (p.accumulate) v += to_f32<OT>(yrow[kc]);
                     yrow[kc] = from_f32<OT>(v);

@@ -257,7 +257,7 @@ int hdy_conv_stem_slabs(int N, int H, int W, int K, int dtype) {
 
 // Returns 1 and launches when the stem shape qualifies; 0 = not eligible (generic kernel runs).
 int hdy_conv_stem_try(const ConvArgs& a, int dtype, int out_f32, hipStream_t st, int* rc) {
-    if (!a.span_pixels || out_f32 || a.res || a.accumulate || !a.dense_out) return 0;
+    if (!a.span_pixels || out_f32 || a.res || a.accumulate || !a.dense_out || a.act > 1) return 0;
     if (!(a.TH == 6 && a.TW == 1 && a.C == 24 && a.ldx == 4 && a.ih_mul == 2 && a.iw_mul == 2 && a.Kdp >= 160)) return 0;
     if (!(a.Hin == 2 * a.Ho + 4 && a.Win == 2 * a.Wo + 4 && stem_shape_ok(a.K, a.Ho, a.Wo, dtype))) return 0;
     const bool aligned = a.ldy % 8 == 0 && ((uintptr_t)a.y & 15) == 0 && ((uintptr_t)a.x & 15) == 0 && ((uintptr_t)a.w & 15) == 0;

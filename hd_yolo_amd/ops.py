@@ -11,7 +11,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import ACT_NONE, ACT_SILU, BF16, F32, PACK_DGRAD, PACK_FWD, PACK_STEM  # noqa: F401
+from ._lib import ACT_NONE, ACT_RELU, ACT_SILU, BF16, F32, PACK_DGRAD, PACK_FWD, PACK_STEM  # noqa: F401
 
 BN_EPS, BN_MOMENTUM = 1e-3, 0.03     # metayolo/models/utils_torch.py:47-49
 
@@ -359,6 +359,43 @@ def nms(boxes, scores, iou_thres, max_det=4096):
     _lib.call('hdy_nms_boxes', bs.data_ptr(), 1, N, float(iou_thres), int(max_det), keep.data_ptr(), n_keep.data_ptr(), ws.data_ptr(),
               ws.numel() * 8, stream_ptr())
     return keep[0, :int(n_keep.item())]
+
+
+# ------------------------------------------------------------------------------------------ mask branch primitives (row f2)
+def roi_align(feat, rois, spatial_scale, P, sampling_ratio=2, aligned=False):
+    """feat NHWC (B, H, W, C) (possibly a pitched view), rois (R, 5) fp32 [image, x1, y1, x2, y2] -> (R, P, P, C) NHWC."""
+    fp, B, H, W, C, ldf = nhwc(feat)
+    R = rois.shape[0]
+    out = torch.empty((R, P, P, C), dtype=feat.dtype, device=feat.device)
+    rois = rois.float().contiguous()
+    _lib.call('hdy_roi_align_fwd', fp, ldf, B, H, W, C, rois.data_ptr(), R, float(spatial_scale), P, sampling_ratio, int(aligned),
+              out.data_ptr(), dcode(feat.dtype), stream_ptr())
+    return out
+
+
+def roi_align_bwd(dout, shape, rois, spatial_scale, sampling_ratio=2, aligned=False, into=None):
+    """Scatter dout (R, P, P, C) into an fp32 image (B, H, W, C) (`into`, accumulated, or a fresh zero image)."""
+    B, H, W, C = shape
+    R, P = dout.shape[0], dout.shape[1]
+    dfeat = torch.zeros((B, H, W, C), dtype=torch.float32, device=dout.device) if into is None else into
+    rois = rois.float().contiguous()
+    _lib.call('hdy_roi_align_bwd', dout.contiguous().data_ptr(), dfeat.data_ptr(), B, H, W, C, rois.data_ptr(), R, float(spatial_scale), P,
+              sampling_ratio, int(aligned), dcode(dout.dtype), stream_ptr())
+    return dfeat
+
+
+def relu_bwd(dz, y):
+    assert dz.is_contiguous() and y.is_contiguous() and dz.shape == y.shape and dz.dtype == y.dtype
+    du = torch.empty_like(dz)
+    _lib.call('hdy_relu_bwd', dz.data_ptr(), y.data_ptr(), du.data_ptr(), dz.numel(), dcode(dz.dtype), stream_ptr())
+    return du
+
+
+def cast_store(src_f32, dst, accumulate=False):
+    """dst (NHWC view, any pitch) (+)= src_f32 (same logical shape, contiguous fp32)."""
+    dp, N, H, W, C, ldd = nhwc(dst)
+    assert src_f32.dtype == torch.float32 and src_f32.is_contiguous() and tuple(src_f32.shape) == (N, H, W, C)
+    _lib.call('hdy_cast_store', src_f32.data_ptr(), dp, ldd, N * H * W, C, int(accumulate), dcode(dst.dtype), stream_ptr())
 
 
 # ------------------------------------------------------------------------------------------ fused detection loss

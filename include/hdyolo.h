@@ -38,6 +38,7 @@ extern "C" {
 
 #define HDY_ACT_NONE 0
 #define HDY_ACT_SILU 1
+#define HDY_ACT_RELU 2 /* the Mask-RCNN head's convolutions (row f2) */
 
 const char* hdy_last_error(void);
 int hdy_version(void);
@@ -155,6 +156,20 @@ int hdy_nms_batched(const float* preds, int B, int N, int row, int nc, float con
  * score order (stable), -1 padded; n_keep[B].  Same kernel, workspace and max_det limit as hdy_nms_batched. */
 int hdy_nms_boxes(const float* boxes_scores, int B, int N, float iou, int max_det, long long* keep, int* n_keep, void* workspace,
                   size_t ws_bytes, void* stream);
+
+/* ---- mask branch primitives ------------------------------------------------------------
+ * hdy_roi_align_fwd/bwd replace torchvision.ops.roi_align as the reference calls it (metayolo/models/yolo_head.py:243 on ground
+ * truth boxes in training, :294 multiscale_roi_align on detections): feat NHWC [B][H][W][ldf] (C channels), rois [R][5] fp32
+ * (image index, x1, y1, x2, y2 in input pixels), out NHWC [R][P][P][C]; sampling_ratio^2 bilinear samples per bin.
+ * The backward scatters dout into dfeat_f32 [B][H][W][C] (fp32, zeroed by the caller) with atomic adds; hdy_cast_store moves
+ * that image into a pitched gradient view (dst[m][c] (+)= src[m][c]).  hdy_relu_bwd: du = dz * (y > 0) for the head's
+ * conv + bias + ReLU layers (torchvision MaskRCNNHeads / MaskRCNNPredictor, yolo_head.py:125-128). */
+int hdy_roi_align_fwd(const void* feat, int ldf, int B, int H, int W, int C, const float* rois, int R, float spatial_scale, int P,
+                      int sampling_ratio, int aligned, void* out, int dtype, void* stream);
+int hdy_roi_align_bwd(const void* dout, float* dfeat_f32, int B, int H, int W, int C, const float* rois, int R, float spatial_scale, int P,
+                      int sampling_ratio, int aligned, int dtype, void* stream);
+int hdy_relu_bwd(const void* dz, const void* y, void* du, long long n, int dtype, void* stream);
+int hdy_cast_store(const float* src, void* dst, int ldd, long long M, int C, int accumulate, int dtype, void* stream);
 
 /* ---- fused detection loss --------------------------------------------------------------
  * Replaces Detect.matcher (metayolo/models/yolo_head.py:358-417), DetLoss.forward (metayolo/models/loss.py:190-244) with

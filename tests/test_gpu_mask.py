@@ -1,0 +1,88 @@
+"""SURVEY §8 row f2 (mask branch) on the MI355X: roi_align forward/backward, the Mask-RCNN head's forward and backward through the HIP
+conv kernels, against the oracle's restatement of the third-party pieces (oracle/mask_ref.py) and torch autograd on the CPU."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from collections import OrderedDict
+
+from hd_yolo_amd import maskhead, ops
+from oracle import mask_ref
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device('cuda', 0)
+
+
+def relmax(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def _rois(gen, R, B, size):
+    c = torch.rand((R, 2), generator=gen) * size
+    wh = torch.rand((R, 2), generator=gen) * size * 0.2 + 2
+    r = torch.cat([torch.randint(0, B, (R, 1), generator=gen).float(), c - wh / 2, c + wh / 2], 1)
+    r[0, 1:] = torch.tensor([-20.0, -15.0, 10.0, 12.0])         # partly outside the image
+    r[1, 1:] = torch.tensor([size - 6.0, size - 5.0, size + 30.0, size + 40.0])
+    r[2, 1:] = torch.tensor([40.0, 40.0, 40.2, 40.1])           # narrower than one feature pixel: clamped to 1
+    return r
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 1e-5), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize('aligned', [False, True])
+def test_roi_align_forward_backward(dtype, tol, aligned):
+    g = torch.Generator().manual_seed(3)
+    B, C, H, W, stride, P = 3, 16, 20, 24, 8, 14
+    feat = torch.randn((B, C, H, W), generator=g).to(dtype).float()
+    rois = _rois(g, 37, B, H * stride)
+    fr = feat.clone().requires_grad_(True)
+    ref = mask_ref.roi_align(fr, rois, P, 1.0 / stride, 2, aligned)
+    dout = torch.randn(ref.shape, generator=g).to(dtype).float()
+    ref.backward(dout)
+    # device: NHWC feature inside a wider (pitched) buffer
+    buf = torch.zeros((B, H, W, C + 8), dtype=dtype, device=DEV)
+    buf[..., :C] = feat.permute(0, 2, 3, 1).to(DEV).to(dtype)
+    out = ops.roi_align(buf[..., :C], rois.to(DEV), 1.0 / stride, P, 2, aligned)
+    assert relmax(out.permute(0, 3, 1, 2), ref.detach()) < tol
+    df = ops.roi_align_bwd(dout.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype), (B, H, W, C), rois.to(DEV), 1.0 / stride, 2, aligned)
+    assert relmax(df.permute(0, 3, 1, 2), fr.grad) < 1e-4        # fp32 atomics: order-dependent rounding only
+    gbuf = torch.full((B, H, W, C + 8), 2.0, dtype=dtype, device=DEV)
+    ops.cast_store(df, gbuf[..., :C], accumulate=True)
+    assert relmax(gbuf[..., :C].permute(0, 3, 1, 2), fr.grad + 2.0) < max(tol, 1e-4) and (gbuf[..., C:] == 2.0).all()
+    assert ops.roi_align(buf[..., :C], torch.zeros((0, 5), device=DEV), 0.125, P).shape == (0, P, P, C)
+
+
+class _SegH(nn.Sequential):
+    def __init__(self, c_in, nc_masks):
+        super().__init__(OrderedDict([('maskrcnn_heads', mask_ref.MaskRCNNHeads(c_in, (256, 256, 256, 256), 1)),
+                                      ('maskrcnn_preds', mask_ref.MaskRCNNPredictor(256, 256, nc_masks))]))
+
+
+# bf16: every intermediate gradient of the 6-layer chain is rounded to bf16 and ReLU masks of near-zero activations may flip;
+# fp32 is the parity mode
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 2e-4), (torch.bfloat16, 8e-2)])
+def test_mask_head_forward_backward(dtype, tol):
+    torch.manual_seed(1)
+    R, C, P, ncm = 9, 64, 14, 3
+    seg_h = _SegH(C, ncm)
+    for p in seg_h.parameters():
+        p.data = p.data.to(dtype).float()
+        if p.dim() == 1:
+            p.data.uniform_(-0.2, 0.2)
+    x = (torch.randn((R, C, P, P)) * 0.5).to(dtype).float()
+    xr = x.clone().requires_grad_(True)
+    ref = seg_h(xr)                                            # (R, ncm, 28, 28)
+    dl = torch.randn(ref.shape) * 0.1
+    ref.backward(dl)
+    dev_h = _SegH(C, ncm).to(DEV)
+    dev_h.load_state_dict(seg_h.state_dict())
+    run = maskhead.MaskHeadRun(dev_h, dtype)
+    out = run.forward(x.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype), train=True)
+    assert out.dtype == torch.float32 and tuple(out.shape) == (R, 2 * P, 2 * P, ncm)
+    assert relmax(out.permute(0, 3, 1, 2), ref.detach()) < tol
+    grads = {id(p): torch.zeros_like(p) for p in dev_h.parameters()}
+    dx = run.backward(dl.permute(0, 2, 3, 1).contiguous().to(DEV), lambda p: grads[id(p)])
+    assert relmax(dx.permute(0, 3, 1, 2), xr.grad) < tol * 2
+    for (name, p), q in zip(seg_h.named_parameters(), dev_h.parameters()):
+        assert relmax(grads[id(q)], p.grad) < tol * 2, name
