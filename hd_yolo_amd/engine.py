@@ -73,6 +73,54 @@ class _PlanFn(torch.autograd.Function):
         return None, None, None, None
 
 
+class _PlanMaskFn(torch.autograd.Function):
+    """_PlanFn for a model with a mask branch: besides the logits it returns a 1-element token that the mask branch's autograd
+    node consumes, so that autograd runs the branch's backward (which fills the plan's mask-feature gradients) before this one."""
+
+    @staticmethod
+    def forward(ctx, engine, plan, hook, images):
+        ctx.engine, ctx.plan = engine, plan
+        return tuple(plan.run_forward(images)) + (torch.zeros(1, device=images.device),)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        ctx.plan.run_backward(grads[:-1])
+        ctx.engine.after_backward()
+        return None, None, None, None
+
+
+class MaskBranchFn(torch.autograd.Function):
+    """roi_align over the plan's mask feature maps + the Mask R-CNN head (hd_yolo_amd/maskhead.py), as one autograd node:
+    forward -> fp32 logits (R, nc_masks, 28, 28); backward -> head parameter gradients into the flat store and the roi_align
+    scatter into the plan's mask-feature gradient buffers."""
+
+    @staticmethod
+    def forward(ctx, token, engine, plan, head, rois_by_level, order, dtype):
+        from .maskhead import MaskHeadRun
+        P = head.mask_output_size // 2
+        feats = plan.mask_features()
+        parts = [ops.roi_align(feats[l], r, 1.0 / float(head.anchors[l].stride), P, 2, head.aligned) for l, r in enumerate(rois_by_level)]
+        x = torch.cat(parts)[order]
+        run = MaskHeadRun(head.seg_h, dtype)
+        logits = run.forward(x.contiguous(), train=True)
+        ctx.engine, ctx.plan, ctx.head, ctx.run = engine, plan, head, run
+        ctx.rois, ctx.order, ctx.sizes = rois_by_level, order, [p.shape[0] for p in parts]
+        return logits.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        store, plan, head = ctx.engine.store, ctx.plan, ctx.head
+        dx = ctx.run.backward(dlogits.permute(0, 2, 3, 1).contiguous().float(), store.view_of)
+        inv = torch.empty_like(ctx.order)
+        inv[ctx.order] = torch.arange(len(ctx.order), device=ctx.order.device)
+        dparts = torch.split(dx[inv], ctx.sizes)                  # back to the per-level concatenation order
+        for l, (v, rois, dpart) in enumerate(zip(plan.mask_vals, ctx.rois, dparts)):
+            img = ops.roi_align_bwd(dpart.contiguous(), (v.n, v.h, v.w, v.c), rois, 1.0 / float(head.anchors[l].stride), 2, head.aligned)
+            ops.cast_store(img, v.g(), accumulate=False)
+        plan.mask_grads_ready = True
+        return torch.zeros(1, device=dlogits.device), None, None, None, None, None, None
+
+
 class _FusedLossFn(torch.autograd.Function):
     """loss = hdy_det_loss(plan logits, targets); its backward replays the plan's backward launch list."""
 
@@ -98,6 +146,7 @@ class Engine:
         self.store = None
         self.hook = None
         self.grad_hooks = []          # callables run after every backward, before publish (data-parallel all-reduce)
+        self.mask_token = None
 
     # An engine is a cache of device buffers and marshalled launch records for the module OBJECTS it was traced from: a copied or
     # unpickled module (ModelEMA, Deploy(fuse=True), torch.save of a whole model) gets none and builds its own on first use.
@@ -171,8 +220,12 @@ class Engine:
     def forward(self, x, training, dtype):
         """Returns (plan, det logits list).  With grad enabled in training mode the logits are attached to autograd."""
         plan = self.plan_for(x, training, dtype)
+        self.mask_token = None
         if training and torch.is_grad_enabled():
-            dets = _PlanFn.apply(self, plan, self.hook, x)
+            if plan.mask_vals:
+                *dets, self.mask_token = _PlanMaskFn.apply(self, plan, self.hook, x)
+            else:
+                dets = _PlanFn.apply(self, plan, self.hook, x)
         else:
             dets = plan.run_forward(x)
         return plan, list(dets)

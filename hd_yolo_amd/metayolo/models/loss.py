@@ -118,3 +118,34 @@ class DetLoss(nn.Module):
         lbox, lobj, lcls = lbox * self.hyp['box'], lobj * self.hyp['obj'], lcls * self.hyp['cls']
         bs = p[0].shape[0]
         return (lbox + lobj + lcls) * bs, {'box': lbox.detach(), 'obj': lobj.detach(), 'cls': lcls.detach()}
+
+
+class SegLoss(nn.Module):
+    """Mask loss on the (n, nc_masks, 28, 28) logits of the kept proposals (reference: metayolo/models/loss.py:247-283): the channel
+    of each proposal's mask label, BCE-with-logits (or 1 - soft dice for type 'dice') against the 28 x 28 target masks, over proposals
+    with a non-empty target and a label >= 0; times hyp['mask']; shape (1,) like det_loss."""
+
+    def __init__(self, hyp={}):
+        super().__init__()
+        self.hyp = self.get_hyp_params(hyp)
+        if self.hyp['type'] not in ('bce', 'dice'):
+            raise ValueError(f"SegLoss type {self.hyp['type']!r}")
+
+    def get_hyp_params(self, args={}):
+        defaults = {'mask': 1.0, 'type': 'bce'}
+        return {k: args.get(k, v) for k, v in defaults.items()}
+
+    def forward(self, mask_logits, mask_targets, mask_labels):
+        rows = torch.arange(mask_labels.shape[0], device=mask_labels.device)
+        logits = mask_logits[rows, mask_labels][:, None]
+        keep = (mask_targets.sum(dim=[1, 2, 3]) > 0) & (mask_labels >= 0)
+        targets, logits = mask_targets[keep], logits[keep]
+        if targets.numel() == 0:
+            return logits.sum() * 0
+        if self.hyp['type'] == 'bce':
+            loss = F.binary_cross_entropy_with_logits(logits, targets)
+        else:
+            p = logits.sigmoid()                     # soft dice: mask_iou(factor=0, eps=0), utils_general.py:268-280
+            prod, plus = (targets * p).sum([2, 3]), (targets + p).sum([2, 3])
+            loss = 1 - (2 * prod / plus).mean()
+        return (loss * self.hyp['mask'])[None]

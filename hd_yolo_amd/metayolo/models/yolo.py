@@ -92,7 +92,8 @@ class Model(nn.Module):
                 if keep != list(range(x.shape[0])):
                     sel = torch.tensor(keep, device=x.device, dtype=torch.long)
                     task_dets = [d.index_select(0, sel) for d in dets]
-            losses[task_id], outputs[task_id] = header.forward_dets(task_dets, task_gts, compute_masks=compute_masks)
+            mask_ctx = (self._eng(), plan, dtype) if getattr(header, 'nc_masks', 0) > 0 else None
+            losses[task_id], outputs[task_id] = header.forward_dets(task_dets, task_gts, compute_masks=compute_masks, mask_ctx=mask_ctx)
         outputs = [dict(zip(outputs.keys(), per_image)) for per_image in zip(*outputs.values())]
         return losses, self.post_processing(outputs)
 

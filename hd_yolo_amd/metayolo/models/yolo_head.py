@@ -4,10 +4,13 @@
 :358-417 matcher, :419-448 grids / bias init / NMS params, :473-511 hierarchical scores).
 
 On MI355X: the per-level 1x1 convs run inside the model's HIP plan (or a head-only plan when Detect is called on
-feature maps directly); decode and NMS are the `hdy_decode` / `hdy_nms_batched` kernels.  The mask branch
-(`masks` > 0: roi_align, Mask-RCNN heads, SegLoss) is SURVEY.md §8 row f2 and raises NotImplementedError.
+feature maps directly); decode and NMS are the `hdy_decode` / `hdy_nms_batched` kernels.  The mask branch (SURVEY.md §8 row f2;
+reference :114-130, :231-275, :279-299, :320-353): the per-level seg convs are part of the model plan, roi_align and the Mask R-CNN
+head run on their own kernels per call (hd_yolo_amd/maskhead.py, engine.MaskBranchFn), SegLoss is a tensor expression on the
+(n, 1, 28, 28) logits.
 """
 import math
+from collections import OrderedDict
 from typing import Dict, List, Optional
 
 import torch
@@ -16,8 +19,10 @@ import torch.nn as nn
 from .. import LOGGER
 from ... import engine as _engine
 from ... import ops as _ops
-from .loss import DetLoss
-from .utils_general import nms_per_image, xyxy2xywh
+from .layers import Conv
+from .loss import DetLoss, SegLoss
+from .mask_rcnn import MaskRCNNHeads, MaskRCNNPredictor
+from .utils_general import nms_per_image, paired_box_iou, xywh2xyxy, xyxy2xywh
 from .utils_torch import one_hot_labels
 
 
@@ -69,14 +74,26 @@ class Detect(nn.Module):
         self.register_buffer('mask_indices', mask_indices)
         self.dim_reduced = dim_reduced
         if self.nc_masks > 0:
-            raise NotImplementedError('Detect: the mask branch (masks >= 0) is the next hot-path row (SURVEY.md §8 f2); '
-                                      'build the header with masks = -1')
-        self.mask_output_size = None
-        self.seg, self.seg_h, self.seg_loss = None, None, None
+            self.mask_output_size = mask_output_size
+            self.seg, self.seg_h = self.build_seg_layers()
+            self.aligned = False                      # the reference's ROI_ALIGN global (yolo_head.py:15)
+            self.seg_loss = None if is_scripting else SegLoss(loss_hyp)
+        else:
+            self.mask_output_size = None
+            self.seg, self.seg_h, self.seg_loss = None, None, None
 
     # ------------------------------------------------------------------ construction helpers
     def build_det_layers(self):
         return nn.ModuleList(nn.Conv2d(c, self.no * self.na, 1) for c in self.ch)
+
+    def build_seg_layers(self):
+        """One 3x3 Conv (-> dim_reduced) per level, top-down like the reference (yolo_head.py:123-128), and the Mask R-CNN head."""
+        seg = nn.ModuleList(Conv(self.ch[i], self.dim_reduced, kernel_size=3, act=True) for i in range(self.nl - 1, -1, -1))
+        seg_h = nn.Sequential(OrderedDict([
+            ('maskrcnn_heads', MaskRCNNHeads(self.dim_reduced, (256, 256, 256, 256), 1)),
+            ('maskrcnn_preds', MaskRCNNPredictor(256, 256, self.nc_masks)),
+        ]))
+        return seg, seg_h
 
     def _make_grid(self, anchor, stride, nx: int = 20, ny: int = 20):
         d, t = anchor.device, anchor.dtype
@@ -137,15 +154,18 @@ class Detect(nn.Module):
         plan = eng.plan_for_features(feats, _engine.compute_dtype(self, next(iter(feats.values()))))
         return list(plan.run_forward_features(feats))
 
-    def forward_dets(self, dets: List[torch.Tensor], targets=None, compute_masks: bool = True):
-        """Tail of Detect.forward given the per-level logits (bs, na, ny, nx, no) fp32."""
+    def forward_dets(self, dets: List[torch.Tensor], targets=None, compute_masks: bool = True, mask_ctx=None):
+        """Tail of Detect.forward given the per-level logits (bs, na, ny, nx, no) fp32.  mask_ctx = (engine, plan, dtype) of the
+        launch plan whose mask feature maps the mask branch reads (None: no mask branch in this call)."""
         if self.training:
             assert targets is not None
             want_loss, want_out = True, False
         else:
             want_loss, want_out = targets is not None, True
-        losses = self.compute_losses(dets, [], [], targets, compute_masks=False) if want_loss else {}
-        outputs = self.compute_outputs(self.compute_proposals(dets), [], compute_masks=False) if want_out else []
+        compute_masks = bool(compute_masks) and self.nc_masks > 0 and mask_ctx is not None
+        preds = self.compute_proposals(dets) if (want_out or (want_loss and compute_masks)) else []
+        losses = self.compute_losses(dets, preds, mask_ctx, targets, compute_masks=compute_masks) if want_loss else {}
+        outputs = self.compute_outputs(preds, mask_ctx, compute_masks=compute_masks) if want_out else []
         return losses, outputs
 
     def anchor_px(self, i):
@@ -206,7 +226,37 @@ class Detect(nn.Module):
             hit = cls_scores > conf
             out_scores = torch.where(hit, cls_scores, obj).view(bs, max_det)
             out_labels = torch.where(hit, cls_labels + 1, torch.full_like(cls_labels, -100)).view(bs, max_det)
-        return [{'boxes': res['boxes'][b, :n], 'scores': out_scores[b, :n], 'labels': out_labels[b, :n]} for b, n in enumerate(n_keep)]
+        results = [{'boxes': res['boxes'][b, :n], 'scores': out_scores[b, :n], 'labels': out_labels[b, :n]} for b, n in enumerate(n_keep)]
+        if compute_masks and sum(n_keep) > 0 and not self.multi_label:
+            self.attach_masks(results, res, n_keep, features)
+        return results
+
+    def attach_masks(self, results, res, n_keep, mask_ctx):
+        """multiscale_roi_align over the detections (each from the level that produced it) -> Mask R-CNN head -> sigmoid -> the
+        channel of the detection's mask label; 28 x 28 masks in box coordinates (reference: yolo_head.py:320-353, :279-299)."""
+        from ...maskhead import MaskHeadRun
+        engine, plan, dtype = mask_ctx
+        dev = res['boxes'].device
+        img = torch.cat([torch.full((n,), float(b), device=dev) for b, n in enumerate(n_keep)])
+        boxes = torch.cat([res['boxes'][b, :n] for b, n in enumerate(n_keep)])
+        levels = torch.cat([res['extra'][b, :n, 0] for b, n in enumerate(n_keep)]).long()
+        rois = torch.cat([img[:, None], boxes], 1)
+        P = self.mask_output_size // 2
+        feats = plan.mask_features()
+        parts, pos = [], []
+        for l in range(self.nl):
+            sel = (levels == l).nonzero().flatten()
+            pos.append(sel)
+            parts.append(_ops.roi_align(feats[l], rois[sel], 1.0 / float(self.anchors[l].stride), P, 2, self.aligned))
+        order = torch.empty(len(rois), dtype=torch.long, device=dev)
+        order[torch.cat(pos)] = torch.arange(len(rois), device=dev)
+        logits = MaskHeadRun(self.seg_h, dtype).forward(torch.cat(parts)[order].contiguous())        # (R, 28, 28, nc_masks) fp32
+        probs = logits.sigmoid().permute(0, 3, 1, 2).split(n_keep, dim=0)
+        for r, m in zip(results, probs):
+            if len(m):
+                mask_labels = self.mask_indices[r['labels'].clamp(min=0)]
+                r['masks'] = m[torch.arange(len(m), device=dev), mask_labels][:, None]
+                r['masks'][mask_labels < 0] = 0
 
     # ------------------------------------------------------------------ training side
     def fused_loss_ok(self):
@@ -214,7 +264,7 @@ class Detect(nn.Module):
         import os
         dl = self.det_loss
         return (os.environ.get('HDY_FUSED_LOSS', '1') != '0' and not dl.autobalance and dl.hyp['fl_gamma'] == 0 and dl.gr == 1.0
-                and not dl.sort_obj_iou and self.nc <= 128)
+                and not dl.sort_obj_iou and self.nc <= 128 and self.nc_masks == 0)
 
     def flatten_targets(self, targets, dev):
         """Per-image ann dicts -> gts (nt,5) [img, cx, cy, w, h] and one-hot labels (nt, nc+1), built once per batch."""
@@ -250,8 +300,55 @@ class Detect(nn.Module):
         tbox, tids, indices, anchors = self.matcher(dets, gts)
         tcls = [gt_labels[i] for i in tids]
         det_loss, items = self.det_loss(dets, tcls, tbox, indices, anchors)
-        mask_loss = torch.zeros_like(det_loss)
+        mask_loss = self.mask_losses(preds, features, targets, gts, tids, indices, tcls) if compute_masks else None
+        if mask_loss is None:
+            mask_loss = torch.zeros_like(det_loss)
         return {'det_loss': det_loss, 'mask_loss': mask_loss, 'loss_items': {**items, 'mask': mask_loss.detach()}}
+
+    def mask_losses(self, preds, mask_ctx, targets, gts, tids, indices, tcls):
+        """Mask loss of the matched cells (reference: yolo_head.py:231-275): per level, roi_align of the mask feature map over the
+        GROUND-TRUTH boxes of the matched targets; of all cells matched to one target only the one whose predicted box has the
+        best IoU with the truth, and only if that IoU >= 0.8, goes through the Mask R-CNN head; SegLoss against the 28 x 28 target."""
+        engine, plan, dtype = mask_ctx
+        dev = gts.device
+        props, gt_props, obj_ids, rois = [], [], [], []
+        for i, buf in enumerate(self.anchors):
+            v = plan.mask_vals[i]
+            b, a, gj, gi = indices[i]
+            boxes = xywh2xyxy(preds[i][b, a, gj, gi, :4].detach())
+            gt_boxes = xywh2xyxy(gts[tids[i]][:, 1:] * gts.new([v.w, v.h, v.w, v.h]) * buf.stride)
+            props.append(boxes)
+            gt_props.append(gt_boxes)
+            obj_ids.append(tids[i])
+            rois.append(torch.cat([b[:, None].to(gt_boxes.dtype), gt_boxes], -1))
+        sizes = [len(o) for o in obj_ids]
+        props, gt_props, obj_ids = torch.cat(props), torch.cat(gt_props), torch.cat(obj_ids)
+        if not len(obj_ids):
+            return None
+        # torch_scatter.scatter_max(box_ious, obj_ids): per target its best IoU and the FIRST row attaining it
+        ious = paired_box_iou(props, gt_props)
+        nobj = int(gts.shape[0])
+        best = torch.zeros(nobj, dtype=ious.dtype, device=dev).scatter_reduce_(0, obj_ids, ious, 'amax', include_self=False)
+        rows = torch.arange(len(ious), device=dev)
+        hit = ious == best[obj_ids]
+        arg = torch.full((nobj,), len(ious), dtype=torch.long, device=dev).scatter_reduce_(0, obj_ids[hit], rows[hit], 'amin')
+        present = torch.zeros(nobj, dtype=torch.bool, device=dev).index_fill_(0, obj_ids, True)
+        keep = arg[(best >= 0.8) & present]
+        if not len(keep):
+            return None
+        # roi_align only what is kept; rows are concatenated level by level, `order` puts them in `keep` order
+        level = torch.repeat_interleave(torch.arange(self.nl, device=dev), torch.tensor(sizes, device=dev))
+        all_rois = torch.cat(rois)
+        klev = level[keep]
+        by_level = [all_rois[keep[klev == l]] for l in range(self.nl)]
+        pos = torch.cat([(klev == l).nonzero().flatten() for l in range(self.nl)])       # position in `keep` of each concatenated row
+        order = torch.empty_like(pos)
+        order[pos] = torch.arange(len(pos), device=dev)
+        mask_logits = _engine.MaskBranchFn.apply(engine.mask_token, engine, plan, self, by_level, order, dtype)
+        mask_targets = torch.cat([t['masks'] for t in targets]).to(dev)[obj_ids[keep], None] * 1.0
+        gt_labels = torch.cat(tcls)[keep]
+        hier = (gt_labels * torch.arange(self.nc + 1, device=dev)).max(-1)[1]
+        return self.seg_loss(mask_logits, mask_targets, self.mask_indices[hier])
 
     def _const(self, key, dev, make):
         """small constant tensors are uploaded once per device, not once per step (each upload is a host sync)"""

@@ -263,6 +263,15 @@ class Plan:
                 self.units.append(u)
                 self.det_units.append(u)
             self.na, self.no = head.na, head.no
+        # mask branch: one 3x3 Conv per level, top-down module order (yolo_head.py:123-124, :170-173); their outputs
+        # feed roi_align outside the plan and their output gradients arrive from there (MaskBranch in engine.py)
+        self.mask_vals = []
+        if head is not None and getattr(head, 'seg', None) is not None:
+            f = head.f if isinstance(head.f, (list, tuple)) else [head.f]
+            vals = [self._module(m, outs[f[-i]]) for i, m in enumerate(head.seg, 1)]
+            self.mask_vals = vals[::-1]
+        self.mask_grads_ready = False
+        self.seg_h_params = list(head.seg_h.parameters()) if self.mask_vals else []
 
     # ------------------------------------------------------------------ memory
     def _new(self, *shape, dtype=None, zero=False):
@@ -463,6 +472,10 @@ class Plan:
             views.append(u.logits[..., :u.K].view(x.n, x.h, x.w, self.na, self.no).permute(0, 3, 1, 2, 4))
         return views
 
+    def mask_features(self):
+        """NHWC views of the mask branch's per-level feature maps (level order)."""
+        return [v.t() for v in self.mask_vals]
+
     def feature(self, index):
         """NCHW-shaped (channels-last strided) view of layer `index`'s output."""
         return self.outs[index].t().permute(0, 3, 1, 2)
@@ -583,6 +596,12 @@ class Plan:
                 else:
                     pre.append(ops.rec_det_grad_pack(g, u.gdet, self.na, self.no))
         ops.run(pre)
+        if self.mask_vals and not self.mask_grads_ready:
+            for v in self.mask_vals:                 # no mask loss in this step: the branch contributes nothing
+                v.g().zero_()
+            for q in self.seg_h_params:
+                self.grad_store.view_of(q).zero_()
+        self.mask_grads_ready = False
         self._replay('bwd', self.bwd)
         for u in self.det_units:
             u.gb.copy_(u.gbias_pad[:u.K])

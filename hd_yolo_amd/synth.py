@@ -103,6 +103,8 @@ def synth_state_dict(shapes, seed=0):
             v = 0.5 + u
         elif '.bn.' in key and key.endswith('bias'):
             v = (u - 0.5) * 0.4
+        elif '.seg_h.' in key and key.endswith('bias'):   # Mask R-CNN head: small positive biases keep the ReLU chain alive
+            v = u * 0.2
         elif key.endswith('bias'):          # Detect 1x1 conv bias
             v = (u - 0.5) * 2.0 - 2.0
         else:                               # conv weight [K, C, R, S]
@@ -113,6 +115,16 @@ def synth_state_dict(shapes, seed=0):
             v = (u * 2 - 1) * bound
         out[key] = v.to(dtype)
     return out
+
+
+def mask_state_dict(module, seed=0):
+    """synth_state_dict with the detection convs damped, so that matched cells predict (almost) their anchor box: IoU >= 0.8 with the
+    anchor-shaped truths of synth_mask_targets — otherwise nothing would reach the mask head."""
+    sd = synth_state_dict(shapes_of(module), seed=seed)
+    for k in list(sd):
+        if k.startswith('headers.det.m.'):
+            sd[k] = sd[k] * (0.02 if k.endswith('weight') else 0.0)
+    return sd
 
 
 def shapes_of(module):
@@ -126,11 +138,12 @@ def synth_images(batch, size, seed=0):
     return torch.rand((batch, 3, size, size), generator=g, dtype=torch.float32)
 
 
-def synth_targets(batch, size, nc, nmin=50, nmax=400, seed=1, task='det', normalize=True):
+def synth_targets(batch, size, nc, nmin=50, nmax=400, seed=1, task='det', normalize=True, masks=False):
     """Nuclei-like targets in the reference's batch schema (metayolo/datasets.py:462-519).
 
     boxes are xyxy, normalised to 0..1 when `normalize` (training convention,
-    metayolo/datasets.py:496-497); labels are int64 in 1..nc.
+    metayolo/datasets.py:496-497); labels are int64 in 1..nc.  With `masks`, every object also gets a (28, 28)
+    float mask in its box frame (an ellipse of random fill; about one in ten is empty), as the mask branch consumes them.
     """
     g = torch.Generator(device='cpu')
     g.manual_seed(2000 + seed)
@@ -145,8 +158,44 @@ def synth_targets(batch, size, nc, nmin=50, nmax=400, seed=1, task='det', normal
         labels = torch.randint(1, nc + 1, (n,), generator=g, dtype=torch.int64)
         ann = {'size': torch.tensor([size, size], dtype=torch.int64),
                'boxes': boxes.float(), 'labels': labels}
+        if masks:
+            yy, xx = torch.meshgrid(torch.linspace(-1, 1, 28), torch.linspace(-1, 1, 28), indexing='ij')
+            rad = 0.5 + 0.5 * torch.rand((n, 1, 1), generator=g)
+            m = ((xx[None] ** 2 + yy[None] ** 2) <= rad ** 2).float()
+            m[torch.rand(n, generator=g) < 0.1] = 0.0
+            ann['masks'] = m
         targets.append({'image_id': torch.tensor([i], dtype=torch.int64),
                         'size': torch.tensor([size, size], dtype=torch.int64),
+                        'anns': {task: [ann]}})
+    return tuple(targets)
+
+
+def synth_mask_targets(batch, size, nc, per_image=6, seed=4, task='det'):
+    """Targets for exercising the mask branch: boxes that sit on a P3 / P4 cell centre with (almost) an anchor's shape, so that with
+    near-zero box logits the predicted box of the matched cell overlaps its truth with IoU >= 0.8 (the reference only sends such
+    proposals through the mask head, yolo_head.py:255-258); (28, 28) elliptic masks, one per image left empty."""
+    g = torch.Generator(device='cpu')
+    g.manual_seed(4000 + seed)
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, 28), torch.linspace(-1, 1, 28), indexing='ij')
+    targets = []
+    for i in range(batch):
+        boxes = []
+        for _ in range(per_image):
+            lvl = int(torch.randint(0, 2, (1,), generator=g))
+            stride = (8, 16)[lvl]
+            aw, ah = ANCHORS_P5[lvl][2 * int(torch.randint(0, 3, (1,), generator=g)):][:2]
+            n = size // stride
+            gi, gj = (int(v) for v in torch.randint(1, n - 1, (2,), generator=g))
+            jit = 1.0 + 0.06 * (torch.rand(2, generator=g) - 0.5)
+            cx, cy, w, h = (gi + 0.5) * stride, (gj + 0.5) * stride, aw * float(jit[0]), ah * float(jit[1])
+            boxes.append([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2])
+        boxes = (torch.tensor(boxes) / size).clamp_(0.0, 1.0)
+        labels = torch.randint(1, nc + 1, (per_image,), generator=g, dtype=torch.int64)
+        rad = 0.5 + 0.5 * torch.rand((per_image, 1, 1), generator=g)
+        m = ((xx[None] ** 2 + yy[None] ** 2) <= rad ** 2).float()
+        m[0] = 0.0
+        ann = {'size': torch.tensor([size, size], dtype=torch.int64), 'boxes': boxes.float(), 'labels': labels, 'masks': m}
+        targets.append({'image_id': torch.tensor([i], dtype=torch.int64), 'size': torch.tensor([size, size], dtype=torch.int64),
                         'anns': {task: [ann]}})
     return tuple(targets)
 

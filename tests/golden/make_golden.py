@@ -36,7 +36,7 @@ REF = '/root/reference'
 sys.path.insert(0, ROOT)
 
 from hd_yolo_amd import synth  # noqa: E402
-from oracle import nms_ref     # noqa: E402
+from oracle import mask_ref, nms_ref     # noqa: E402
 
 
 def install_shims():
@@ -90,27 +90,30 @@ def install_shims():
     class FrozenBatchNorm2d(nn.Module):
         pass
 
-    ops.nms, ops.remove_small_boxes, ops.roi_align = nms, remove_small_boxes, _absent
+    # mask branch: the oracle's restatements of the absent third-party pieces (oracle/mask_ref.py; boundary unpinned)
+    ops.nms, ops.remove_small_boxes, ops.roi_align = nms, remove_small_boxes, mask_ref.roi_align
     ops.FrozenBatchNorm2d = misc.FrozenBatchNorm2d = FrozenBatchNorm2d
     ops.misc = misc
     tv.ops = ops
     models = types.ModuleType('torchvision.models')
     det = types.ModuleType('torchvision.models.detection')
     mr = types.ModuleType('torchvision.models.detection.mask_rcnn')
-    mr.MaskRCNNHeads = mr.MaskRCNNPredictor = _absent
+    mr.MaskRCNNHeads, mr.MaskRCNNPredictor = mask_ref.MaskRCNNHeads, mask_ref.MaskRCNNPredictor
     tv.models, models.detection, det.mask_rcnn = models, det, mr
     for name, m in [('torchvision', tv), ('torchvision.ops', ops), ('torchvision.ops.misc', misc),
                     ('torchvision.models', models), ('torchvision.models.detection', det),
                     ('torchvision.models.detection.mask_rcnn', mr)]:
         sys.modules[name] = m
     ts = types.ModuleType('torch_scatter')
-    ts.scatter_max = _absent
+    ts.scatter_max = mask_ref.scatter_max
     sys.modules['torch_scatter'] = ts
 
 
-def ref_model(variant, nc, hyp):
+def ref_model(variant, nc, hyp, masks=-1):
     yolo = importlib.import_module('metayolo.models.yolo')
-    model = yolo.Model(synth.make_cfg(variant, nc), hyp)
+    cfg = synth.make_cfg(variant, nc)
+    cfg['headers'][0][3][3] = masks
+    model = yolo.Model(cfg, hyp)
     sd = synth.synth_state_dict(synth.shapes_of(model), seed=0)
     missing = model.load_state_dict(sd, strict=False)
     assert not missing.unexpected_keys
@@ -396,6 +399,70 @@ def gen_nms_options():
     print('wrote nms_options.npz', {k: v.shape for k, v in out.items() if k.endswith('_0')})
 
 
+def gen_masks():
+    """the reference's Detect with masks=1, on the oracle's roi_align / Mask R-CNN head / scatter_max."""
+    out = {}
+    # ---- eval: detections with 28 x 28 masks
+    hyp = synth.make_hyp(conf_thres=0.05)
+    model = ref_model('n', 2, hyp, masks=1)
+    model.load_state_dict(synth.mask_state_dict(model), strict=False)
+    model.eval()
+    x = synth.synth_images(2, 128, seed=7)
+    # compute_outputs(compute_masks=True) itself does not run on this torch (yolo_head.py:348 indexes with the float result of
+    # clamp(min=0.) -> IndexError), so its steps are called one by one: every call below is the reference's own function
+    from torch.nn import functional as F
+    ug = importlib.import_module('metayolo.models.utils_general')
+    with torch.no_grad():
+        head = model.headers['det']
+        feats = model.neck(model.backbone(x))
+        xs = [feats[j] for j in head.f]
+        dets = []
+        for i, conv in enumerate(head.m):
+            f = conv(xs[i])
+            bs, _, ny, nx = f.shape
+            dets.append(f.view(bs, head.na, head.no, ny, nx).permute(0, 1, 3, 4, 2).contiguous())
+        preds = head.compute_proposals(dets)
+        mask_maps = [seg(xs[-i]) for i, seg in enumerate(head.seg, 1)][::-1]
+        flat = torch.cat([F.pad(y.view(y.shape[0], -1, head.no), [0, 1], value=float(idx)) for idx, y in enumerate(preds)], 1)
+        kept = ug.nms_per_image(flat, nc=head.nc, conf_thres=head.nms_params['conf_thres'], iou_thres=head.nms_params['iou_thres'],
+                                max_det=int(head.nms_params['max_det']))
+        proposals = torch.cat([F.pad(k['boxes'], [1, 0], value=float(i)) for i, k in enumerate(kept) if len(k['boxes'])])
+        levels = torch.cat([k['extra'][:, 0] for k in kept if len(k['boxes'])])
+        probs = head.seg_h(head.multiscale_roi_align(mask_maps, boxes=proposals, levels=levels)).sigmoid()
+        _, outputs = model(x, compute_masks=False)
+    out['eval_mask_probs'] = npf(probs)                       # (R, nc_masks, 28, 28), detections of image 0 then image 1
+    out['eval_levels'] = npf(levels)
+    for l, f in enumerate(mask_maps):
+        out[f'eval_maskmap_{l}'] = npf(f)
+    for b, o in enumerate(outputs):
+        for k in ('boxes', 'scores', 'labels'):
+            out[f'eval_{b}_{k}'] = npf(o['det'][k])
+    # ---- train: det + mask loss, gradients
+    model = ref_model('n', 2, synth.make_hyp(), masks=1)
+    model.load_state_dict(synth.mask_state_dict(model), strict=False)
+    model.train()
+    x = synth.synth_images(2, 128, seed=11)
+    targets = synth.synth_mask_targets(2, 128, 2, per_image=6, seed=4)
+    losses, _ = model(x, targets, compute_masks=True)
+    (losses['det']['det_loss'] + losses['det']['mask_loss']).backward()
+    out['train_det_loss'], out['train_mask_loss'] = npf(losses['det']['det_loss']), npf(losses['det']['mask_loss'])
+    params = dict(model.named_parameters())
+    names, sums = [], []
+    for k, p in params.items():
+        if p.grad is None:
+            continue
+        names.append(k)
+        g64 = p.grad.double()
+        sums.append([g64.sum().item(), g64.abs().sum().item(), g64.pow(2).sum().sqrt().item()])
+    out['gradsum_names'], out['gradsum'] = np.array(names), np.array(sums, dtype=np.float64)
+    for k in ('headers.det.seg_h.maskrcnn_preds.mask_fcn_logits.weight', 'headers.det.seg_h.maskrcnn_preds.mask_fcn_logits.bias',
+              'headers.det.seg_h.maskrcnn_heads.mask_fcn1.bias', 'headers.det.seg.0.bn.weight', 'headers.det.seg.2.bn.bias'):
+        out['grad:' + k] = npf(params[k].grad)
+    np.savez_compressed(os.path.join(HERE, 'masks.npz'), **out)
+    print('wrote masks.npz', 'mask_loss', out['train_mask_loss'], 'eval dets', [out[f'eval_{b}_boxes'].shape for b in range(2)],
+          'mask grad l2', float(out['gradsum'][names.index('headers.det.seg_h.maskrcnn_heads.mask_fcn1.weight'), 2]))
+
+
 def main():
     assert os.path.isdir(REF), 'the reference is only mounted in the build container'
     torch.set_num_threads(8)
@@ -409,6 +476,7 @@ def main():
     gen_train('s_128', 's', 8, 2, 128, 10, 30)
     gen_f3()
     gen_nms_options()
+    gen_masks()
 
 
 if __name__ == '__main__':

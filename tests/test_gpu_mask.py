@@ -7,7 +7,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from collections import OrderedDict
 
-from hd_yolo_amd import maskhead, ops
+from hd_yolo_amd import maskhead, ops, synth
 from oracle import mask_ref
 
 pytestmark = pytest.mark.gpu
@@ -86,3 +86,74 @@ def test_mask_head_forward_backward(dtype, tol):
     assert relmax(dx.permute(0, 3, 1, 2), xr.grad) < tol * 2
     for (name, p), q in zip(seg_h.named_parameters(), dev_h.parameters()):
         assert relmax(grads[id(q)], p.grad) < tol * 2, name
+
+
+# ------------------------------------------------------------------------------------------ whole model against the reference
+import os  # noqa: E402
+
+G = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'masks.npz'), allow_pickle=False)
+
+
+def _mask_model(hyp):
+    from metayolo.models.yolo import Model
+    cfg = synth.make_cfg('n', 2)
+    cfg['headers'][0][3][3] = 1                         # masks: every class uses mask channel 1 (+ the general channel 0)
+    m = Model(cfg, hyp)
+    missing = m.load_state_dict(synth.mask_state_dict(m), strict=False)
+    assert not missing.unexpected_keys
+    return m.to(DEV)
+
+
+def test_eval_masks_match_reference():
+    """Detections + 28 x 28 masks of yolov5n / masks=1 on 2 x 128^2 tiles (tests/golden/masks.npz: the reference's own
+    multiscale_roi_align / seg convs / score logic on the oracle's roi_align and Mask R-CNN head)."""
+    model = _mask_model(synth.make_hyp(conf_thres=0.05)).eval()
+    x = synth.synth_images(2, 128, seed=7).to(DEV)
+    with torch.no_grad():
+        _, outputs = model(x, compute_masks=True)
+        plan = next(iter(model._eng().plans.values()))
+        for l, f in enumerate(plan.mask_features()):
+            assert relmax(f.permute(0, 3, 1, 2), torch.from_numpy(G[f'eval_maskmap_{l}'])) < 1e-4
+    probs = torch.from_numpy(G['eval_mask_probs'])
+    off = 0
+    for b, o in enumerate(outputs):
+        o = o['det']
+        n = len(G[f'eval_{b}_boxes'])
+        np.testing.assert_allclose(o['boxes'].cpu().numpy(), G[f'eval_{b}_boxes'], rtol=1e-4, atol=1e-3)
+        assert np.array_equal(o['labels'].cpu().numpy(), G[f'eval_{b}_labels'])
+        labels = torch.from_numpy(G[f'eval_{b}_labels']).clamp(min=0)
+        want = probs[off:off + n][torch.arange(n), model.headers['det'].mask_indices.cpu()[labels]][:, None]
+        assert o['masks'].shape == (n, 1, 28, 28)
+        assert (o['masks'].cpu() - want).abs().max() < 2e-4
+        off += n
+    _, plain = model(x, compute_masks=False)
+    assert 'masks' not in plain[0]['det']
+
+
+def test_train_step_with_mask_loss_matches_reference():
+    """det + mask loss and every parameter gradient (3 numbers each) of one training step with anchor-shaped truths."""
+    model = _mask_model(synth.make_hyp()).train()
+    x = synth.synth_images(2, 128, seed=11).to(DEV)
+    targets = synth.synth_mask_targets(2, 128, 2, per_image=6, seed=4)
+    losses, _ = model(x, targets, compute_masks=True)
+    l = losses['det']
+    np.testing.assert_allclose(l['det_loss'].detach().cpu().numpy(), G['train_det_loss'], rtol=2e-4)
+    np.testing.assert_allclose(l['mask_loss'].detach().cpu().numpy(), G['train_mask_loss'], rtol=2e-4)
+    (l['det_loss'] + l['mask_loss']).backward()
+    params = dict(model.named_parameters())
+    worst = 0.0
+    for name, ref in zip(G['gradsum_names'].tolist(), G['gradsum']):
+        g = params[name].grad.double()
+        got = np.array([g.sum().item(), g.abs().sum().item(), g.pow(2).sum().sqrt().item()])
+        worst = max(worst, abs(got[2] - ref[2]) / (ref[2] + 1e-12))
+        # 5e-3: the mask path adds fp32-atomic scatter order and BatchNorm over as few as 32 samples per channel (2 tiles, 4x4 P5)
+        assert abs(got[2] - ref[2]) <= 5e-3 * ref[2] + 1e-7, (name, got, ref)
+        assert abs(got[1] - ref[1]) <= 5e-3 * ref[1] + 1e-6, (name, got, ref)
+    for k in [k for k in G.files if k.startswith('grad:')]:
+        assert relmax(params[k[5:]].grad, torch.from_numpy(G[k])) < 5e-3, k
+    # a step without mask loss leaves the mask branch's gradients at zero instead of stale
+    model.zero_grad(set_to_none=True)
+    losses, _ = model(x, targets, compute_masks=False)
+    losses['det']['det_loss'].backward()
+    assert float(params['headers.det.seg_h.maskrcnn_heads.mask_fcn1.weight'].grad.abs().sum()) == 0.0
+    assert float(params['headers.det.seg.0.conv.weight'].grad.abs().sum()) == 0.0
