@@ -10,8 +10,10 @@
 //   * and reads all 9 taps' A fragments out of that patch: L2->LDS traffic per 256 outputs drops from 440 KB to 41 KB;
 //   * runs 8 waves (2 per SIMD) so one wave's fragment reads / address VALU overlap the other's MFMAs.
 // Fragment addressing: lane row = output pixel (ty, tx) of the tile, tap (r, s) reads patch pixel (ty+r)*18 + tx+s; the
-// 16 lanes of a fragment read 16 consecutive patch pixels, and chunk ^ ((patch column>>1)&7) spreads them over all 16
-// 16-byte slots of the 256-byte bank row (conflict-free ds_read_b128).  LDS-DMA writes linearly, so that XOR is applied to the
+// 16 lanes of a fragment read 16 consecutive patch pixels, and chunk ^ (((patch column>>1)&3)<<1) spreads them over the 16
+// 16-byte slots of the 256-byte bank row.  ds_read_b128 is served in groups of 16 lanes that MIX two k-chunks (lanes 0-3, 12-15 of
+// chunk c with lanes 4-11 of chunk c+1): keying on bits 1-2 only leaves bit 0 to tell the two chunks apart, which is conflict-free
+// for every tap shift (the first key, (column>>1)&7, collided at odd shifts: 25 % of the LDS cycles were conflict cycles).  LDS-DMA writes linearly, so that XOR is applied to the
 // source address (rule: linear destination + permuted source + permuted read).
 // The MFMAs run with the FILTER as the row operand, so a lane's 4 accumulator values are 4 consecutive output channels of ONE
 // pixel: the epilogue packs them into one 8-byte LDS write (instead of four 2-byte scatters) and the BatchNorm sums stay in
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(NTHR) void conv3x3_c64_kernel(const ConvArgs p) {
         const int pos = tid + NTHR * i;
         const int pix = pos >> 3;
         const int py = pix / PW, px = pix - py * PW;
-        const int lcp = (tid & 7) ^ ((px >> 1) & 7);      // patch swizzle keys on the COLUMN (see the fragment reads)
+        const int lcp = (tid & 7) ^ (((px >> 1) & 3) << 1);   // patch swizzle keys on the COLUMN (see the fragment reads)
         prel[i] = (py * p.Win + px) * p.ldx + lcp * 8;
         pyx[i] = py | (px << 8);
     }
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(NTHR) void conv3x3_c64_kernel(const ConvArgs p) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int px = fr + s;
-            aoff[s][ks] = px * 128 + (((ks * 4 + fq) ^ ((px >> 1) & 7)) << 4);
+            aoff[s][ks] = px * 128 + (((ks * 4 + fq) ^ (((px >> 1) & 3) << 1)) << 4);
         }
 #pragma unroll
     for (int b = 0; b < 2; ++b)
