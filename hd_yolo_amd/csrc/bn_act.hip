@@ -284,8 +284,9 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restri
         float sc[VE], sh[VE], mu[VE], is[VE], k1[VE], k2[VE];
 #pragma unroll
         for (int i = 0; i < VE; ++i) {
-            sc[i] = scale[c + i]; sh[i] = shift[c + i]; mu[i] = mean[c + i]; is[i] = invstd[c + i];
-            k1[i] = c1[c + i]; k2[i] = c2[c + i];
+            sc[i] = scale[c + i]; sh[i] = shift[c + i];
+            mu[i] = mean ? mean[c + i] : 0.f; is[i] = invstd ? invstd[c + i] : 0.f;     // frozen statistics: no mean / variance terms
+            k1[i] = c1 ? c1[c + i] : 0.f; k2[i] = c2 ? c2[c + i] : 0.f;
         }
         for (int m = blockIdx.x * L.RL + L.rl; m < M; m += gridDim.x * L.RL) {
             float g[VE], v[VE];
@@ -407,7 +408,7 @@ int hdy_bn_act_bwd(const void* dz, int lddz, const void* y, int ldy, const float
                    const float* invstd, void* dy, int lddy, float* dgamma, float* dbeta, int accumulate, long long M, int K, int act,
                    int dtype, float* workspace, void* stream) {
     const int VE = dtype == HDY_BF16 ? 8 : 4;
-    HDY_ARG(dz && y && dy && scale && shift && mean && invstd && workspace && M_OK(M) && K > 0, "bn_act_bwd: bad args");
+    HDY_ARG(dz && y && dy && scale && shift && workspace && M_OK(M) && K > 0 && (!mean == !invstd), "bn_act_bwd: bad args");
     HDY_ARG(K % VE == 0 && VEC_OK(dz, lddz, VE) && VEC_OK(y, ldy, VE) && VEC_OK(dy, lddy, VE), "bn_act_bwd: K/pitch/alignment must be multiples of one 16-byte vector");
     const int nb = hdy_bn_bwd_blocks(M);
     const int rows = (int)((M + nb - 1) / nb);
@@ -415,6 +416,21 @@ int hdy_bn_act_bwd(const void* dz, int lddz, const void* y, int ldy, const float
     float* c1 = workspace + (size_t)nb * 2 * K;
     float* c2 = c1 + K;
     hipStream_t st = (hipStream_t)stream;
+    if (!mean) {
+        // frozen BatchNorm (torchvision FrozenBatchNorm2d after Model.freeze): z = act(y*scale + shift) with constant scale/shift,
+        // so dy = scale * dz * act'(u) and there is no statistics gradient: the apply pass alone
+        const int g2 = stream_grid(M, K / VE);
+        if (dtype == HDY_BF16)
+            hipLaunchKernelGGL(bn_act_bwd_apply_kernel<bf16_t>, dim3(g2), dim3(256), 0, st, (const bf16_t*)dz, lddz, (const bf16_t*)y, ldy, scale,
+                               shift, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (bf16_t*)dy, lddy,
+                               (int)M, K, act);
+        else
+            hipLaunchKernelGGL(bn_act_bwd_apply_kernel<float>, dim3(g2), dim3(256), 0, st, (const float*)dz, lddz, (const float*)y, ldy, scale,
+                               shift, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)dy, lddy,
+                               (int)M, K, act);
+        HDY_LAUNCH_CHECK("bn_act_bwd_apply(frozen)");
+        return HDY_OK;
+    }
     dim3 grid(nb, cdiv(K / VE, 256));
     if (dtype == HDY_BF16)
         hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dz, lddz, (const bf16_t*)y, ldy, scale,

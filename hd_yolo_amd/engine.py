@@ -172,7 +172,8 @@ class Engine:
     def _signature(self):
         b, n, h = self.parts
         fused = tuple(hasattr(m, 'bn') for part in (b, n) if part is not None for m in part.modules() if type(m).__name__ == 'Conv')
-        return hash(fused)
+        # requires_grad flags select which backward launches a training plan contains (Model.freeze)
+        return hash((fused, tuple(p.requires_grad for p in self._params())))
 
     def _check_parameters(self):
         """Plans and the flat gradient store hold the parameter OBJECTS they were traced with: when a caller swaps some (e.g.

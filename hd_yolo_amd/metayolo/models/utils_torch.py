@@ -64,9 +64,45 @@ def freeze_params(model, layers=()):
     return model
 
 
+class FrozenBatchNorm2d(nn.Module):
+    """BatchNorm2d with fixed statistics and affine parameters (all four are buffers) — what the reference takes from
+    torchvision.ops.FrozenBatchNorm2d (utils_torch.py:192).  It only holds state here: inside a launch plan it becomes a constant
+    per-channel scale / shift in training as well as in eval (hd_yolo_amd/plan.py)."""
+
+    def __init__(self, num_features, eps=1e-5):
+        super().__init__()
+        self.eps = eps
+        self.register_buffer('weight', torch.ones(num_features))
+        self.register_buffer('bias', torch.zeros(num_features))
+        self.register_buffer('running_mean', torch.zeros(num_features))
+        self.register_buffer('running_var', torch.ones(num_features))
+
+    def _load_from_state_dict(self, state_dict, prefix, *args):
+        state_dict.pop(prefix + 'num_batches_tracked', None)
+        super()._load_from_state_dict(state_dict, prefix, *args)
+
+    def forward(self, x):
+        raise RuntimeError('FrozenBatchNorm2d runs inside the HIP plan of its Conv block')
+
+
 def freeze_bn(model, layers=()):
-    if layers:
-        raise NotImplementedError('frozen BatchNorm statistics are outside the hot path of this build')
+    """Replace every nn.BatchNorm2d under the named layers by a FrozenBatchNorm2d with the same statistics (reference :180-203);
+    the launch plans are rebuilt on the next forward."""
+    if not layers:
+        return model
+    swap = {}
+    for k, m in model.named_modules():
+        if isinstance(m, nn.BatchNorm2d) and any(k == name or k.startswith(name + '.') for name in layers):
+            f = FrozenBatchNorm2d(m.num_features, m.eps).to(m.weight.device)
+            f.load_state_dict(m.state_dict())
+            swap[k] = f
+    for k, f in swap.items():
+        parent = model
+        *path, leaf = k.split('.')
+        for a in path:
+            parent = getattr(parent, a)
+        LOGGER.info(f'Replace layer: {k} with FrozenBatchNorm2d')
+        setattr(parent, leaf, f)
     return model
 
 

@@ -33,7 +33,7 @@ DY_RING = int(os.environ.get('HDY_DY_RING', '4'))
 class Val:
     """A tensor of the traced graph: logical NHWC shape + where it lives (buffer, channel offset)."""
     __slots__ = ('n', 'h', 'w', 'c', 'name', 'buf', 'off', 'cat', 'parts', 'gbuf', 'goff', 'ginit', 'galias', 'gfinal',
-                 'order', 'last_use', 'index')
+                 'order', 'last_use', 'index', 'needs_grad')
 
     def __init__(self, n, h, w, c, name, order):
         self.n, self.h, self.w, self.c, self.name, self.order = n, h, w, c, name, order
@@ -43,6 +43,7 @@ class Val:
         self.ginit = False
         self.last_use = order
         self.index = None          # model-level node index, when this is a layer output
+        self.needs_grad = True     # False: nothing trainable upstream (Model.freeze): no gradient is propagated into it
 
     def t(self):
         return self.buf[..., self.off:self.off + self.c]
@@ -63,6 +64,9 @@ class ConvUnit:
         self.K = sum(self.Ks)
         self.C = c.in_channels
         self.has_bn = hasattr(mods[0], 'bn')
+        # torchvision-style FrozenBatchNorm2d put in place by Model.freeze (utils_torch.freeze_bn): constant scale / shift in training too
+        self.frozen = self.has_bn and type(mods[0].bn).__name__ == 'FrozenBatchNorm2d'
+        assert all((hasattr(m, 'bn') and type(m.bn).__name__ == 'FrozenBatchNorm2d') == self.frozen for m in mods)
         self.act = act_code(mods[0].act)
 
 
@@ -181,7 +185,8 @@ class Plan:
             h = self._conv([m.cv1], x)[0]
             return self._conv([m.cv2], h, res=x if m.add else None)[0]
         if t == 'C3':
-            fuse = self.training and hasattr(m.cv1, 'bn') and hasattr(m.cv2, 'bn')
+            fuse = (self.training and hasattr(m.cv1, 'bn') and hasattr(m.cv2, 'bn') and type(m.cv1.bn) is type(m.cv2.bn)
+                    and m.cv1.conv.weight.requires_grad == m.cv2.conv.weight.requires_grad)
             if fuse:
                 a, b = self._conv([m.cv1, m.cv2], x)
             else:
@@ -303,9 +308,13 @@ class Plan:
                     if not u.has_bn:
                         raise _lib.HdyError('training a fused (BN-folded) model is not supported: build the model unfused')
                     u.yraw = self._new(o.n, o.h, o.w, u.K)
-                    u.mean, u.invstd = self._new(u.K, dtype=f32), self._new(u.K, dtype=f32)
                     hin, win = (self.H, self.W) if u.stem else (u.x.h, u.x.w)
-                    u.mtiles = ops.stat_slabs(o.n, hin, win, u.C, u.K, u.k, u.k, u.s, u.p, dt)
+                    if u.frozen:
+                        u.mean = u.invstd = None
+                        u.mtiles = 0
+                    else:
+                        u.mean, u.invstd = self._new(u.K, dtype=f32), self._new(u.K, dtype=f32)
+                        u.mtiles = ops.stat_slabs(o.n, hin, win, u.C, u.K, u.k, u.k, u.s, u.p, dt)
                     max_stats = max(max_stats, u.mtiles * 2 * u.K)
                     max_dy = max(max_dy, M * u.K)
                     max_wg = max(max_wg, ops.wgrad_ws_bytes(o.n, hin, win, u.C, u.K, u.k, u.k, u.s, u.p, dt, stem=u.stem))
@@ -387,14 +396,17 @@ class Plan:
                     wb = u.mods[1].conv.weight if len(u.mods) > 1 else None
                     self.packs.add(u.mods[0].conv.weight, wb, u.s, u.p, kind, u.wp)
                     M = o0.n * o0.h * o0.w
-                    stats = self.stats[:u.mtiles * 2 * u.K].view(u.mtiles, 2, u.K)
+                    stats = None if u.frozen else self.stats[:u.mtiles * 2 * u.K].view(u.mtiles, 2, u.K)
                     recs.append(ops.rec_conv_fwd(x, u.wp, u.yraw, u.K, u.k, u.k, u.s, u.p, stats=stats, stem_hw=stem_hw))
                     k0 = 0
                     for m, o in zip(u.mods, u.outs):
                         K = m.conv.out_channels
                         g, b, rm, rv = self._bn(m)
-                        recs.append(ops.rec_bn_finalize(stats[:, :, k0:], u.mtiles, K, M, g, b, rm, rv, u.scale[k0:], u.shift[k0:],
-                                                        u.mean[k0:], u.invstd[k0:], stats_ld=u.K, ws=self.fin_ws))
+                        if u.frozen:
+                            recs.append(ops.rec_bn_eval_coeffs(g, b, rm, rv, u.scale[k0:k0 + K], u.shift[k0:k0 + K], eps=m.bn.eps))
+                        else:
+                            recs.append(ops.rec_bn_finalize(stats[:, :, k0:], u.mtiles, K, M, g, b, rm, rv, u.scale[k0:], u.shift[k0:],
+                                                            u.mean[k0:], u.invstd[k0:], stats_ld=u.K, ws=self.fin_ws))
                         res = u.res.t() if u.res is not None else None
                         recs.append(ops.rec_bn_act_fwd(u.yraw[..., k0:k0 + K], u.scale[k0:k0 + K], u.shift[k0:k0 + K], o.t(), res=res, act=u.act))
                         k0 += K
@@ -403,7 +415,7 @@ class Plan:
                     self.packs.add(m.conv.weight, None, u.s, u.p, kind, u.wp)
                     if u.has_bn:
                         g, b, rm, rv = self._bn(m)
-                        recs.append(ops.rec_bn_eval_coeffs(g, b, rm, rv, u.scale, u.shift))
+                        recs.append(ops.rec_bn_eval_coeffs(g, b, rm, rv, u.scale, u.shift, eps=m.bn.eps))
                         scale, shift = u.scale, u.shift
                     else:
                         scale, shift = None, m.conv.bias
@@ -436,7 +448,7 @@ class Plan:
         g.replay()
 
     def bn_counters(self):
-        return [m.bn.num_batches_tracked for u in self.units if isinstance(u, ConvUnit) and u.has_bn for m in u.mods]
+        return [m.bn.num_batches_tracked for u in self.units if isinstance(u, ConvUnit) and u.has_bn and not u.frozen for m in u.mods]
 
     def run_forward_features(self, feats):
         """Feature-input plan: feats {layer index: NCHW tensor} -> det logits views (empty without a head)."""
@@ -515,22 +527,62 @@ class Plan:
 
         slot_user = {}
         nconv = 0
+
+        # Model.freeze: a tensor needs a gradient only if something trainable lies upstream of it; units without trainable
+        # parameters below frozen inputs are skipped altogether, frozen filters skip their weight gradient
+        def trainable(u):
+            if isinstance(u, DetUnit):
+                return u.conv.weight.requires_grad or u.conv.bias.requires_grad
+            ps = [m.conv.weight for m in u.mods]
+            if u.has_bn and not u.frozen:
+                ps += [q for m in u.mods for q in (m.bn.weight, m.bn.bias)]
+            return any(q.requires_grad for q in ps)
+
+        if self.input is not None:
+            self.input.needs_grad = False
+        for v in self.ext.values():
+            v.needs_grad = False
+
+        def up(v):                                   # needs_grad of a (possibly concatenated) input value
+            if v is None:
+                return False
+            if v.parts is not None:
+                v.needs_grad = any(pv.needs_grad for pv, _ in v.parts)
+            return v.needs_grad
+
+        for u in self.units:
+            if isinstance(u, ConvUnit):
+                ng = trainable(u) or up(u.x) or up(u.res)
+                for o in u.outs:
+                    o.needs_grad = ng
+            elif isinstance(u, PoolUnit):
+                for o in u.outs:
+                    o.needs_grad = up(u.x)
+            elif isinstance(u, UpUnit):
+                u.out.needs_grad = up(u.x)
         for u in reversed(self.units):
             if isinstance(u, DetUnit):
                 x = u.x
                 gw, gb = self._grad_views(u.conv.weight), self._grad_views(u.conv.bias)
                 recs.append(ops.rec_colsum(u.gdet, self._det_bias_tmp(u), self.bn_ws))
                 wgrad(ops.rec_conv_wgrad(x.t(), u.gdet, gw, None, 1, 1, 1, 0, self.wg_ws))
+                u.gb = gb
+                if not up(x):
+                    continue
                 self.packs.add(u.conv.weight, None, 1, 0, ops.PACK_DGRAD, u.wpd, K=u.Kp)
                 recs.append(ops.rec_conv_dgrad(u.gdet, u.wpd, x.g(), 1, 1, 1, 0, accumulate=self._contrib(x)))
-                u.gb = gb
             elif isinstance(u, UpUnit):
-                recs.append(ops.rec_upsample_bwd(u.out.gread(), u.x.g(), accumulate=self._contrib(u.x)))
+                if up(u.x):
+                    recs.append(ops.rec_upsample_bwd(u.out.gread(), u.x.g(), accumulate=self._contrib(u.x)))
             elif isinstance(u, PoolUnit):
                 a = u.x
+                if not up(a):
+                    continue
                 gs = [a.g()] + [o.g() for o in u.outs]
                 recs.append(ops.rec_sppf_pool_bwd(gs[0], gs[1], gs[2], gs[3], u.idx, a.gfinal))
             elif isinstance(u, ConvUnit):
+                if not u.outs[0].needs_grad:
+                    continue
                 o0 = u.outs[0]
                 slot = nconv % len(self.dy_ring)
                 nconv += 1
@@ -540,16 +592,21 @@ class Plan:
                 k0 = 0
                 for m, o in zip(u.mods, u.outs):
                     K = m.conv.out_channels
-                    recs.append(ops.rec_bn_act_bwd(o.gread(), u.yraw[..., k0:k0 + K], u.scale[k0:k0 + K], u.shift[k0:k0 + K], u.mean[k0:k0 + K],
-                                                   u.invstd[k0:k0 + K], dy[..., k0:k0 + K], self._grad_views(m.bn.weight),
-                                                   self._grad_views(m.bn.bias), self.bn_ws, act=u.act))
+                    if u.frozen:
+                        recs.append(ops.rec_bn_act_bwd(o.gread(), u.yraw[..., k0:k0 + K], u.scale[k0:k0 + K], u.shift[k0:k0 + K], None, None,
+                                                       dy[..., k0:k0 + K], None, None, self.bn_ws, act=u.act))
+                    else:
+                        recs.append(ops.rec_bn_act_bwd(o.gread(), u.yraw[..., k0:k0 + K], u.scale[k0:k0 + K], u.shift[k0:k0 + K],
+                                                       u.mean[k0:k0 + K], u.invstd[k0:k0 + K], dy[..., k0:k0 + K],
+                                                       self._grad_views(m.bn.weight), self._grad_views(m.bn.bias), self.bn_ws, act=u.act))
                     k0 += K
                 x = self.prep if u.stem else u.x.t()
                 stem_hw = (self.H, self.W) if u.stem else None
                 ga = self._grad_views(u.mods[0].conv.weight)
                 gb = self._grad_views(u.mods[1].conv.weight) if len(u.mods) > 1 else None
-                wgrad(ops.rec_conv_wgrad(x, dy, ga, gb, u.k, u.k, u.s, u.p, self.wg_ws, stem_hw=stem_hw), reads_dy_slot=slot)
-                if not u.stem and u.x is not self.input:
+                if any(m.conv.weight.requires_grad for m in u.mods):
+                    wgrad(ops.rec_conv_wgrad(x, dy, ga, gb, u.k, u.k, u.s, u.p, self.wg_ws, stem_hw=stem_hw), reads_dy_slot=slot)
+                if not u.stem and u.x is not self.input and up(u.x):
                     wb = u.mods[1].conv.weight if len(u.mods) > 1 else None
                     self.packs.add(u.mods[0].conv.weight, wb, u.s, u.p, ops.PACK_DGRAD, u.wpd)
                     xv = u.x

@@ -109,6 +109,8 @@ int hdy_bn_act_fwd(const void* y, int ldy, const float* scale, const float* shif
                    long long M, int K, int act, int dtype, void* stream);
 int hdy_bn_bwd_blocks(long long M);
 /* workspace: (hdy_bn_bwd_blocks(M) * 2 * K + 2 * K) floats */
+/* mean == invstd == NULL: frozen statistics (FrozenBatchNorm2d, metayolo/models/utils_torch.py:180-203): dy = scale * dz * act'(u),
+ * dgamma / dbeta untouched. */
 int hdy_bn_act_bwd(const void* dz, int lddz, const void* y, int ldy, const float* scale, const float* shift, const float* mean,
                    const float* invstd, void* dy, int lddy, float* dgamma, float* dbeta, int accumulate, long long M, int K, int act,
                    int dtype, float* workspace, void* stream);

@@ -118,8 +118,10 @@ class RefNet:
         self.shapes[p + '.bn.running_var'] = ((c2,), torch.float32)
 
     # ------------------------------------------------------------------ blocks
-    @staticmethod
-    def conv_bn_silu(sd, p, x, s, pad, training):
+    def conv_bn_silu(self, sd, p, x, s, pad, training):
+        # Model.freeze(layers): BatchNorm under a frozen prefix is a FrozenBatchNorm2d = the eval formula, in training too
+        # (metayolo/models/utils_torch.py:180-203)
+        training = training and not any(p == f or p.startswith(f + '.') for f in getattr(self, 'frozen', ()))
         y = F.conv2d(x, sd[p + '.conv.weight'], None, stride=s, padding=pad)
         y = F.batch_norm(y, sd[p + '.bn.running_mean'], sd[p + '.bn.running_var'], sd[p + '.bn.weight'],
                          sd[p + '.bn.bias'], training=training, momentum=BN_MOM, eps=BN_EPS)

@@ -180,6 +180,45 @@ def test_train_step_matches_reference_golden_fp32(golden_dir, tag, variant, fuse
     assert relmax(g2 - g1, g1) < 0.5 and (g2 - g1).abs().max() > 0      # second step has different BN statistics: not 2x, but added
 
 
+def test_freeze_backbone_matches_oracle():
+    """Model.freeze(['backbone']) (reference: yolo.py:103-107, utils_torch.py:163-203): frozen parameters get no gradient, their
+    BatchNorms use (and keep) the running statistics in training mode, nothing is back-propagated below the first trainable
+    layer; the trainable neck / head gradients and the loss follow the oracle with the same layers frozen."""
+    from oracle.ref_net import RefNet
+    nc, B, S = 2, 2, 64
+    cfg, hyp = synth.make_cfg('n', nc), synth.make_hyp()
+    model = build('n', nc)
+    model.freeze(['backbone', 'neck.0'])
+    model.train()
+    assert type(model.backbone[0].bn).__name__ == 'FrozenBatchNorm2d' and 'backbone.0.bn.num_batches_tracked' not in model.state_dict()
+    assert not model.backbone[2].cv1.conv.weight.requires_grad and model.neck[3].cv1.conv.weight.requires_grad
+    net = RefNet(cfg, hyp)
+    net.frozen = ('backbone', 'neck.0')
+    sd = net.init_state()
+    train_keys = [k for k in sd if 'running' not in k and not k.startswith('backbone.') and not k.startswith('neck.0.')]
+    for k in train_keys:
+        sd[k].requires_grad_(True)
+    x = synth.synth_images(B, S, seed=11)
+    targets = synth.synth_targets(B, S, nc, nmin=3, nmax=8, seed=5)
+    rm0 = sd['backbone.1.bn.running_mean'].clone()
+    loss_c, _, _ = net.train_forward(sd, x, synth.synth_targets(B, S, nc, nmin=3, nmax=8, seed=5))
+    loss_c.backward()
+    assert torch.equal(sd['backbone.1.bn.running_mean'], rm0)
+    losses, _ = model(x.to(DEV), targets)
+    losses['det']['det_loss'].backward()
+    assert abs(float(losses['det']['det_loss']) - float(loss_c)) < 2e-4 * abs(float(loss_c))
+    params = dict(model.named_parameters())
+    assert all(p.grad is None for k, p in params.items() if k.startswith('backbone.') or k.startswith('neck.0.'))
+    assert relmax(model.state_dict()['backbone.1.bn.running_mean'], rm0) < 1e-6
+    worst = max(relmax(params[k].grad, sd[k].grad) for k in train_keys)
+    assert worst < 2e-3, worst
+    # the backward list of the frozen part is gone: no weight gradient / dgrad launches for backbone layers
+    plan = next(p for p in model._eng().plans.values() if p.training)
+    n_wgrad = sum(1 for r in plan.bwd if r[0] == '@fork')
+    n_conv = sum(1 for u in plan.units if type(u).__name__ in ('ConvUnit', 'DetUnit'))
+    assert n_wgrad < n_conv - 20
+
+
 def test_three_sgd_steps_track_the_oracle():
     """fwd + bwd + SGD(nesterov) x3 in fp32: the loss trajectory and the updated weights follow the CPU oracle."""
     from oracle.ref_net import RefNet
