@@ -4,8 +4,8 @@
 // output (M, M), spatial_scale = 1/stride, sampling_ratio = 2, aligned = ROI_ALIGN = False): per output bin the average of
 // sampling_ratio^2 bilinear samples; a sample outside [-1, size] contributes 0, coordinates are clamped to >= 0, and the last
 // row/column interpolates with itself.  Output is NHWC [R][P][P][C] so the head's convolutions consume it directly.
-// HBM-bound gathers / scatters: one lane per (roi, bin, 8- or 4-channel vector).  The backward scatters with fp32 atomics into
-// an fp32 image (bf16 has no atomic add and several rois overlap); hdy_cast_store then writes the plan's gradient buffer.
+// Forward: an HBM-bound gather, one lane per (roi, bin, 8- or 4-channel vector).  The backward accumulates into an fp32 image
+// (bf16 has no atomic add and rois overlap), privatised per roi in LDS; hdy_cast_store then writes the plan's gradient buffer.
 #include "common.h"
 #include "hdyolo.h"
 
@@ -71,10 +71,9 @@ __device__ __forceinline__ RoiGeom roi_geom(const float* roi, float scale, int P
     return g;
 }
 
-template <typename T, bool BWD>
-__global__ __launch_bounds__(256) void roi_align_kernel(const T* __restrict__ feat, float* __restrict__ dfeat, int ldf, int B, int H, int W, int C,
-                                                        const float* __restrict__ rois, int R, float scale, int P, int S, int aligned,
-                                                        T* __restrict__ out, const T* __restrict__ dout) {
+template <typename T>
+__global__ __launch_bounds__(256) void roi_align_kernel(const T* __restrict__ feat, int ldf, int B, int H, int W, int C, const float* __restrict__ rois,
+                                                        int R, float scale, int P, int S, int aligned, T* __restrict__ out) {
     constexpr int VE = RT<T>::VE;
     const int VC = C / VE;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -86,57 +85,93 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const T* __restrict__ fe
     const int ph = (int)(t % P);
     const int r = (int)(t / P);
     const RoiGeom g = roi_geom(rois + (size_t)r * 5, scale, P, aligned);
-    if (g.b < 0 || g.b >= B) {
-        if (!BWD) {
-            float z[VE];
-#pragma unroll
-            for (int i = 0; i < VE; ++i) z[i] = 0.f;
-            st_vec<T>(out + (((size_t)r * P + ph) * P + pw) * C + vc * VE, z);
-        }
-        return;
-    }
-    const float inv = 1.0f / (float)(S * S);
     float acc[VE];
-    if (BWD) {
-        ld_vec<T>(dout + (((size_t)r * P + ph) * P + pw) * C + vc * VE, acc);
 #pragma unroll
-        for (int i = 0; i < VE; ++i) acc[i] *= inv;
-    } else {
-#pragma unroll
-        for (int i = 0; i < VE; ++i) acc[i] = 0.f;
-    }
-    for (int iy = 0; iy < S; ++iy) {
-        const float y = g.y0 + (float)ph * g.bin_h + ((float)iy + 0.5f) * g.bin_h / (float)S;
-        for (int ix = 0; ix < S; ++ix) {
-            const float x = g.x0 + (float)pw * g.bin_w + ((float)ix + 0.5f) * g.bin_w / (float)S;
-            const Sample s = sample_at(y, x, H, W);
-            if (!s.ok) continue;
-            const size_t base = (size_t)g.b * H * W;
-            const size_t o00 = (base + (size_t)s.y0 * W + s.x0) * ldf + vc * VE, o01 = (base + (size_t)s.y0 * W + s.x1) * ldf + vc * VE;
-            const size_t o10 = (base + (size_t)s.y1 * W + s.x0) * ldf + vc * VE, o11 = (base + (size_t)s.y1 * W + s.x1) * ldf + vc * VE;
-            if (BWD) {
-#pragma unroll
-                for (int i = 0; i < VE; ++i) {
-                    atomicAdd(dfeat + o00 + i, acc[i] * s.w00);
-                    atomicAdd(dfeat + o01 + i, acc[i] * s.w01);
-                    atomicAdd(dfeat + o10 + i, acc[i] * s.w10);
-                    atomicAdd(dfeat + o11 + i, acc[i] * s.w11);
-                }
-            } else {
+    for (int i = 0; i < VE; ++i) acc[i] = 0.f;
+    if (g.b >= 0 && g.b < B) {
+        for (int iy = 0; iy < S; ++iy) {
+            const float y = g.y0 + (float)ph * g.bin_h + ((float)iy + 0.5f) * g.bin_h / (float)S;
+            for (int ix = 0; ix < S; ++ix) {
+                const float x = g.x0 + (float)pw * g.bin_w + ((float)ix + 0.5f) * g.bin_w / (float)S;
+                const Sample s = sample_at(y, x, H, W);
+                if (!s.ok) continue;
+                const size_t base = (size_t)g.b * H * W;
                 float a[VE], b[VE], c[VE], d[VE];
-                ld_vec<T>(feat + o00, a);
-                ld_vec<T>(feat + o01, b);
-                ld_vec<T>(feat + o10, c);
-                ld_vec<T>(feat + o11, d);
+                ld_vec<T>(feat + (base + (size_t)s.y0 * W + s.x0) * ldf + vc * VE, a);
+                ld_vec<T>(feat + (base + (size_t)s.y0 * W + s.x1) * ldf + vc * VE, b);
+                ld_vec<T>(feat + (base + (size_t)s.y1 * W + s.x0) * ldf + vc * VE, c);
+                ld_vec<T>(feat + (base + (size_t)s.y1 * W + s.x1) * ldf + vc * VE, d);
 #pragma unroll
                 for (int i = 0; i < VE; ++i) acc[i] += s.w00 * a[i] + s.w01 * b[i] + s.w10 * c[i] + s.w11 * d[i];
             }
         }
-    }
-    if (!BWD) {
+        const float inv = 1.0f / (float)(S * S);
 #pragma unroll
         for (int i = 0; i < VE; ++i) acc[i] *= inv;
-        st_vec<T>(out + (((size_t)r * P + ph) * P + pw) * C + vc * VE, acc);
+    }
+    st_vec<T>(out + (((size_t)r * P + ph) * P + pw) * C + vc * VE, acc);
+}
+
+// Backward with the scatter privatised per roi: one workgroup per (roi, 32-channel block) accumulates the roi's 14 x 14 x S^2
+// samples into an LDS image of the roi's footprint on the feature map (LDS atomics) and only then adds the footprint to the fp32
+// gradient image — one global atomic per footprint pixel and channel instead of 16 per bin and channel.  The matched truths of a
+// nuclei tile are a few feature pixels wide, so ~200 bins fall onto a handful of pixels: the direct scatter spent 8 ms per call
+// serialising on them.  Rois whose footprint exceeds the LDS tile scatter directly (they are large, hence uncontended).
+constexpr int FT = 24;                   // footprint tile side (feature pixels)
+constexpr int CB = 32;                   // channels per workgroup
+
+template <typename T>
+__global__ __launch_bounds__(256) void roi_align_bwd_tiled_kernel(float* __restrict__ dfeat, int B, int H, int W, int C, const float* __restrict__ rois,
+                                                                  float scale, int P, int S, int aligned, const T* __restrict__ dout) {
+    __shared__ float tile[FT * FT * CB];
+    const int r = blockIdx.x, c0 = blockIdx.y * CB;
+    const int cl = threadIdx.x & (CB - 1), bl = threadIdx.x / CB;      // channel lane, bin lane (8 bins in flight)
+    const RoiGeom g = roi_geom(rois + (size_t)r * 5, scale, P, aligned);
+    if (g.b < 0 || g.b >= B) return;
+    // footprint of all samples (after the clamp of sample_at): rows [fy0, fy1], columns [fx0, fx1]
+    const float ylo = g.y0 + 0.5f * g.bin_h / (float)S, yhi = g.y0 + ((float)P - 0.5f / (float)S) * g.bin_h;
+    const float xlo = g.x0 + 0.5f * g.bin_w / (float)S, xhi = g.x0 + ((float)P - 0.5f / (float)S) * g.bin_w;
+    const int fy0 = min(max((int)floorf(fmaxf(ylo, 0.f)), 0), H - 1), fy1 = min(max((int)floorf(fmaxf(yhi, 0.f)) + 1, 0), H - 1);
+    const int fx0 = min(max((int)floorf(fmaxf(xlo, 0.f)), 0), W - 1), fx1 = min(max((int)floorf(fmaxf(xhi, 0.f)) + 1, 0), W - 1);
+    const int fh = fy1 - fy0 + 1, fw = fx1 - fx0 + 1;
+    const bool tiled = fh <= FT && fw <= FT;
+    if (tiled) {
+        for (int i = threadIdx.x; i < fh * fw * CB; i += 256) tile[i] = 0.f;
+        __syncthreads();
+    }
+    const float inv = 1.0f / (float)(S * S);
+    const bool ch_ok = c0 + cl < C;
+    for (int bin = bl; bin < P * P; bin += 256 / CB) {
+        const int ph = bin / P, pw = bin - ph * P;
+        const float d = ch_ok ? (float)dout[(((size_t)r * P + ph) * P + pw) * C + c0 + cl] * inv : 0.f;
+        for (int iy = 0; iy < S; ++iy) {
+            const float y = g.y0 + (float)ph * g.bin_h + ((float)iy + 0.5f) * g.bin_h / (float)S;
+            for (int ix = 0; ix < S; ++ix) {
+                const float x = g.x0 + (float)pw * g.bin_w + ((float)ix + 0.5f) * g.bin_w / (float)S;
+                const Sample s = sample_at(y, x, H, W);
+                if (!s.ok || !ch_ok) continue;
+                if (tiled) {
+                    atomicAdd(&tile[((s.y0 - fy0) * fw + (s.x0 - fx0)) * CB + cl], d * s.w00);
+                    atomicAdd(&tile[((s.y0 - fy0) * fw + (s.x1 - fx0)) * CB + cl], d * s.w01);
+                    atomicAdd(&tile[((s.y1 - fy0) * fw + (s.x0 - fx0)) * CB + cl], d * s.w10);
+                    atomicAdd(&tile[((s.y1 - fy0) * fw + (s.x1 - fx0)) * CB + cl], d * s.w11);
+                } else {
+                    const size_t base = (size_t)g.b * H * W;
+                    atomicAdd(dfeat + (base + (size_t)s.y0 * W + s.x0) * C + c0 + cl, d * s.w00);
+                    atomicAdd(dfeat + (base + (size_t)s.y0 * W + s.x1) * C + c0 + cl, d * s.w01);
+                    atomicAdd(dfeat + (base + (size_t)s.y1 * W + s.x0) * C + c0 + cl, d * s.w10);
+                    atomicAdd(dfeat + (base + (size_t)s.y1 * W + s.x1) * C + c0 + cl, d * s.w11);
+                }
+            }
+        }
+    }
+    if (!tiled) return;
+    __syncthreads();
+    for (int i = threadIdx.x; i < fh * fw * CB; i += 256) {
+        const int c = i & (CB - 1), px = i / CB;
+        const int fy = px / fw, fx = px - fy * fw;
+        const float v = tile[i];
+        if (v != 0.f && c0 + c < C) atomicAdd(dfeat + (((size_t)g.b * H + fy0 + fy) * W + fx0 + fx) * C + c0 + c, v);
     }
 }
 
@@ -183,11 +218,11 @@ int hdy_roi_align_fwd(const void* feat, int ldf, int B, int H, int W, int C, con
     const long long n = (long long)R * P * P * (C / VE);
     const int grid = (int)((n + 255) / 256);
     if (dtype == HDY_BF16)
-        hipLaunchKernelGGL((roi_align_kernel<bf16_t, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)feat, (float*)nullptr, ldf, B,
-                           H, W, C, rois, R, spatial_scale, P, sampling_ratio, aligned, (bf16_t*)out, (const bf16_t*)nullptr);
+        hipLaunchKernelGGL(roi_align_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)feat, ldf, B, H, W, C, rois, R,
+                           spatial_scale, P, sampling_ratio, aligned, (bf16_t*)out);
     else
-        hipLaunchKernelGGL((roi_align_kernel<float, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)feat, (float*)nullptr, ldf, B,
-                           H, W, C, rois, R, spatial_scale, P, sampling_ratio, aligned, (float*)out, (const float*)nullptr);
+        hipLaunchKernelGGL(roi_align_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)feat, ldf, B, H, W, C, rois, R,
+                           spatial_scale, P, sampling_ratio, aligned, (float*)out);
     HDY_LAUNCH_CHECK("roi_align_fwd");
     return HDY_OK;
 }
@@ -198,14 +233,13 @@ int hdy_roi_align_bwd(const void* dout, float* dfeat_f32, int B, int H, int W, i
     if (R == 0) return HDY_OK;
     const int VE = dtype == HDY_BF16 ? 8 : 4;
     HDY_ARG(dout && rois && dfeat_f32 && C % VE == 0 && (((uintptr_t)dout) & 15) == 0, "roi_align_bwd: pointers / channel vectors");
-    const long long n = (long long)R * P * P * (C / VE);
-    const int grid = (int)((n + 255) / 256);
+    const dim3 grid(R, (C + CB - 1) / CB);
     if (dtype == HDY_BF16)
-        hipLaunchKernelGGL((roi_align_kernel<bf16_t, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)nullptr, dfeat_f32, C, B, H, W,
-                           C, rois, R, spatial_scale, P, sampling_ratio, aligned, (bf16_t*)nullptr, (const bf16_t*)dout);
+        hipLaunchKernelGGL(roi_align_bwd_tiled_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, dfeat_f32, B, H, W, C, rois, spatial_scale, P,
+                           sampling_ratio, aligned, (const bf16_t*)dout);
     else
-        hipLaunchKernelGGL((roi_align_kernel<float, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr, dfeat_f32, C, B, H, W, C,
-                           rois, R, spatial_scale, P, sampling_ratio, aligned, (float*)nullptr, (const float*)dout);
+        hipLaunchKernelGGL(roi_align_bwd_tiled_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, dfeat_f32, B, H, W, C, rois, spatial_scale, P,
+                           sampling_ratio, aligned, (const float*)dout);
     HDY_LAUNCH_CHECK("roi_align_bwd");
     return HDY_OK;
 }
