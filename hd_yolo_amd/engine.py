@@ -73,6 +73,21 @@ class _PlanFn(torch.autograd.Function):
         return None, None, None, None
 
 
+class _FusedLossMaskFn(torch.autograd.Function):
+    """_FusedLossFn for a model with a mask branch: also returns the ordering token (see _PlanMaskFn)."""
+
+    @staticmethod
+    def forward(ctx, engine, plan, hook, loss_view):
+        ctx.engine, ctx.plan = engine, plan
+        return loss_view.clone(), torch.zeros(1, device=loss_view.device)
+
+    @staticmethod
+    def backward(ctx, g, _token_grad):
+        ctx.plan.run_backward(None, scale=g)
+        ctx.engine.after_backward()
+        return None, None, None, None
+
+
 class _PlanMaskFn(torch.autograd.Function):
     """_PlanFn for a model with a mask branch: besides the logits it returns a 1-element token that the mask branch's autograd
     node consumes, so that autograd runs the branch's backward (which fills the plan's mask-feature gradients) before this one."""
@@ -236,7 +251,11 @@ class Engine:
         plan = self.plan_for(x, True, dtype)
         plan.run_forward(x)
         plan.fused_loss(head)(gts, tcls)
-        loss = _FusedLossFn.apply(self, plan, self.hook, plan.loss_out[0:1])
+        self.mask_token = None
+        if plan.mask_vals:
+            loss, self.mask_token = _FusedLossMaskFn.apply(self, plan, self.hook, plan.loss_out[0:1])
+        else:
+            loss = _FusedLossFn.apply(self, plan, self.hook, plan.loss_out[0:1])
         return plan, loss, plan.loss_out[1:4].clone()
 
     def after_backward(self):

@@ -77,7 +77,7 @@ class Model(nn.Module):
             if header.fused_loss_ok() and all(task_id in t['anns'] and len(t['anns'][task_id]) == 1 for t in targets):
                 # forward launch list, then target assignment + loss + logits gradient in one fused launch sequence
                 gts = [t['anns'][task_id][0] for t in targets]
-                _, losses = header.fused_losses(self._eng(), x, dtype, gts)
+                _, losses = header.fused_losses(self._eng(), x, dtype, gts, compute_masks=compute_masks)
                 return {task_id: losses}, self.post_processing([{task_id: o} for o in []])
         plan, dets = self._eng().forward(x, self.training, dtype)
         losses, outputs = {}, {}

@@ -264,7 +264,7 @@ class Detect(nn.Module):
         import os
         dl = self.det_loss
         return (os.environ.get('HDY_FUSED_LOSS', '1') != '0' and not dl.autobalance and dl.hyp['fl_gamma'] == 0 and dl.gr == 1.0
-                and not dl.sort_obj_iou and self.nc <= 128 and self.nc_masks == 0)
+                and not dl.sort_obj_iou and self.nc <= 128)
 
     def flatten_targets(self, targets, dev):
         """Per-image ann dicts -> gts (nt,5) [img, cx, cy, w, h] and one-hot labels (nt, nc+1), built once per batch."""
@@ -284,11 +284,20 @@ class Detect(nn.Module):
             gt_labels = torch.cat([one_hot_labels(l, self.nc) if l.dim() == 1 else l for l in labs]).to(dev)
         return gts, gt_labels
 
-    def fused_losses(self, engine, x, dtype, targets):
+    def fused_losses(self, engine, x, dtype, targets, compute_masks=False):
         gts, gt_labels = self.flatten_targets(targets, x.device)
         tcls = gt_labels[:, 1:].float().contiguous()
         plan, loss, items = engine.forward_fused_loss(x, dtype, self, gts.contiguous(), tcls)
-        mask_loss = torch.zeros_like(loss)
+        mask_loss = None
+        if compute_masks and self.nc_masks > 0:
+            # the mask branch needs WHICH cells were matched: the tensor-expression matcher on the (detached) logits — the same
+            # assignment the loss kernel made — and the decoded boxes of those cells
+            dets = [d.detach() for d in plan.det_views()]
+            _, tids, indices, _ = self.matcher(dets, gts)
+            mask_loss = self.mask_losses(self.compute_proposals(dets), (engine, plan, dtype), targets, gts, tids, indices,
+                                         [gt_labels[i] for i in tids])
+        if mask_loss is None:
+            mask_loss = torch.zeros_like(loss)
         return plan, {'det_loss': loss, 'mask_loss': mask_loss,
                       'loss_items': {'box': items[0:1], 'obj': items[1:2], 'cls': items[2:3], 'mask': mask_loss.detach()}}
 

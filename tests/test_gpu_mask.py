@@ -130,8 +130,11 @@ def test_eval_masks_match_reference():
     assert 'masks' not in plain[0]['det']
 
 
-def test_train_step_with_mask_loss_matches_reference():
-    """det + mask loss and every parameter gradient (3 numbers each) of one training step with anchor-shaped truths."""
+@pytest.mark.parametrize('fused', ['1', '0'])
+def test_train_step_with_mask_loss_matches_reference(fused, monkeypatch):
+    """det + mask loss and every parameter gradient (3 numbers each) of one training step with anchor-shaped truths; with the
+    fused detection-loss kernel (the mask branch then re-derives the matched cells with the tensor-expression matcher) and without."""
+    monkeypatch.setenv('HDY_FUSED_LOSS', fused)
     model = _mask_model(synth.make_hyp()).train()
     x = synth.synth_images(2, 128, seed=11).to(DEV)
     targets = synth.synth_mask_targets(2, 128, 2, per_image=6, seed=4)
