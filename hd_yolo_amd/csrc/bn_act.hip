@@ -269,7 +269,8 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
     }
 }
 
-template <typename T>
+// FROZEN: constant scale / shift (FrozenBatchNorm2d): dy = scale * du, no statistics terms (mean / invstd / c1 / c2 unused)
+template <typename T, bool FROZEN>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restrict__ dz, int lddz, const T* __restrict__ y, int ldy,
                                                                const float* __restrict__ scale, const float* __restrict__ shift,
                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -285,8 +286,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restri
 #pragma unroll
         for (int i = 0; i < VE; ++i) {
             sc[i] = scale[c + i]; sh[i] = shift[c + i];
-            mu[i] = mean ? mean[c + i] : 0.f; is[i] = invstd ? invstd[c + i] : 0.f;     // frozen statistics: no mean / variance terms
-            k1[i] = c1 ? c1[c + i] : 0.f; k2[i] = c2 ? c2[c + i] : 0.f;
+            mu[i] = FROZEN ? 0.f : mean[c + i]; is[i] = FROZEN ? 0.f : invstd[c + i];
+            k1[i] = FROZEN ? 0.f : c1[c + i]; k2[i] = FROZEN ? 0.f : c2[c + i];
         }
         for (int m = blockIdx.x * L.RL + L.rl; m < M; m += gridDim.x * L.RL) {
             float g[VE], v[VE];
@@ -340,7 +341,7 @@ inline int stream_grid(long long M, int VC) {
 
 extern "C" {
 
-size_t hdy_bn_finalize_workspace_bytes(int mtiles, int K) { return mtiles > 256 ? (size_t)32 * 2 * K * sizeof(double) : 0; }
+size_t hdy_bn_finalize_workspace_bytes(int mtiles, int K) { return mtiles > 1024 ? (size_t)32 * 2 * K * sizeof(double) : 0; }
 
 int hdy_bn_finalize(const float* stats, int stats_ld, int mtiles, int K, long long count, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float eps, float momentum, float* scale, float* shift, float* save_mean, float* save_invstd,
@@ -349,7 +350,7 @@ int hdy_bn_finalize(const float* stats, int stats_ld, int mtiles, int K, long lo
     HDY_ARG(mtiles > 0 && K > 0 && count > 0 && stats_ld >= K, "bn_finalize: bad sizes");
     HDY_ARG((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running_mean/var must both be given or both null");
     hipStream_t st = (hipStream_t)stream;
-    if (mtiles > 256 && workspace) {
+    if (mtiles > 1024 && workspace) {
         // two stages: 32 groups of tiles reduced in parallel, then the usual final stage over 32 fp64 partials
         const int G = 32, tpg = cdiv(mtiles, G);
         double* part = (double*)workspace;
@@ -421,11 +422,11 @@ int hdy_bn_act_bwd(const void* dz, int lddz, const void* y, int ldy, const float
         // so dy = scale * dz * act'(u) and there is no statistics gradient: the apply pass alone
         const int g2 = stream_grid(M, K / VE);
         if (dtype == HDY_BF16)
-            hipLaunchKernelGGL(bn_act_bwd_apply_kernel<bf16_t>, dim3(g2), dim3(256), 0, st, (const bf16_t*)dz, lddz, (const bf16_t*)y, ldy, scale,
+            hipLaunchKernelGGL((bn_act_bwd_apply_kernel<bf16_t, true>), dim3(g2), dim3(256), 0, st, (const bf16_t*)dz, lddz, (const bf16_t*)y, ldy, scale,
                                shift, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (bf16_t*)dy, lddy,
                                (int)M, K, act);
         else
-            hipLaunchKernelGGL(bn_act_bwd_apply_kernel<float>, dim3(g2), dim3(256), 0, st, (const float*)dz, lddz, (const float*)y, ldy, scale,
+            hipLaunchKernelGGL((bn_act_bwd_apply_kernel<float, true>), dim3(g2), dim3(256), 0, st, (const float*)dz, lddz, (const float*)y, ldy, scale,
                                shift, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)dy, lddy,
                                (int)M, K, act);
         HDY_LAUNCH_CHECK("bn_act_bwd_apply(frozen)");
@@ -444,10 +445,10 @@ int hdy_bn_act_bwd(const void* dz, int lddz, const void* y, int ldy, const float
     HDY_LAUNCH_CHECK("bn_bwd_finalize");
     const int g2 = stream_grid(M, K / VE);
     if (dtype == HDY_BF16)
-        hipLaunchKernelGGL(bn_act_bwd_apply_kernel<bf16_t>, dim3(g2), dim3(256), 0, st, (const bf16_t*)dz, lddz, (const bf16_t*)y, ldy, scale,
+        hipLaunchKernelGGL((bn_act_bwd_apply_kernel<bf16_t, false>), dim3(g2), dim3(256), 0, st, (const bf16_t*)dz, lddz, (const bf16_t*)y, ldy, scale,
                            shift, mean, invstd, c1, c2, (bf16_t*)dy, lddy, (int)M, K, act);
     else
-        hipLaunchKernelGGL(bn_act_bwd_apply_kernel<float>, dim3(g2), dim3(256), 0, st, (const float*)dz, lddz, (const float*)y, ldy, scale,
+        hipLaunchKernelGGL((bn_act_bwd_apply_kernel<float, false>), dim3(g2), dim3(256), 0, st, (const float*)dz, lddz, (const float*)y, ldy, scale,
                            shift, mean, invstd, c1, c2, (float*)dy, lddy, (int)M, K, act);
     HDY_LAUNCH_CHECK("bn_act_bwd_apply");
     return HDY_OK;

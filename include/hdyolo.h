@@ -98,7 +98,7 @@ int hdy_conv_wgrad(const void* x, int ldx, const void* dy, int lddy, int N, int 
  * Conv.forward (metayolo/models/layers.py:37-38), the shortcut add of Bottleneck.forward (:97), their backward,
  * and the eval-time folding of fuse_conv_and_bn (metayolo/models/utils_torch.py:79-99). */
 /* stats: [mtiles][2][stats_ld] slabs from hdy_conv_fwd (channel slice of K).  workspace (optional, enables the parallel
- * two-stage reduction for mtiles > 256): hdy_bn_finalize_workspace_bytes(mtiles, K) bytes, 8-byte aligned. */
+ * two-stage reduction for mtiles > 1024): hdy_bn_finalize_workspace_bytes(mtiles, K) bytes, 8-byte aligned. */
 size_t hdy_bn_finalize_workspace_bytes(int mtiles, int K);
 int hdy_bn_finalize(const float* stats, int stats_ld, int mtiles, int K, long long count, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float eps, float momentum, float* scale, float* shift, float* save_mean, float* save_invstd,
