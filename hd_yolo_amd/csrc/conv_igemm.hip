@@ -34,6 +34,8 @@
 // :124-126 (C3), :179-180 (SPPF), yolo_head.py:112 (det conv), and autograd's conv backward-data.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "hdyolo_internal.h"
 
@@ -304,30 +306,41 @@ __global__ __launch_bounds__(2 * BM, (BM == 256 || BN == 128) ? 2 : (BN == 64 ? 
 #pragma unroll
             for (int pass = 0; pass < BM / RPP; ++pass) {
                 if ((wm * 64) / RPP == pass) {
+                    // one specialised copy of the staging loop per (affine, activation): as runtime selects inside the
+                    // value loop they cost ~0.5 ms per train step (raw outputs) for nothing
+                    auto stage = [&](auto affine_c, auto act_c) {
+                        constexpr bool AFF = decltype(affine_c)::value;
+                        constexpr int ACT = decltype(act_c)::value;
 #pragma unroll
-                    for (int b = 0; b < NT; ++b) {
-                        const int col = wn * (BN / 2) + b * 16 + fq * 4;
-                        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-                        if (affine) {
-                            sc = COEF_LDS ? *(const f32x4*)(coef + col) : sc_reg;
-                            sh = COEF_LDS ? *(const f32x4*)(coef + BN + col) : sh_reg;
-                        }
-                        const int slot = wn * (BN / 8) + b * 4 + fq;
-#pragma unroll
-                        for (int a = 0; a < MT; ++a) {
-                            const int row = (wm * 64) % RPP + a * 16 + fr;
-                            float v[4];
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                v[r] = acc[a][b][r];
-                                if (affine) v[r] = v[r] * sc[r] + sh[r];
-                                if (p.act == 1) v[r] = v[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[r]));   // SiLU; 1 ulp, then bf16
-                                else if (p.act == 2) v[r] = fmaxf(v[r], 0.0f);
+                        for (int b = 0; b < NT; ++b) {
+                            const int col = wn * (BN / 2) + b * 16 + fq * 4;
+                            f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+                            if (AFF) {
+                                sc = COEF_LDS ? *(const f32x4*)(coef + col) : sc_reg;
+                                sh = COEF_LDS ? *(const f32x4*)(coef + BN + col) : sh_reg;
                             }
-                            bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-                            *(bf16x4*)(scratch + row * ROWB + ((slot ^ (row & SWM)) << 3)) = o;
+                            const int slot = wn * (BN / 8) + b * 4 + fq;
+#pragma unroll
+                            for (int a = 0; a < MT; ++a) {
+                                const int row = (wm * 64) % RPP + a * 16 + fr;
+                                float v[4];
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    v[r] = acc[a][b][r];
+                                    if (AFF) v[r] = v[r] * sc[r] + sh[r];
+                                    if (ACT == 1) v[r] = v[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[r]));   // SiLU; 1 ulp, then bf16
+                                    else if (ACT == 2) v[r] = fmaxf(v[r], 0.0f);
+                                }
+                                bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                                *(bf16x4*)(scratch + row * ROWB + ((slot ^ (row & SWM)) << 3)) = o;
+                            }
                         }
-                    }
+                    };
+                    using std::integral_constant;
+                    if (!affine && p.act == 0) stage(integral_constant<bool, false>{}, integral_constant<int, 0>{});
+                    else if (p.act == 1) stage(integral_constant<bool, true>{}, integral_constant<int, 1>{});
+                    else if (p.act == 2) stage(integral_constant<bool, true>{}, integral_constant<int, 2>{});
+                    else stage(integral_constant<bool, true>{}, integral_constant<int, 0>{});
                 }
                 __syncthreads();
                 const int ch = tid % CPR, rr = tid / CPR;
