@@ -186,7 +186,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
 
 // ---------------------------------------------------------------- backward
 // partial[block][2][K]: sum(du), sum(du*xhat) over this block's rows.  grid.x = row blocks, grid.y = column chunks.
-template <typename T>
+// MODE 0: plain column sums of dz (colsum: y and the coefficients are null); 1: BatchNorm backward without activation; 2: with SiLU
+template <typename T, int MODE>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restrict__ dz, int lddz, const T* __restrict__ y, int ldy,
                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -201,28 +202,24 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restr
 #pragma unroll
     for (int i = 0; i < VE; ++i) {
         a1[i] = 0.f; a2[i] = 0.f;
-        sc[i] = (scale && L.live) ? scale[c + i] : 1.f;
-        sh[i] = (shift && L.live) ? shift[c + i] : 0.f;
-        mu[i] = (mean && L.live) ? mean[c + i] : 0.f;
-        is[i] = (invstd && L.live) ? invstd[c + i] : 0.f;
+        sc[i] = (MODE != 0 && L.live) ? scale[c + i] : 1.f;
+        sh[i] = (MODE != 0 && L.live) ? shift[c + i] : 0.f;
+        mu[i] = (MODE != 0 && L.live) ? mean[c + i] : 0.f;
+        is[i] = (MODE != 0 && L.live) ? invstd[c + i] : 0.f;
     }
     const int mbeg = blockIdx.x * rows_per_block;
     const int mend = min(mbeg + rows_per_block, M);
     if (L.live) {
         for (int m = mbeg + L.rl; m < mend; m += L.RL) {
-            float g[VE], v[VE];
+            float g[VE], v[VE] = {};
             unpack<T>(*(const i32x4*)(dz + (size_t)m * lddz + c), g);
-            if (y) unpack<T>(*(const i32x4*)(y + (size_t)m * ldy + c), v);
-            else {
-#pragma unroll
-                for (int i = 0; i < VE; ++i) v[i] = 0.f;
-            }
+            if (MODE != 0) unpack<T>(*(const i32x4*)(y + (size_t)m * ldy + c), v);
 #pragma unroll
             for (int i = 0; i < VE; ++i) {
                 float du = g[i];
-                if (act == 1) du *= dsilu_f(v[i] * sc[i] + sh[i]);
+                if (MODE == 2) du *= dsilu_f(v[i] * sc[i] + sh[i]);
                 a1[i] += du;
-                a2[i] += du * ((v[i] - mu[i]) * is[i]);
+                if (MODE != 0) a2[i] += du * ((v[i] - mu[i]) * is[i]);
             }
         }
 #pragma unroll
@@ -271,7 +268,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
 }
 
 // FROZEN: constant scale / shift (FrozenBatchNorm2d): dy = scale * du, no statistics terms (mean / invstd / c1 / c2 unused)
-template <typename T, bool FROZEN>
+template <typename T, bool FROZEN, int ACT>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restrict__ dz, int lddz, const T* __restrict__ y, int ldy,
                                                                const float* __restrict__ scale, const float* __restrict__ shift,
                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -297,7 +294,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restri
 #pragma unroll
             for (int i = 0; i < VE; ++i) {
                 float du = g[i];
-                if (act == 1) du *= dsilu_f(v[i] * sc[i] + sh[i]);
+                if (ACT == 1) du *= dsilu_f(v[i] * sc[i] + sh[i]);
                 const float xh = (v[i] - mu[i]) * is[i];
                 g[i] = sc[i] * (du - k1[i] - xh * k2[i]);
             }
@@ -333,6 +330,28 @@ inline int stream_grid(long long M, int VC) {
     if (g > 256 * 8) g = 256 * 8;
     if (g < 1) g = 1;
     return (int)g;
+}
+
+template <typename T>
+void bn_bwd_reduce_launch(dim3 grid, hipStream_t st, const void* dz, int lddz, const void* y, int ldy, const float* scale, const float* shift,
+                          const float* mean, const float* invstd, int M, int K, int act, int rows, float* partial) {
+    if (act == 1)
+        hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, 2>), grid, dim3(256), 0, st, (const T*)dz, lddz, (const T*)y, ldy, scale, shift, mean, invstd, M, K,
+                           act, rows, partial);
+    else
+        hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, 1>), grid, dim3(256), 0, st, (const T*)dz, lddz, (const T*)y, ldy, scale, shift, mean, invstd, M, K,
+                           act, rows, partial);
+}
+
+template <typename T, bool FROZEN>
+void bn_bwd_apply_launch(int grid, hipStream_t st, const void* dz, int lddz, const void* y, int ldy, const float* scale, const float* shift,
+                         const float* mean, const float* invstd, const float* c1, const float* c2, void* dy, int lddy, int M, int K, int act) {
+    if (act == 1)
+        hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, FROZEN, 1>), dim3(grid), dim3(256), 0, st, (const T*)dz, lddz, (const T*)y, ldy, scale, shift, mean,
+                           invstd, c1, c2, (T*)dy, lddy, M, K, act);
+    else
+        hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, FROZEN, 0>), dim3(grid), dim3(256), 0, st, (const T*)dz, lddz, (const T*)y, ldy, scale, shift, mean,
+                           invstd, c1, c2, (T*)dy, lddy, M, K, act);
 }
 
 template <typename T, int ACT>
@@ -434,39 +453,25 @@ int hdy_bn_act_bwd(const void* dz, int lddz, const void* y, int ldy, const float
     float* c1 = workspace + (size_t)nb * 2 * K;
     float* c2 = c1 + K;
     hipStream_t st = (hipStream_t)stream;
+    HDY_ARG(act == 0 || act == 1, "bn_act_bwd: activation %d has no BatchNorm backward here", act);
+    const int g2 = stream_grid(M, K / VE);
     if (!mean) {
         // frozen BatchNorm (torchvision FrozenBatchNorm2d after Model.freeze): z = act(y*scale + shift) with constant scale/shift,
         // so dy = scale * dz * act'(u) and there is no statistics gradient: the apply pass alone
-        const int g2 = stream_grid(M, K / VE);
-        if (dtype == HDY_BF16)
-            hipLaunchKernelGGL((bn_act_bwd_apply_kernel<bf16_t, true>), dim3(g2), dim3(256), 0, st, (const bf16_t*)dz, lddz, (const bf16_t*)y, ldy, scale,
-                               shift, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (bf16_t*)dy, lddy,
-                               (int)M, K, act);
-        else
-            hipLaunchKernelGGL((bn_act_bwd_apply_kernel<float, true>), dim3(g2), dim3(256), 0, st, (const float*)dz, lddz, (const float*)y, ldy, scale,
-                               shift, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)dy, lddy,
-                               (int)M, K, act);
+        if (dtype == HDY_BF16) bn_bwd_apply_launch<bf16_t, true>(g2, st, dz, lddz, y, ldy, scale, shift, nullptr, nullptr, nullptr, nullptr, dy, lddy, (int)M, K, act);
+        else bn_bwd_apply_launch<float, true>(g2, st, dz, lddz, y, ldy, scale, shift, nullptr, nullptr, nullptr, nullptr, dy, lddy, (int)M, K, act);
         HDY_LAUNCH_CHECK("bn_act_bwd_apply(frozen)");
         return HDY_OK;
     }
     dim3 grid(nb, cdiv(K / VE, 256));
-    if (dtype == HDY_BF16)
-        hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dz, lddz, (const bf16_t*)y, ldy, scale,
-                           shift, mean, invstd, (int)M, K, act, rows, partial);
-    else
-        hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<float>, grid, dim3(256), 0, st, (const float*)dz, lddz, (const float*)y, ldy, scale,
-                           shift, mean, invstd, (int)M, K, act, rows, partial);
+    if (dtype == HDY_BF16) bn_bwd_reduce_launch<bf16_t>(grid, st, dz, lddz, y, ldy, scale, shift, mean, invstd, (int)M, K, act, rows, partial);
+    else bn_bwd_reduce_launch<float>(grid, st, dz, lddz, y, ldy, scale, shift, mean, invstd, (int)M, K, act, rows, partial);
     HDY_LAUNCH_CHECK("bn_act_bwd_reduce");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(K, 32)), dim3(1024), 0, st, partial, nb, K, (double)M, dgamma, dbeta, accumulate, c1,
                        c2);
     HDY_LAUNCH_CHECK("bn_bwd_finalize");
-    const int g2 = stream_grid(M, K / VE);
-    if (dtype == HDY_BF16)
-        hipLaunchKernelGGL((bn_act_bwd_apply_kernel<bf16_t, false>), dim3(g2), dim3(256), 0, st, (const bf16_t*)dz, lddz, (const bf16_t*)y, ldy, scale,
-                           shift, mean, invstd, c1, c2, (bf16_t*)dy, lddy, (int)M, K, act);
-    else
-        hipLaunchKernelGGL((bn_act_bwd_apply_kernel<float, false>), dim3(g2), dim3(256), 0, st, (const float*)dz, lddz, (const float*)y, ldy, scale,
-                           shift, mean, invstd, c1, c2, (float*)dy, lddy, (int)M, K, act);
+    if (dtype == HDY_BF16) bn_bwd_apply_launch<bf16_t, false>(g2, st, dz, lddz, y, ldy, scale, shift, mean, invstd, c1, c2, dy, lddy, (int)M, K, act);
+    else bn_bwd_apply_launch<float, false>(g2, st, dz, lddz, y, ldy, scale, shift, mean, invstd, c1, c2, dy, lddy, (int)M, K, act);
     HDY_LAUNCH_CHECK("bn_act_bwd_apply");
     return HDY_OK;
 }
@@ -480,10 +485,10 @@ int hdy_colsum(const void* dz, int lddz, long long M, int K, float* out, int acc
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(nb, cdiv(K / VE, 256));
     if (dtype == HDY_BF16)
-        hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dz, lddz, (const bf16_t*)nullptr, 0,
+        hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<bf16_t, 0>), grid, dim3(256), 0, st, (const bf16_t*)dz, lddz, (const bf16_t*)nullptr, 0,
                            (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (int)M, K, 0, rows, workspace);
     else
-        hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<float>, grid, dim3(256), 0, st, (const float*)dz, lddz, (const float*)nullptr, 0,
+        hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<float, 0>), grid, dim3(256), 0, st, (const float*)dz, lddz, (const float*)nullptr, 0,
                            (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (int)M, K, 0, rows, workspace);
     HDY_LAUNCH_CHECK("colsum_reduce");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(K, 32)), dim3(1024), 0, st, workspace, nb, K, (double)M, (float*)nullptr, out, accumulate,
