@@ -20,6 +20,7 @@
 // registers across all of the workgroup's tiles (one statistics slab per workgroup).
 // Work split: every workgroup gets floor(tiles / grid) whole tiles; the remaining tiles are cut into 2 or 4 row bands so that
 // they still spread over all CUs (1600 tiles on 256 CUs: 6 tiles + one 4-row band each, instead of 229 CUs x 7 tiles).
+// Measured and not adopted: 8-byte stores straight from the accumulators (no staging tile, one barrier per item): 43.3 us vs 39.9 us.
 // Measured per-tile phases (shader clocks, 16x16 tile): patch DMA issue ~1.1k, MFMA ~4.7k (at the MFMA rate for 2 waves per
 // SIMD), epilogue ~0.5k, row stores ~0.6k, barriers ~0.5k.
 //
