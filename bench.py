@@ -88,7 +88,7 @@ def conv_roofline(device, iters=30):
     flops = 2.0 * N * K * C * 9 * H * W
     ach = flops / t / 1e12
     return {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_BF16_TFLOPS, 4),
-            'traffic': pmc_traffic(), 'kernel': 'conv3x3_c64_kernel (bf16, filter-resident) fwd 3x3 64->64 @80x80 B=64 (+BN stat slabs)',
+            'traffic': pmc_traffic(), 'kernel': 'conv3x3_c64_kernel (bf16, filter in registers) fwd 3x3 64->64 @80x80 B=64 (+BN stat slabs)',
             'us_per_launch': round(t * 1e6, 2), 'algorithmic_gflop_per_launch': round(flops / 1e9, 2)}
 
 

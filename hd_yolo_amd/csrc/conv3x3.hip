@@ -1,31 +1,45 @@
-// 3x3 / stride 1 / pad 1 convolution for 64 input channels (bf16), weights resident in LDS — the kernel behind the
+// 3x3 / stride 1 / pad 1 convolution for 64 input channels (bf16), filter resident in REGISTERS — the kernel behind the
 // layer BASELINE.json names ("fused 3x3 conv at batch 64 x 640 x 640": yolov5s' 64->64 @80x80) and its dgrad.
 //
 // Why a second conv kernel: the generic implicit GEMM (conv_igemm.hip) fetches the A operand once per tap — 9x the
 // activation bytes from L2 per output tile, plus the 73 KB filter per tile.  At ~2 us of L2 latency and 64 KB in flight per
 // CU that caps it near 9 TB/s of L2->LDS traffic, i.e. ~350 TFLOP/s on this layer whatever the MFMA schedule does.
-// Here each workgroup
-//   * keeps the whole filter (9 taps x 64 x 64 bf16 = 72 KB) in LDS for its lifetime (persistent over ~6 tiles),
-//   * stages one (16+2) x (16+2) input patch (41 KB) per 16x16 output tile by LDS-DMA, double buffered across tiles,
-//   * and reads all 9 taps' A fragments out of that patch: L2->LDS traffic per 256 outputs drops from 440 KB to 41 KB;
-//   * runs 8 waves (2 per SIMD) so one wave's fragment reads / address VALU overlap the other's MFMAs.
-// Fragment addressing: lane row = output pixel (ty, tx) of the tile, tap (r, s) reads patch pixel (ty+r)*18 + tx+s; the
+// Here a workgroup is 4 waves, persistent over ~6 output tiles of 8 x 16 pixels, and
+//   * each wave owns 16 output channels and keeps their 9 x 64 filter slice as 18 MFMA row operands (72 VGPRs) for its
+//     lifetime: no filter bytes in LDS, no filter reads in the MFMA loop;
+//   * one (8+2) x (16+2) input patch (23 KB) per tile is staged by LDS-DMA, double buffered across tiles; all 9 taps read their
+//     A fragments out of it: L2->LDS traffic per 256 outputs is 46 KB instead of 440 KB;
+//   * with every tap in registers one patch-row fragment feeds all the (tile row, filter row) pairs that touch it: an 8-row
+//     tile reads 10 x 6 fragments, not 8 x 18 (LDS read traffic per 256 outputs: 480 KB; 864 KB with the filter in LDS);
+//   * LDS per workgroup is 2 patches + a separate staging tile = 61 KB and the kernel is capped at 256 VGPRs, so TWO workgroups
+//     share a CU (2 waves per SIMD).  They are independent — own barriers — and the second one is dispatched ~3 us after the
+//     first, so one's patch issue / epilogue / stores overlap the other's MFMAs.
+// Fragment addressing: lane column = output pixel (ty, tx) of the tile, tap (r, s) reads patch pixel (ty+r)*18 + tx+s; the
 // 16 lanes of a fragment read 16 consecutive patch pixels, and chunk ^ (((patch column>>1)&3)<<1) spreads them over the 16
 // 16-byte slots of the 256-byte bank row.  ds_read_b128 is served in groups of 16 lanes that MIX two k-chunks (lanes 0-3, 12-15 of
 // chunk c with lanes 4-11 of chunk c+1): keying on bits 1-2 only leaves bit 0 to tell the two chunks apart, which is conflict-free
-// for every tap shift (the first key, (column>>1)&7, collided at odd shifts: 25 % of the LDS cycles were conflict cycles).  LDS-DMA writes linearly, so that XOR is applied to the
-// source address (rule: linear destination + permuted source + permuted read).
+// for every tap shift (a first key, (column>>1)&7, collided at odd shifts: 25 % of the LDS cycles were conflict cycles).
+// LDS-DMA writes linearly, so that XOR is applied to the source address (rule: linear destination + permuted source + permuted read).
 // The MFMAs run with the FILTER as the row operand, so a lane's 4 accumulator values are 4 consecutive output channels of ONE
-// pixel: the epilogue packs them into one 8-byte LDS write (instead of four 2-byte scatters) and the BatchNorm sums stay in
-// registers across all of the workgroup's tiles (one statistics slab per workgroup).
+// pixel: the epilogue packs them into one 8-byte LDS write, the BatchNorm sums stay in registers across all of the workgroup's
+// tiles (one statistics slab per workgroup) and — a wave's channels being its own — leave without a cross-wave reduction.
 // Work split: every workgroup gets floor(tiles / grid) whole tiles; the remaining tiles are cut into 2 or 4 row bands so that
-// they still spread over all CUs (1600 tiles on 256 CUs: 6 tiles + one 4-row band each, instead of 229 CUs x 7 tiles).
-// Measured and not adopted: 8-byte stores straight from the accumulators (no staging tile, one barrier per item): 43.3 us vs 39.9 us.
-// Measured per-tile phases (shader clocks, 16x16 tile): patch DMA issue ~1.1k, MFMA ~4.7k (at the MFMA rate for 2 waves per
-// SIMD), epilogue ~0.5k, row stores ~0.6k, barriers ~0.5k.
+// they still spread over all CUs (3200 tiles on 512 workgroups: 6 tiles + one 2-row band each).
+//
+// Measured on the BASELINE layer (64 x 80 x 80, 30.2 GFLOP; us per launch, same box):
+//   39.6  first generation: one 8-wave workgroup per CU, filter in LDS (72 KB), 16x16 tiles, 6 LDS reads per 8 MFMAs
+//   40.0  this design with the compiler's schedule (ds_read -> wait -> 3 MFMAs: a wave is LDS-latency bound, 4.4k cycles per item)
+//   36.9  + fragment reads software-pipelined by hand (sched_barrier fences; 3.0k cycles per item alone, 2.3k = MFMA rate)
+// and NOT adopted, all within +-0.5 us of 36.9 or worse: patch pieces issued from inside the MFMA loop (38.4: an LDS-DMA costs the
+// wave ~350 cycles of issue time wherever it sits); the patch through registers (global_load + ds_write, 38.0) and the same with two
+// register sets = two items of lead (37.0); inline-asm reads with exact lgkmcnt waits (38.3); starting the second workgroup of
+// a CU on its band item to shift its phase (37.5); first generation with 8-byte stores straight from the accumulators (43.3).
+// Ablation: without the patch fetch 35.1, without the output stores 34.8, without both 32.9 us — the kernel is not memory bound;
+// the MFMA pipe is busy ~45 % of the cycles (1.7 GHz under this load), the rest is per-item work that two waves per SIMD do
+// not overlap completely (patch issue ~2.0k cycles, statistics + staging ~0.6k, row stores ~0.5k, barriers ~0.4k per 8-row item).
 //
 // Requirements (checked by the launcher, otherwise the generic kernel runs): bf16 in/out, C == 64, K <= 64, R = S = 3,
-// stride 1, pad 1, H % 16 == 0, W % 16 == 0, 16-byte aligned rows.
+// stride 1, pad 1, H % 8 == 0, W % 16 == 0, 16-byte aligned rows.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -36,12 +50,6 @@
 __device__ uint4 g_hdy_zero16_c3[4];   // zero page for out-of-image patch pixels
 
 namespace {
-
-constexpr int NTHR = 512;                                                // 8 waves = 4 (tile-row groups) x 2 (channel halves)
-constexpr int TH = 16, TW = 16, PW = TW + 2, PPIX = (TH + 2) * PW;       // 324 patch pixels
-constexpr int PATCH_B = PPIX * 128;                                      // 41472
-constexpr int W_B = 9 * 64 * 128;                                        // 73728
-constexpr int SMEM_B = W_B + 2 * PATCH_B;                                // 156672 of 163840
 
 __device__ __forceinline__ void glds16(const void* g, unsigned char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g,
@@ -63,66 +71,94 @@ __host__ __device__ inline WorkSplit work_split(int tiles, int grid) {
     return s;
 }
 
-struct Item { int n, th, tw, row0, nrows; };   // rows [row0, row0 + nrows) of tile (n, th, tw); nrows in {16, 8, 4}
+struct Item { int n, th, tw, row0, nrows; };   // rows [row0, row0 + nrows) of tile (n, th, tw); nrows in {8, 4, 2}
+
+constexpr int NTHR = 256;                                            // 4 waves: wave = 16-channel group
+constexpr int TH = 8, TW = 16, PW = TW + 2, PPIX = (TH + 2) * PW;    // 180 patch pixels
+constexpr int PATCH_B = PPIX * 128;                                  // 23040
+constexpr int STAGE_B = TH * TW * 128;                               // 16384
+constexpr int SMEM_B = 2 * PATCH_B + STAGE_B;                        // 62464: two workgroups per CU
+constexpr int NPASS = (PPIX * 8 + NTHR - 1) / NTHR;                  // 6 loader passes (last partial)
 
 // EPI: 0 = raw convolution out (train-mode forward, dgrad), 1 = scale/shift, 2 = scale/shift + SiLU
-template <int EPI>
-__global__ __launch_bounds__(NTHR) void conv3x3_c64_kernel(const ConvArgs p) {
+// STATS: accumulate BatchNorm partial sums (one slab per workgroup)
+template <int EPI, bool STATS>
+__global__ __launch_bounds__(NTHR, 2) void conv3x3_c64_kernel(const ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* sW = smem;                    // [9][64][128 B]
-    unsigned char* sP = smem + W_B;              // [2][324][128 B]
+    unsigned char* sP = smem;                    // [2][180][128 B]
+    unsigned char* sS = smem + 2 * PATCH_B;      // [128][128 B] staging tile
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
     const int fr = lane & 15, fq = lane >> 4;
     const int tiles_w = p.Wo / TW, tiles_h = p.Ho / TH;
     const int tiles_total = p.N * tiles_w * tiles_h;
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);       // logical workgroup: owns statistics slab wg
-    const WorkSplit ws = work_split(tiles_total, (int)gridDim.x);
-    const int nitems = ws.per + (wg < ws.units ? 1 : 0);   // >= 1: the launcher never starts more workgroups than tiles
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const WorkSplit ws = work_split(tiles_total, (int)gridDim.x);        // here the bands are 8 / 4 / 2 rows
+    const int nitems = ws.per + (wg < ws.units ? 1 : 0);
 
     const bf16_t* __restrict__ x = (const bf16_t*)p.x;
     const bf16_t* __restrict__ w = (const bf16_t*)p.w;
     const unsigned char* zero = (const unsigned char*)g_hdy_zero16_c3;
-    const int lc = (tid & 7) ^ ((tid >> 4) & 7);          // logical chunk for physical slot tid & 7 (rows differ by 32*i)
 
-    // ---- filter: 9 taps x 64 rows, once per workgroup.  LDS row (tap*64 + k) <- packed w[k][tap*64 .. +63]
+    // ---- filter slice -> registers: row operand of tap t, k-half ks = w[wave*16 + fr][t*64 + (ks*4 + fq)*8 .. +7]
+    V16 bw[9][2];
+    {
+        const int k = wave * 16 + fr;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {                          // 576 rows * 8 chunks / 512 threads
-        const int pos = tid + NTHR * i;
-        const int row = pos >> 3;                          // tap*64 + k
-        const int tap = row >> 6, k = row & 63;
-        const void* src = (k < p.K) ? (const void*)(w + (size_t)k * p.Kdp + tap * 64 + lc * 8) : (const void*)zero;
-        glds16(src, sW + (wave * 64 + NTHR * i) * 16);
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const void* src = (k < p.K) ? (const void*)(w + (size_t)k * p.Kdp + t * 64 + (ks * 4 + fq) * 8) : (const void*)zero;
+                bw[t][ks].i = *(const i32x4*)src;
+            }
     }
 
-    // ---- patch loader: each thread's 6 (pixel, chunk) slots of the 18-wide patch are the same for every item; only the
-    // origin, the number of patch rows and the image-border test change: a compare + select + add per DMA.
-    // (Issuing the next patch piecewise from inside the MFMA loop was measured slower: 45.1 / 43.5 us against 42.9 us per
-    // launch with all DMAs at the top of the item — the loads land later, and an in-order wave cannot issue MFMAs past a DMA
-    // that is waiting for a queue slot.)
-    int prel[6], pyx[6];
+    // ---- patch loader: each thread's 6 (pixel, chunk) slots of the 18-wide patch are the same for every item; only the origin,
+    // the number of patch rows and the image-border test change
+    int prel[NPASS], pyx[NPASS];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {                          // 2592 chunks / 512 threads (last pass partial)
+    for (int i = 0; i < NPASS; ++i) {
         const int pos = tid + NTHR * i;
         const int pix = pos >> 3;
         const int py = pix / PW, px = pix - py * PW;
-        const int lcp = (tid & 7) ^ (((px >> 1) & 3) << 1);   // patch swizzle keys on the COLUMN (see the fragment reads)
+        const int lcp = (tid & 7) ^ (((px >> 1) & 3) << 1);
         prel[i] = (py * p.Win + px) * p.ldx + lcp * 8;
         pyx[i] = py | (px << 8);
     }
-    auto item_at = [&](int idx) {
+    // Items: whole tiles wg*per .. wg*per + per-1 (consecutive, so (n, th, tw) advances without divisions), then the band.
+    auto first_item = [&]() {
         Item c;
         int t;
-        if (idx < ws.per) {
-            t = wg * ws.per + idx;
+        if (ws.per > 0) {
+            t = wg * ws.per;
             c.row0 = 0;
             c.nrows = TH;
         } else {
-            t = ws.per * (int)gridDim.x + wg / ws.bands;
+            t = wg / ws.bands;
             c.nrows = TH / ws.bands;
             c.row0 = (wg % ws.bands) * c.nrows;
         }
+        const int per_img = tiles_w * tiles_h;
+        c.n = t / per_img;
+        const int rem = t - c.n * per_img;
+        c.th = rem / tiles_w;
+        c.tw = rem - c.th * tiles_w;
+        return c;
+    };
+    auto item_after = [&](Item c, int idx) {               // item idx + 1, given item idx
+        if (idx + 1 < ws.per) {
+            if (++c.tw == tiles_w) {
+                c.tw = 0;
+                if (++c.th == tiles_h) {
+                    c.th = 0;
+                    ++c.n;
+                }
+            }
+            return c;
+        }
+        const int t = ws.per * (int)gridDim.x + wg / ws.bands;
+        c.nrows = TH / ws.bands;
+        c.row0 = (wg % ws.bands) * c.nrows;
         const int per_img = tiles_w * tiles_h;
         c.n = t / per_img;
         const int rem = t - c.n * per_img;
@@ -136,21 +172,17 @@ __global__ __launch_bounds__(NTHR) void conv3x3_c64_kernel(const ConvArgs p) {
         const bf16_t* org = x + (((long long)c.n * p.Hin + h0) * p.Win + w0) * p.ldx;
         unsigned char* dst = sP + buf * PATCH_B;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
+        for (int i = 0; i < NPASS; ++i) {
             const int py = pyx[i] & 255;
-            // wave-uniform cut: the patch is filled in pixel order, so whole 1 KB pieces beyond its last row are skipped
-            if (((wave * 64 + NTHR * i) >> 3) >= prow * PW) break;
-            if (py >= prow) continue;                      // lanes past the patch's last pixel stay masked: no LDS write at all
+            if (((wave * 64 + NTHR * i) >> 3) >= prow * PW) break;         // wave-uniform: whole 1 KB pieces past the patch
+            if (py >= prow) continue;                                     // lanes past the last pixel: no LDS write
             const int h = h0 + py, ww = w0 + (pyx[i] >> 8);
             const void* src = ((unsigned)h < (unsigned)p.Hin && (unsigned)ww < (unsigned)p.Win) ? (const void*)(org + prel[i]) : (const void*)zero;
             glds16(src, dst + (wave * 64 + NTHR * i) * 16);
         }
     };
 
-    // Per-lane LDS byte offsets, computed once: with the patch swizzle keyed on the patch column (fr + s) and the filter
-    // swizzle on the filter row, every fragment address is lane_offset + compile-time constant, so the fragment reads carry no
-    // address VALU at all.  (The wave's first patch row, wm * rows-per-wave, is added to the wave-uniform base pointer.)
-    int aoff[3][2], boff[2][2];
+    int aoff[3][2];
 #pragma unroll
     for (int s = 0; s < 3; ++s)
 #pragma unroll
@@ -158,100 +190,86 @@ __global__ __launch_bounds__(NTHR) void conv3x3_c64_kernel(const ConvArgs p) {
             const int px = fr + s;
             aoff[s][ks] = px * 128 + (((ks * 4 + fq) ^ (((px >> 1) & 3) << 1)) << 4);
         }
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int k = wn * 32 + b * 16 + fr;
-            boff[b][ks] = k * 128 + (((ks * 4 + fq) ^ ((k >> 1) & 7)) << 4);
-        }
 
-    float sc[2][4], sh[2][4], s1[2][4], s2[2][4];
+    float sc[4], sh[4], s1[4], s2[4];
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int c = wn * 32 + b * 16 + fq * 4 + r;
-            sc[b][r] = (p.scale && c < p.K) ? p.scale[c] : 1.0f;
-            sh[b][r] = (p.shift && c < p.K) ? p.shift[c] : 0.0f;
-            s1[b][r] = 0.f;
-            s2[b][r] = 0.f;
-        }
-    // epilogue staging: item pixel row -> 128 bytes; 8-byte slot XOR (row & 14) makes the 16 lanes of a write hit 16 different
-    // slots (rows of equal slot differ in parity = in 128-byte half of the bank line); the 16-byte read-back sees whole chunks
-    const int st_ch = tid & 7, st_rr = tid >> 3;                              // store phase: chunk, first row (rows + 64 j)
+    for (int r = 0; r < 4; ++r) {
+        const int c = wave * 16 + fq * 4 + r;
+        sc[r] = (p.scale && c < p.K) ? p.scale[c] : 1.0f;
+        sh[r] = (p.shift && c < p.K) ? p.shift[c] : 0.0f;
+        s1[r] = 0.f;
+        s2[r] = 0.f;
+    }
+    const int st_ch = tid & 7, st_rr = tid >> 3;                              // store phase: chunk, first row (rows + 32 j)
     const int st_lds = st_rr * 128 + ((st_ch ^ ((st_rr >> 1) & 7)) << 4);
     const long long st_off = ((long long)(st_rr >> 4) * p.Wo + (st_rr & 15)) * p.ldy + st_ch * 8;
-    const long long st_step = (long long)4 * p.Wo * p.ldy;
+    const long long st_step = (long long)2 * p.Wo * p.ldy;
     const long long rs_off = ((long long)(st_rr >> 4) * p.Wo + (st_rr & 15)) * p.ldr + st_ch * 8;
-    const long long rs_step = (long long)4 * p.Wo * p.ldr;
-    int ep_off[2];
-#pragma unroll
-    for (int b = 0; b < 2; ++b) ep_off[b] = fr * 128 + (((wn * 8 + b * 4 + fq) ^ (fr & 14)) << 3);
+    const long long rs_step = (long long)2 * p.Wo * p.ldr;
+    const int ep_off = fr * 128 + (((wave * 4 + fq) ^ (fr & 14)) << 3);
 
-    // ---- one item: AR = tile rows per wave (the item has 4*AR rows, wave wm owns rows wm*AR .. wm*AR + AR-1)
+    // ---- one item of AR rows (every wave covers all rows for its 16 channels)
     auto compute = [&](auto ar_c, const Item& it, int cur) {
         constexpr int AR = decltype(ar_c)::value;
-        f32x4 acc[AR][2];
+        f32x4 acc[AR];
 #pragma unroll
-        for (int a = 0; a < AR; ++a)
+        for (int a = 0; a < AR; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const unsigned char* pb = sP + cur * PATCH_B;
+        // Software pipeline by hand: the next 3 fragments (half a patch row) are requested before the 9 MFMAs of the current 3 start,
+        // and the scheduler is fenced from sinking them next to their uses (left alone it emits read -> wait -> 3 MFMAs, which
+        // leaves a lone wave LDS-latency bound: 4.4k instead of 3.0k cycles per 8-row item; 2.3k is the MFMA rate).
+        V16 fa[2][3];
+        auto load_half = [&](int g, V16* f) {            // group g = (patch row g >> 1, k-half g & 1): its 3 column shifts
 #pragma unroll
-            for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const unsigned char* pb = sP + cur * PATCH_B + wm * AR * PW * 128;
+            for (int s = 0; s < 3; ++s) f[s].i = *(const i32x4*)(pb + aoff[s][g & 1] + (g >> 1) * PW * 128);
+        };
+        load_half(0, fa[0]);
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int r = tap / 3, s = tap - 3 * r;
+        for (int g = 0; g < 2 * (AR + 2); ++g) {         // patch row q serves tile row a with filter row r = q - a
+            const int q = g >> 1, ks = g & 1;
+            if (g + 1 < 2 * (AR + 2)) load_half(g + 1, fa[(g + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                V16 af[AR], bf[2];
+            for (int s = 0; s < 3; ++s)
 #pragma unroll
-                for (int a = 0; a < AR; ++a)     // item row wm*AR + a, patch row + r: a compile-time offset from the lane base
-                    af[a].i = *(const i32x4*)(pb + aoff[s][ks] + (a + r) * PW * 128);
-#pragma unroll
-                for (int b = 0; b < 2; ++b) bf[b].i = *(const i32x4*)(sW + boff[b][ks] + tap * 64 * 128);
-#pragma unroll
-                for (int a = 0; a < AR; ++a)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[b].h, af[a].h, acc[a][b], 0, 0, 0);
-            }
+                for (int r = 0; r < 3; ++r) {
+                    const int a = q - r;
+                    if (a >= 0 && a < AR) acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[r * 3 + s][ks].h, fa[g & 1][s].h, acc[a], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();                                   // everyone is done with patch `cur`: it becomes scratch
-        unsigned char* scratch = sP + cur * PATCH_B;
-        if (p.stats) {
+        if (STATS) {
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int a = 0; a < AR; ++a)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float v = acc[a][b][r];
-                        s1[b][r] += v;
-                        s2[b][r] = __builtin_fmaf(v, v, s2[b][r]);
-                    }
-        }
-#pragma unroll
-        for (int a = 0; a < AR; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                float v[4];
+            for (int a = 0; a < AR; ++a)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    v[r] = acc[a][b][r];
-                    if (EPI >= 1) v[r] = v[r] * sc[b][r] + sh[b][r];
-                    if (EPI == 2) v[r] = v[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[r]));     // SiLU; 1 ulp, then rounded to bf16
+                    const float v = acc[a][r];
+                    s1[r] += v;
+                    s2[r] = __builtin_fmaf(v, v, s2[r]);
                 }
-                bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-                *(bf16x4*)(scratch + ep_off[b] + (wm * AR + a) * 16 * 128) = o;
+        }
+        // the staging tile is separate from the patches: no barrier between a wave's last MFMA and its staging writes
+#pragma unroll
+        for (int a = 0; a < AR; ++a) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[a][r];
+                if (EPI >= 1) v[r] = v[r] * sc[r] + sh[r];
+                if (EPI == 2) v[r] = v[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[r]));     // SiLU; 1 ulp, then rounded to bf16
             }
-        __syncthreads();
+            bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+            *(bf16x4*)(sS + ep_off + a * 16 * 128) = o;
+        }
+        __syncthreads();                                   // staging complete; every wave is done with patch `cur`
         if (st_ch * 8 < p.K) {
             const long long org = (((long long)it.n * p.Ho + it.th * TH + it.row0) * p.Wo + it.tw * TW);
             bf16_t* yb = (bf16_t*)p.y + org * p.ldy + st_off;
             const bf16_t* rb = p.res ? (const bf16_t*)p.res + org * p.ldr + rs_off : nullptr;
 #pragma unroll
-            for (int j = 0; j < AR; ++j) {                 // 64 pixel rows of 128 bytes per pass
+            for (int j = 0; j < AR / 2; ++j) {             // 32 pixel rows of 128 bytes per pass
                 V16 v;
-                v.i = *(const i32x4*)(scratch + st_lds + j * 64 * 128);
+                v.i = *(const i32x4*)(sS + st_lds + j * 32 * 128);
                 if (p.res || p.accumulate) {
                     float f[8];
 #pragma unroll
@@ -274,13 +292,12 @@ __global__ __launch_bounds__(NTHR) void conv3x3_c64_kernel(const ConvArgs p) {
                 *(i32x4*)(yb + j * st_step) = v.i;
             }
         }
-        // the next patch's DMA was issued before this item's AR row stores, and vmcnt retires in issue order: leaving the
-        // stores in flight (instead of vmcnt(0)) keeps their ~2 us write latency off the critical path
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AR) : "memory");
-        __syncthreads();
+        // the next patch's DMA precedes these AR/2 stores in the wave's vm queue: wait for it, not for the stores
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AR / 2) : "memory");
+        __syncthreads();                                   // next patch landed for everyone; staging tile free again
     };
 
-    Item cur_it = item_at(0);
+    Item cur_it = first_item();
     issue_patch(cur_it, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -288,47 +305,46 @@ __global__ __launch_bounds__(NTHR) void conv3x3_c64_kernel(const ConvArgs p) {
     for (int idx = 0; idx < nitems; ++idx) {
         Item nxt_it = cur_it;
         if (idx + 1 < nitems) {
-            nxt_it = item_at(idx + 1);
+            nxt_it = item_after(cur_it, idx);
             issue_patch(nxt_it, cur ^ 1);
         }
-        if (cur_it.nrows == 16) compute(std::integral_constant<int, 4>{}, cur_it, cur);
-        else if (cur_it.nrows == 8) compute(std::integral_constant<int, 2>{}, cur_it, cur);
-        else compute(std::integral_constant<int, 1>{}, cur_it, cur);
+        if (cur_it.nrows == 8) compute(std::integral_constant<int, 8>{}, cur_it, cur);
+        else if (cur_it.nrows == 4) compute(std::integral_constant<int, 4>{}, cur_it, cur);
+        else compute(std::integral_constant<int, 2>{}, cur_it, cur);
         cur ^= 1;
         cur_it = nxt_it;
     }
 
-    if (p.stats) {
-        // one slab per workgroup: 16 pixel lanes -> 4 tile-row groups (waves) -> global
-        float* red = (float*)sP;                           // [4 (wm)][64][2]; every patch buffer is idle after the last barrier
+    if (STATS) {                                           // a wave's channels are its own: 16 pixel lanes -> one value, no LDS
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int r = 0; r < 4; ++r) {
+            float u = s1[r], q = s2[r];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float u = s1[b][r], q = s2[b][r];
-#pragma unroll
-                for (int m = 1; m < 16; m <<= 1) {
-                    u += __shfl_xor(u, m);
-                    q += __shfl_xor(q, m);
-                }
-                if (fr == 0) {
-                    const int c = wn * 32 + b * 16 + fq * 4 + r;
-                    red[(wm * 64 + c) * 2 + 0] = u;
-                    red[(wm * 64 + c) * 2 + 1] = q;
-                }
+            for (int m = 1; m < 16; m <<= 1) {
+                u += __shfl_xor(u, m);
+                q += __shfl_xor(q, m);
             }
-        __syncthreads();
-        if (tid < 128 && (tid & 63) < p.K) {
-            const int which = tid >> 6, c = tid & 63;
-            float v = 0.f;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) v += red[(g * 64 + c) * 2 + which];
-            p.stats[((size_t)wg * 2 + which) * p.K + c] = v;
+            const int c = wave * 16 + fq * 4 + r;
+            if (fr == 0 && c < p.K) {
+                p.stats[((size_t)wg * 2 + 0) * p.K + c] = u;
+                p.stats[((size_t)wg * 2 + 1) * p.K + c] = q;
+            }
         }
     }
 }
 
+template <int EPI, bool STATS>
+static void launch_c3(const ConvArgs& a, int grid, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_c64_kernel<EPI, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv3x3_c64_kernel<EPI, STATS>), dim3(grid), dim3(NTHR), SMEM_B, st, a);
+}
+
 }  // namespace
+
 
 // Shape test shared by the launcher and the statistics-slab query (the two must agree on who writes the slabs).
 static bool conv3x3_shape_ok(int C, int K, int R, int S, int stride, int pad, int H, int W, int dtype) {
@@ -338,9 +354,9 @@ static bool conv3x3_shape_ok(int C, int K, int R, int S, int stride, int pad, in
 }
 
 static int conv3x3_grid(int tiles) {
-    static const int g = getenv("HDY_C3_GRID") ? atoi(getenv("HDY_C3_GRID")) : 256;
+    static const int g = getenv("HDY_C3_GRID") ? atoi(getenv("HDY_C3_GRID")) : 512;
     return tiles < g ? tiles : g;
-}     // one 153 KB, 8-wave workgroup per CU
+}     // two 61 KB, 4-wave workgroups per CU
 
 // Number of statistic slabs the filter-resident kernel writes for this shape (one per workgroup), 0 = not eligible.
 int hdy_conv3x3_c64_slabs(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dtype) {
@@ -362,19 +378,17 @@ int hdy_conv3x3_c64_try(const ConvArgs& a, int dtype, int out_f32, hipStream_t s
         *rc = HDY_EINVAL;
         return 1;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_c64_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B);
-        (void)hipFuncSetAttribute((const void*)conv3x3_c64_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B);
-        (void)hipFuncSetAttribute((const void*)conv3x3_c64_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B);
-        attr_set = true;
-    }
-    const int tiles = a.N * (a.Ho / TH) * (a.Wo / TW);
-    const int grid = conv3x3_grid(tiles);
+    const int grid = conv3x3_grid(a.N * (a.Ho / TH) * (a.Wo / TW));
     const int epi = a.act == 1 ? 2 : ((a.scale || a.shift) ? 1 : 0);
-    if (epi == 2) hipLaunchKernelGGL(conv3x3_c64_kernel<2>, dim3(grid), dim3(NTHR), SMEM_B, st, a);
-    else if (epi == 1) hipLaunchKernelGGL(conv3x3_c64_kernel<1>, dim3(grid), dim3(NTHR), SMEM_B, st, a);
-    else hipLaunchKernelGGL(conv3x3_c64_kernel<0>, dim3(grid), dim3(NTHR), SMEM_B, st, a);
+    if (a.stats) {
+        if (epi == 2) launch_c3<2, true>(a, grid, st);
+        else if (epi == 1) launch_c3<1, true>(a, grid, st);
+        else launch_c3<0, true>(a, grid, st);
+    } else {
+        if (epi == 2) launch_c3<2, false>(a, grid, st);
+        else if (epi == 1) launch_c3<1, false>(a, grid, st);
+        else launch_c3<0, false>(a, grid, st);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         hdy_set_error("conv3x3_c64: launch failed: %s", hipGetErrorString(e));

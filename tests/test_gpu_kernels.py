@@ -62,9 +62,10 @@ CONV_CASES = [
     (2, 20, 20, 32, 64, 3, 2, 1),
     (1, 18, 14, 64, 128, 3, 2, 1),
     (3, 40, 40, 256, 512, 1, 1, 0),
-    (2, 16, 32, 64, 64, 3, 1, 1),        # qualifies for the filter-resident 3x3 kernel (bf16): C=64, H%16==0, W%16==0
+    (2, 16, 32, 64, 64, 3, 1, 1),        # qualifies for the filter-resident 3x3 kernel (bf16): C=64, H%8==0, W%16==0
     (3, 32, 48, 64, 32, 3, 1, 1),
-    # filter-resident kernel, more tiles than CUs: 320 tiles = 1 whole + a 4-row band per workgroup; 352 -> 8-row bands; 416 -> whole
+    (2, 24, 32, 64, 64, 3, 1, 1),        # H % 16 != 0
+    # filter-resident kernel, more 8x16 tiles than its 512 workgroups: 640 tiles = 1 whole + a 2-row band each; 704 -> 4-row bands; 832 -> whole
     (5, 128, 128, 64, 64, 3, 1, 1),
     (2, 176, 256, 64, 48, 3, 1, 1),
     (2, 208, 256, 64, 64, 3, 1, 1),
