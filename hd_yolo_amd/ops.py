@@ -414,7 +414,7 @@ class DetLossCall:
         self.lp = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in logits])
         self.gp = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in gdets])
         self.anc = (ctypes.c_float * (nl * na * 2))(*[float(v) for v in anchors_grid])
-        self.bal = (ctypes.c_float * nl)(*[float(v) for v in balance])
+        self.bal = (ctypes.c_float * nl)(*[float(v) for v in list(balance)[:nl]])    # nl = 4 takes the first 4 of the 5-level table (loss.py:201)
         self.cw = (ctypes.c_float * nc)(*[float(v) for v in cls_cw])
         self.hyp = hyp
         self.dtype = dcode(gdets[0].dtype)

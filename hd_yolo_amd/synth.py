@@ -19,10 +19,16 @@ import torch
 VARIANTS = {'n': (0.33, 0.25), 's': (0.33, 0.50), 'm': (0.67, 0.75), 'l': (1.0, 1.0)}
 
 ANCHORS_P5 = [[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]]
+# the 4-level anchors of the reference's own metayolo-schema files (metayolo/hub/yolov5m6-multihead.yaml:7-11)
+ANCHORS_P6 = [[19, 27, 44, 40, 38, 94], [96, 68, 86, 152, 180, 137], [140, 301, 303, 264, 238, 542], [436, 615, 739, 380, 925, 792]]
 
 
 def make_cfg(variant='s', nc=8):
-    """metayolo-schema P5 config (backbone + fpn + headers); SURVEY.md Appendix A."""
+    """metayolo-schema config (backbone + fpn + headers); SURVEY.md Appendix A.  'n' / 's' / 'm' / 'l' = 3-level P5 graph;
+    a trailing '6' ('n6', 'm6', 'l6') = the 4-level P6 graph of the files the reference ships
+    (metayolo/hub/yolov5{m6,l6}-multihead.yaml, yolov5l6-mask.yaml)."""
+    if variant.endswith('6'):
+        return make_cfg_p6(variant[:-1], nc)
     gd, gw = VARIANTS[variant]
     cfg = {
         'depth_multiple': gd, 'width_multiple': gw,
@@ -60,6 +66,55 @@ def make_cfg(variant='s', nc=8):
         ],
     }
     return cfg
+
+
+def make_cfg_p6(variant='m', nc=8):
+    """Layer list of metayolo/hub/yolov5m6-multihead.yaml:13-66 (P3-P6 outputs, strides 8-64)."""
+    gd, gw = VARIANTS[variant]
+    return {
+        'depth_multiple': gd, 'width_multiple': gw,
+        'anchors': deepcopy(ANCHORS_P6),
+        'backbone': [
+            [-1, 1, 'Conv', [64, 6, 2, 2]],
+            [-1, 1, 'Conv', [128, 3, 2]],
+            [-1, 3, 'C3', [128]],
+            [-1, 1, 'Conv', [256, 3, 2]],
+            [-1, 6, 'C3', [256]],
+            [-1, 1, 'Conv', [512, 3, 2]],
+            [-1, 9, 'C3', [512]],
+            [-1, 1, 'Conv', [768, 3, 2]],
+            [-1, 3, 'C3', [768]],
+            [-1, 1, 'Conv', [1024, 3, 2]],
+            [-1, 3, 'C3', [1024]],
+            [-1, 1, 'SPPF', [1024, 5]],
+        ],
+        'fpn': [
+            [11, 1, 'Conv', [768, 1, 1]],
+            [-1, 1, 'nn.Upsample', [None, 2, 'nearest']],
+            [[-1, 8], 1, 'Concat', [1]],
+            [-1, 3, 'C3', [768, False]],
+            [-1, 1, 'Conv', [512, 1, 1]],
+            [-1, 1, 'nn.Upsample', [None, 2, 'nearest']],
+            [[-1, 6], 1, 'Concat', [1]],
+            [-1, 3, 'C3', [512, False]],
+            [-1, 1, 'Conv', [256, 1, 1]],
+            [-1, 1, 'nn.Upsample', [None, 2, 'nearest']],
+            [[-1, 4], 1, 'Concat', [1]],
+            [-1, 3, 'C3', [256, False], 'P3'],
+            [-1, 1, 'Conv', [256, 3, 2]],
+            [[-1, 20], 1, 'Concat', [1]],
+            [-1, 3, 'C3', [512, False], 'P4'],
+            [-1, 1, 'Conv', [512, 3, 2]],
+            [[-1, 16], 1, 'Concat', [1]],
+            [-1, 3, 'C3', [768, False], 'P5'],
+            [-1, 1, 'Conv', [768, 3, 2]],
+            [[-1, 12], 1, 'Concat', [1]],
+            [-1, 3, 'C3', [1024, False], 'P6'],
+        ],
+        'headers': [
+            [[23, 26, 29, 32], 1, 'Detect', ['anchors', [8.0, 16.0, 32.0, 64.0], nc, -1], 'det'],
+        ],
+    }
 
 
 def make_hyp(conf_thres=0.15, iou_thres=0.45, max_det=300, multi_label=False):

@@ -172,10 +172,12 @@ def gen_stages(tag, variant, nc, batch, size, full=True):
 GRAD_KEYS = ['backbone.0.conv.weight', 'backbone.1.conv.weight', 'backbone.2.m.0.cv2.conv.weight',
              'backbone.2.cv3.conv.weight', 'backbone.2.cv1.bn.weight', 'backbone.2.cv1.bn.bias',
              'backbone.9.cv2.conv.weight', 'neck.3.cv3.conv.weight', 'neck.8.conv.weight',
-             'headers.det.m.0.weight', 'headers.det.m.0.bias', 'headers.det.m.2.weight']
+             'headers.det.m.0.weight', 'headers.det.m.0.bias', 'headers.det.m.2.weight',
+             'headers.det.m.3.weight', 'headers.det.m.3.bias', 'neck.16.conv.weight']       # (keys absent from a graph are skipped)
 STAT_KEYS = ['backbone.0.bn.running_mean', 'backbone.0.bn.running_var',
              'backbone.4.m.1.cv2.bn.running_mean', 'backbone.4.m.1.cv2.bn.running_var',
-             'neck.13.cv3.bn.running_mean', 'neck.13.cv3.bn.running_var']
+             'neck.13.cv3.bn.running_mean', 'neck.13.cv3.bn.running_var',
+             'neck.20.cv3.bn.running_mean', 'neck.20.cv3.bn.running_var']
 
 
 def gen_train(tag, variant, nc, batch, size, nmin, nmax):
@@ -193,10 +195,11 @@ def gen_train(tag, variant, nc, batch, size, nmin, nmax):
         out[f'loss_{k}'] = npf(v)
     sd = model.state_dict()
     for k in STAT_KEYS:
-        out['stat:' + k] = npf(sd[k])
+        if k in sd:
+            out['stat:' + k] = npf(sd[k])
     params = dict(model.named_parameters())
     for k in GRAD_KEYS:
-        if params[k].numel() <= 40000:      # keep fixtures small; gradsum below covers the rest
+        if k in params and params[k].numel() <= 40000:      # keep fixtures small; gradsum below covers the rest
             out['grad:' + k] = npf(params[k].grad)
     # one (sum, abs-sum, l2) triple per parameter: catches a wrong gradient anywhere
     names, sums = [], []
@@ -467,6 +470,10 @@ def main():
     assert os.path.isdir(REF), 'the reference is only mounted in the build container'
     torch.set_num_threads(8)
     install_shims()
+    if sys.argv[1:] == ['p6']:                 # only the P6 fixtures (the others are unchanged by construction)
+        gen_stages('n6_128', 'n6', 3, 2, 128, full=False)
+        gen_train('n6_128', 'n6', 3, 2, 128, 4, 12)
+        return
     gen_keys()
     gen_decode()
     gen_outputs()
@@ -474,6 +481,9 @@ def main():
     gen_stages('s_128', 's', 8, 1, 128, full=False)
     gen_train('n_64', 'n', 2, 2, 64, 3, 8)
     gen_train('s_128', 's', 8, 2, 128, 10, 30)
+    # the 4-level P6 graph of the reference's own hub files (yolov5m6-multihead.yaml), at 'n' widths
+    gen_stages('n6_128', 'n6', 3, 2, 128, full=False)
+    gen_train('n6_128', 'n6', 3, 2, 128, 4, 12)
     gen_f3()
     gen_nms_options()
     gen_masks()

@@ -36,7 +36,7 @@ def test_state_dict_surface(golden_dir, v, nc):
                for k in extra), extra
 
 
-@pytest.mark.parametrize('tag,v', [('n_64', 'n'), ('s_128', 's')])
+@pytest.mark.parametrize('tag,v', [('n_64', 'n'), ('s_128', 's'), ('n6_128', 'n6')])
 def test_eval_stages(golden_dir, tag, v):
     g = load(golden_dir, f'stages_{tag}.npz')
     batch, size, nc = (int(t) for t in g['meta'])
@@ -50,7 +50,8 @@ def test_eval_stages(golden_dir, tag, v):
             close(feats[int(k[6:])], g[k], rtol=1e-4, atol=1e-5)
         elif k.startswith('neck_'):
             close(feats[int(k[5:])], g[k], rtol=1e-4, atol=1e-5)
-    for i in range(3):
+    assert len(dets) == sum(k.startswith('det_') for k in g.files)
+    for i in range(len(dets)):
         close(dets[i], g[f'det_{i}'], rtol=1e-4, atol=1e-5)
         close(preds[i], g[f'pred_{i}'], rtol=1e-4, atol=1e-4)
     for b in range(batch):
@@ -112,7 +113,7 @@ def test_outputs_logic(golden_dir, tag, ml):
         assert seen_unclassified, 'fixture must exercise the -100 label branch'
 
 
-@pytest.mark.parametrize('tag,v', [('n_64', 'n'), ('s_128', 's')])
+@pytest.mark.parametrize('tag,v', [('n_64', 'n'), ('s_128', 's'), ('n6_128', 'n6')])
 def test_train_loss_and_grads(golden_dir, tag, v):
     g = load(golden_dir, f'train_{tag}.npz')
     batch, size, nc, nmin, nmax = (int(t) for t in g['meta'])
