@@ -115,7 +115,22 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const ST* __restrict_
     const int k = blockIdx.x * 32 + cl;
     double s = 0.0, ss = 0.0;
     if (k < K) {
-        for (int t = tl; t < mtiles; t += 32) {
+        // the whole kernel is one chain of load latencies: keep 8 independent loads in flight per lane
+        int t = tl;
+        for (; t + 96 < mtiles; t += 128) {
+            ST a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a[u] = stats[((size_t)(t + 32 * u) * 2 + 0) * stats_ld + k];
+                b[u] = stats[((size_t)(t + 32 * u) * 2 + 1) * stats_ld + k];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                s += (double)a[u];
+                ss += (double)b[u];
+            }
+        }
+        for (; t < mtiles; t += 32) {
             s += (double)stats[((size_t)t * 2 + 0) * stats_ld + k];
             ss += (double)stats[((size_t)t * 2 + 1) * stats_ld + k];
         }
@@ -272,7 +287,21 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
     const int k = blockIdx.x * 32 + cl;
     double s1 = 0.0, s2 = 0.0;
     if (k < K) {
-        for (int t = tl; t < nblocks; t += 32) {
+        int t = tl;
+        for (; t + 96 < nblocks; t += 128) {              // 8 independent loads in flight per lane (see bn_finalize_kernel)
+            float a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a[u] = partial[((size_t)(t + 32 * u) * 2 + 0) * K + k];
+                b[u] = partial[((size_t)(t + 32 * u) * 2 + 1) * K + k];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                s1 += (double)a[u];
+                s2 += (double)b[u];
+            }
+        }
+        for (; t < nblocks; t += 32) {
             s1 += (double)partial[((size_t)t * 2 + 0) * K + k];
             s2 += (double)partial[((size_t)t * 2 + 1) * K + k];
         }
