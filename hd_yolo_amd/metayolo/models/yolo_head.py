@@ -274,7 +274,10 @@ class Detect(nn.Module):
             torch._foreach_clamp_max_(boxes, 1.0)
         counts = [int(b.shape[0]) for b in boxes]
         allb = torch.cat(boxes).to(dev) if boxes else torch.zeros((0, 4), device=dev)
-        img = torch.repeat_interleave(torch.arange(len(boxes), dtype=allb.dtype), torch.tensor(counts)).to(dev)   # one small upload
+        # one small upload, through pinned memory and non-blocking: a pageable .to(dev) makes the host wait for everything queued so
+        # far (the previous step's backward), after which the GPU idles until the forward launches arrive: 16.5 -> 15.9 ms per bench step
+        img = torch.repeat_interleave(torch.arange(len(boxes), dtype=allb.dtype), torch.tensor(counts))
+        img = (img.pin_memory() if dev.type == 'cuda' else img).to(dev, non_blocking=True)
         gts = torch.stack([img, (allb[:, 0] + allb[:, 2]) / 2, (allb[:, 1] + allb[:, 3]) / 2, allb[:, 2] - allb[:, 0],
                            allb[:, 3] - allb[:, 1]], 1)
         labs = [t['labels'] for t in targets]
