@@ -92,7 +92,7 @@ def conv_roofline(device, iters=30):
             'us_per_launch': round(t * 1e6, 2), 'algorithmic_gflop_per_launch': round(flops / 1e9, 2)}
 
 
-def cpu_baseline(variant, nc, size, tiles=4, iters=2):
+def cpu_baseline(variant, nc, size, tiles=8, iters=16):
     """Reference-path port on the host: oracle train step (forward + DetLoss + backward) on `tiles` 640x640 tiles."""
     from oracle.ref_net import RefNet
     from hd_yolo_amd import host_cpu_quota
