@@ -28,6 +28,10 @@ namespace {
 
 constexpr int MAXL = 5, MAXA = 8, MAXC = 128;
 
+template <typename T> struct Quad;                        // 4 consecutive channels in memory
+template <> struct Quad<float> { typedef f32x4 type; };
+template <> struct Quad<bf16_t> { typedef bf16x4 type; };
+
 struct D4 {            // value + 4 partial derivatives (w.r.t. px, py, pw, ph)
     float v, d[4];
 };
@@ -168,6 +172,9 @@ __global__ __launch_bounds__(256) void match_kernel(const LossArgs p, int l) {
     if (threadIdx.x < 4 && sh[threadIdx.x][0] != 0.0) atomicAdd(p.acc + l * 6 + threadIdx.x, sh[threadIdx.x][0]);
 }
 
+// One lane per (cell, 4-channel group): the accumulated gradients are read as 16-byte vectors and the logits gradient leaves as 8-
+// (bf16) or 16-byte (fp32) vectors, lanes of a wave covering consecutive addresses.  (One lane per cell walking its 40 channels with
+// scalar accesses 160 bytes apart took 87 us per level on average.)  Requires ldl % 4 == 0 and ldg % 4 == 0 (checked by the launcher).
 template <typename T>
 __global__ __launch_bounds__(256) void dense_kernel(const LossArgs p, int l) {
     const int na = p.na, no = p.no, ny = p.ny[l], nx = p.nx[l];
@@ -178,29 +185,40 @@ __global__ __launch_bounds__(256) void dense_kernel(const LossArgs p, int l) {
     const float k_cls = n_cls > 0 ? bs * p.h_cls / (float)(n_cls * p.nc) : 0.f;
     const float k_obj = bs * p.h_obj * p.balance[l] / (float)(cells * na);
     T* gd = (T*)p.gdet[l];
+    const int groups = p.ldg / 4;                          // 4-channel groups per cell (padding channels included)
+    const long long items = cells * groups;
     double s_obj = 0.0;
-    for (long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x; pix < cells; pix += (long long)gridDim.x * blockDim.x) {
-        const int x = (int)(pix % nx);
-        const long long t = pix / nx;
-        const int y = (int)(t % ny);
-        const int b = (int)(t / ny);
-        const float* lg = p.logits[l] + pix * p.ldl;
-        const float* gr = p.scratch[l] + pix * p.ldl;
-        T* out = gd + pix * p.ldg;
-        for (int a = 0; a < na; ++a) {
-            const unsigned long long pk = p.tobj[l][(((size_t)b * na + a) * ny + y) * nx + x];
-            const float tgt = pk ? __uint_as_float((unsigned)(pk & 0xFFFFFFFFull)) : 0.f;
-            float go;
-            s_obj += (double)bce(lg[a * no + 4], tgt, p.obj_pw, &go);
-            for (int o = 0; o < no; ++o) {
-                float v;
-                if (o == 4) v = go * k_obj;
-                else if (o < 4) v = gr[a * no + o] * k_box;
-                else v = gr[a * no + o] * k_cls;
-                out[a * no + o] = from_f32<T>(v);
+    for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long long)gridDim.x * blockDim.x) {
+        const long long pix = it / groups;
+        const int c0 = (int)(it - pix * groups) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c0 < p.ldl) {
+            const f32x4 gr = *(const f32x4*)(p.scratch[l] + pix * p.ldl + c0);
+            int a = c0 / no, o = c0 - a * no;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (a < na) {
+                    if (o == 4) {
+                        const int x = (int)(pix % nx);
+                        const long long t = pix / nx;
+                        const int y = (int)(t % ny), b = (int)(t / ny);
+                        const unsigned long long pk = p.tobj[l][(((size_t)b * na + a) * ny + y) * nx + x];
+                        const float tgt = pk ? __uint_as_float((unsigned)(pk & 0xFFFFFFFFull)) : 0.f;
+                        float go;
+                        s_obj += (double)bce(p.logits[l][pix * p.ldl + c0 + i], tgt, p.obj_pw, &go);
+                        v[i] = go * k_obj;
+                    } else {
+                        v[i] = gr[i] * (o < 4 ? k_box : k_cls);
+                    }
+                }
+                if (++o == no) {
+                    o = 0;
+                    ++a;
+                }
             }
         }
-        for (int c = na * no; c < p.ldg; ++c) out[c] = from_f32<T>(0.f);
+        typename Quad<T>::type out = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
+        *(typename Quad<T>::type*)(gd + pix * p.ldg + c0) = out;
     }
     __shared__ double sh[256];
     sh[threadIdx.x] = s_obj;
@@ -257,7 +275,7 @@ int hdy_det_loss(const float* const* logits, int ldl, void* const* gdet, int ldg
     HDY_ARG(nl >= 1 && nl <= MAXL && na >= 1 && na <= MAXA && nc >= 1 && nc <= MAXC && B >= 1 && nt >= 0, "det_loss: bad sizes");
     HDY_ARG(nt == 0 || (gts && tcls), "det_loss: targets missing");
     const int no = nc + 5;
-    HDY_ARG(ldl >= na * no && ldg >= na * no && ldl % 4 == 0, "det_loss: pitches too small");
+    HDY_ARG(ldl >= na * no && ldg >= na * no && ldl % 4 == 0 && ldg % 4 == 0, "det_loss: pitches too small or not multiples of 4");
     HDY_ARG(ws_bytes >= hdy_det_loss_workspace_bytes(nl, ny, nx, B, na, ldl) && ((uintptr_t)workspace & 15) == 0, "det_loss: workspace too small / unaligned");
     HDY_ARG(dtype == HDY_BF16 || dtype == HDY_F32, "det_loss: unknown dtype");
     HDY_ARG((long long)5 * na * nt < (1LL << 31), "det_loss: too many targets");
@@ -289,8 +307,8 @@ int hdy_det_loss(const float* const* logits, int ldl, void* const* gdet, int ldg
         HDY_LAUNCH_CHECK("det_loss match");
     }
     for (int l = 0; l < nl; ++l) {
-        const long long cells = (long long)B * ny[l] * nx[l];
-        const int grid = (int)((cells + 255) / 256 < 2048 ? (cells + 255) / 256 : 2048);
+        const long long items = (long long)B * ny[l] * nx[l] * (ldg / 4);
+        const int grid = (int)((items + 255) / 256 < 4096 ? (items + 255) / 256 : 4096);
         if (dtype == HDY_BF16) hipLaunchKernelGGL(dense_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, a, l);
         else hipLaunchKernelGGL(dense_kernel<float>, dim3(grid), dim3(256), 0, st, a, l);
         HDY_LAUNCH_CHECK("det_loss dense");

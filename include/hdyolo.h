@@ -177,7 +177,8 @@ int hdy_cast_store(const float* src, void* dst, int ldd, long long M, int C, int
  * Replaces Detect.matcher (metayolo/models/yolo_head.py:358-417), DetLoss.forward (metayolo/models/loss.py:190-244) with
  * bbox_iou(CIoU) (metayolo/models/utils_general.py:193-231) and their autograd backward: target assignment, CIoU box loss,
  * objectness / class BCE, and the gradient w.r.t. the logits, written into the NHWC buffers the backward plan consumes.
- * logits[l]: fp32 [B][ny][nx][ldl], channel a*no+o;  gdet[l]: dtype [B][ny][nx][ldg];  anchors_grid: nl*na*2 HOST floats in grid
+ * logits[l]: fp32 [B][ny][nx][ldl], channel a*no+o;  gdet[l]: dtype [B][ny][nx][ldg] (ldl, ldg multiples of 4, 16-byte aligned
+ * bases; channels >= na*no of gdet are written as zero);  anchors_grid: nl*na*2 HOST floats in grid
  * units; balance: nl HOST floats; gts: device [nt][5] (img, cx, cy, w, h normalised); tcls: device [nt][nc] class targets;
  * cls_cw: nc HOST floats.  out: device [4] = loss (x batch), box, obj, cls items.  Supported: fl_gamma = 0, no autobalance. */
 size_t hdy_det_loss_workspace_bytes(int nl, const int* ny, const int* nx, int B, int na, int ldl);
