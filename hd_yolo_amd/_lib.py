@@ -39,6 +39,9 @@ SIGNATURES = {
     'hdy_bn_eval_coeffs': (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
     'hdy_bn_act_fwd': (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _L, _I, _I, _I, _P]),
     'hdy_bn_bwd_blocks': (_I, [_L]),
+    'hdy_bn_finalize_pair': (_I, [_P, _I, _I, _I, _I, _L] + [_P] * 8 + [_F, _F, _P, _P, _P, _P, _P, _P]),
+    'hdy_bn_act_fwd_pair': (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _L, _I, _I, _I, _P]),
+    'hdy_bn_act_bwd_pair': (_I, [_P, _I, _P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P, _P]),
     'hdy_bn_act_bwd': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _L, _I, _I, _I, _P, _P]),
     'hdy_add_inplace': (_I, [_P, _I, _P, _I, _L, _I, _I, _P]),
     'hdy_colsum': (_I, [_P, _I, _L, _I, _P, _I, _I, _P, _P]),

@@ -102,12 +102,21 @@ __global__ __launch_bounds__(1024) void bn_partial_kernel(const float* __restric
     }
 }
 
+// Learnable parameters and running statistics of one BatchNorm, or of the two BatchNorms of a C3's merged cv1 | cv2 convolution:
+// channels [0, Ka) belong to the first module, [Ka, K) to the second (Ka == K: a single module, the *_b pointers are unused).
+// BatchNorm works per channel, so the pair runs through every pass as ONE K-wide layer; only the places that touch module-owned
+// tensors (parameters, running statistics, parameter gradients, the two destinations / gradient sources) split at Ka.
+struct BnParams {
+    const float* gamma; const float* beta; float* rmean; float* rvar;
+    const float* gamma_b; const float* beta_b; float* rmean_b; float* rvar_b;
+    int Ka;
+};
+
 // Final stage.  Input is either the fp32 slabs (ST = float) or stage A's fp64 partials (ST = double).
 // grid = ceil(K/32), block = 32 channels x 32 tile-lanes
 template <typename ST>
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const ST* __restrict__ stats, int stats_ld, int mtiles, int K, double count,
-                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           float* __restrict__ rmean, float* __restrict__ rvar, float eps, float momentum,
+                                                           BnParams bn, float eps, float momentum,
                                                            float* __restrict__ scale, float* __restrict__ shift,
                                                            float* __restrict__ save_mean, float* __restrict__ save_invstd) {
     __shared__ double red[2][32][33];
@@ -145,15 +154,19 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const ST* __restrict_
         double var = ss / count - mean * mean;
         if (var < 0.0) var = 0.0;
         const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float sc = gamma[k] * invstd;
+        const bool second = k >= bn.Ka;                  // channels of the second BatchNorm of a pair
+        const int kk = second ? k - bn.Ka : k;
+        const float sc = (second ? bn.gamma_b : bn.gamma)[kk] * invstd;
         scale[k] = sc;
-        shift[k] = beta[k] - (float)mean * sc;
+        shift[k] = (second ? bn.beta_b : bn.beta)[kk] - (float)mean * sc;
         save_mean[k] = (float)mean;
         save_invstd[k] = invstd;
+        float* rmean = second ? bn.rmean_b : bn.rmean;
+        float* rvar = second ? bn.rvar_b : bn.rvar;
         if (rmean) {
             const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-            rmean[k] = (1.0f - momentum) * rmean[k] + momentum * (float)mean;
-            rvar[k] = (1.0f - momentum) * rvar[k] + momentum * (float)unbiased;
+            rmean[kk] = (1.0f - momentum) * rmean[kk] + momentum * (float)mean;
+            rvar[kk] = (1.0f - momentum) * rvar[kk] + momentum * (float)unbiased;
         }
     }
 }
@@ -172,7 +185,8 @@ __global__ void bn_eval_coeffs_kernel(const float* __restrict__ gamma, const flo
 template <typename T, int ACT, bool RES>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, const T* __restrict__ res, int ldr,
-                                                         T* __restrict__ z, int ldz, int M, int K, int act) {
+                                                         T* __restrict__ z, int ldz, T* __restrict__ z_b, int ldz_b, int Ka, int M, int K,
+                                                         int act) {
     constexpr int VE = VT<T>::VE;
     const int VCt = K / VE;
     for (int chunk = 0; chunk * 256 < VCt; ++chunk) {
@@ -182,6 +196,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
         float sc[VE], sh[VE];
 #pragma unroll
         for (int i = 0; i < VE; ++i) { sc[i] = scale[c + i]; sh[i] = shift[c + i]; }
+        T* const zc = c < Ka ? z + c : z_b + (c - Ka);    // a lane's channels are fixed: the pair's second destination is a pointer choice
+        const int ldzc = c < Ka ? ldz : ldz_b;
         for (int m = blockIdx.x * L.RL + L.rl; m < M; m += gridDim.x * L.RL) {
             float v[VE], r[VE];
             unpack<T>(*(const i32x4*)(y + (size_t)m * ldy + c), v);
@@ -194,7 +210,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
                 if (RES) u += r[i];
                 v[i] = u;
             }
-            *(i32x4*)(z + (size_t)m * ldz + c) = pack<T>(v);
+            *(i32x4*)(zc + (size_t)m * ldzc) = pack<T>(v);
         }
     }
 }
@@ -203,7 +219,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
 // partial[block][2][K]: sum(du), sum(du*xhat) over this block's rows.  grid.x = row blocks, grid.y = column chunks.
 // MODE 0: plain column sums of dz (colsum: y and the coefficients are null); 1: BatchNorm backward without activation; 2: with SiLU
 template <typename T, int MODE>
-__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restrict__ dz, int lddz, const T* __restrict__ y, int ldy,
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restrict__ dz, int lddz, const T* __restrict__ dz_b, int lddz_b, int Ka,
+                                                                const T* __restrict__ y, int ldy,
                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                 int M, int K, int act, int rows_per_block, float* __restrict__ partial) {
@@ -224,6 +241,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restr
     }
     const int mbeg = blockIdx.x * rows_per_block;
     const int mend = min(mbeg + rows_per_block, M);
+    const T* const dzc = c < Ka ? dz + c : dz_b + (c - Ka);        // gradient source of this lane's channels (second module of a pair)
+    const int lddzc = c < Ka ? lddz : lddz_b;
     if (L.live) {
         auto accumulate = [&](const i32x4& gq, const i32x4& vq) {
             float g[VE], v[VE] = {};
@@ -246,14 +265,14 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restr
             i32x4 gq[U], vq[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                gq[u] = *(const i32x4*)(dz + (size_t)(m + u * L.RL) * lddz + c);
+                gq[u] = *(const i32x4*)(dzc + (size_t)(m + u * L.RL) * lddzc);
                 vq[u] = MODE != 0 ? *(const i32x4*)(y + (size_t)(m + u * L.RL) * ldy + c) : i32x4{0, 0, 0, 0};
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) accumulate(gq[u], vq[u]);
         }
         for (; m < mend; m += L.RL) {
-            const i32x4 gq = *(const i32x4*)(dz + (size_t)m * lddz + c);
+            const i32x4 gq = *(const i32x4*)(dzc + (size_t)m * lddzc);
             const i32x4 vq = MODE != 0 ? *(const i32x4*)(y + (size_t)m * ldy + c) : i32x4{0, 0, 0, 0};
             accumulate(gq, vq);
         }
@@ -280,7 +299,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restr
 // global_atomic_add_f64 and deriving c1 / c2 in the apply pass — up to 1024 device-scope atomics per address cost ~100 us per
 // layer: 17.1 -> 22.9 ms per yolov5s bench step.)
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblocks, int K, double count,
-                                                               float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               float* __restrict__ dgamma_b, float* __restrict__ dbeta_b, int Ka, int accumulate,
                                                                float* __restrict__ c1, float* __restrict__ c2) {
     __shared__ double red[2][32][33];
     const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
@@ -312,8 +332,11 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
     if (tl == 0 && k < K) {
         s1 = 0.0; s2 = 0.0;
         for (int t = 0; t < 32; ++t) { s1 += red[0][t][cl]; s2 += red[1][t][cl]; }
-        if (dbeta) dbeta[k] = accumulate ? dbeta[k] + (float)s1 : (float)s1;
-        if (dgamma) dgamma[k] = accumulate ? dgamma[k] + (float)s2 : (float)s2;
+        float* const db = k < Ka ? dbeta : dbeta_b;      // parameter gradients of the pair's second module
+        float* const dg = k < Ka ? dgamma : dgamma_b;
+        const int kk = k < Ka ? k : k - Ka;
+        if (db) db[kk] = accumulate ? db[kk] + (float)s1 : (float)s1;
+        if (dg) dg[kk] = accumulate ? dg[kk] + (float)s2 : (float)s2;
         if (c1) c1[k] = (float)(s1 / count);
         if (c2) c2[k] = (float)(s2 / count);
     }
@@ -321,7 +344,8 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
 
 // FROZEN: constant scale / shift (FrozenBatchNorm2d): dy = scale * du, no statistics terms (mean / invstd / c1 / c2 unused)
 template <typename T, bool FROZEN, int ACT>
-__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restrict__ dz, int lddz, const T* __restrict__ y, int ldy,
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restrict__ dz, int lddz, const T* __restrict__ dz_b, int lddz_b, int Ka,
+                                                               const T* __restrict__ y, int ldy,
                                                                const float* __restrict__ scale, const float* __restrict__ shift,
                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                const float* __restrict__ c1, const float* __restrict__ c2,
@@ -339,9 +363,11 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restri
             mu[i] = FROZEN ? 0.f : mean[c + i]; is[i] = FROZEN ? 0.f : invstd[c + i];
             k1[i] = FROZEN ? 0.f : c1[c + i]; k2[i] = FROZEN ? 0.f : c2[c + i];
         }
+        const T* const dzc = c < Ka ? dz + c : dz_b + (c - Ka);
+        const int lddzc = c < Ka ? lddz : lddz_b;
         for (int m = blockIdx.x * L.RL + L.rl; m < M; m += gridDim.x * L.RL) {
             float g[VE], v[VE];
-            unpack<T>(*(const i32x4*)(dz + (size_t)m * lddz + c), g);
+            unpack<T>(*(const i32x4*)(dzc + (size_t)m * lddzc), g);
             unpack<T>(*(const i32x4*)(y + (size_t)m * ldy + c), v);
 #pragma unroll
             for (int i = 0; i < VE; ++i) {
@@ -384,45 +410,55 @@ inline int stream_grid(long long M, int VC) {
     return (int)g;
 }
 
+// a tensor that may come in two channel ranges: [0, Ka) from (a, lda), [Ka, K) from (b, ldb)  (Ka == K: b unused)
+struct Split {
+    const void* a; int lda;
+    const void* b; int ldb;
+    int Ka;
+};
+
 template <typename T>
-void bn_bwd_reduce_launch(dim3 grid, hipStream_t st, const void* dz, int lddz, const void* y, int ldy, const float* scale, const float* shift,
+void bn_bwd_reduce_launch(dim3 grid, hipStream_t st, const Split& dz, const void* y, int ldy, const float* scale, const float* shift,
                           const float* mean, const float* invstd, int M, int K, int act, int rows, float* partial) {
     if (act == 1)
-        hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, 2>), grid, dim3(256), 0, st, (const T*)dz, lddz, (const T*)y, ldy, scale, shift, mean, invstd, M, K,
-                           act, rows, partial);
+        hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, 2>), grid, dim3(256), 0, st, (const T*)dz.a, dz.lda, (const T*)dz.b, dz.ldb, dz.Ka, (const T*)y, ldy,
+                           scale, shift, mean, invstd, M, K, act, rows, partial);
+    else if (y)
+        hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, 1>), grid, dim3(256), 0, st, (const T*)dz.a, dz.lda, (const T*)dz.b, dz.ldb, dz.Ka, (const T*)y, ldy,
+                           scale, shift, mean, invstd, M, K, act, rows, partial);
     else
-        hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, 1>), grid, dim3(256), 0, st, (const T*)dz, lddz, (const T*)y, ldy, scale, shift, mean, invstd, M, K,
-                           act, rows, partial);
+        hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, 0>), grid, dim3(256), 0, st, (const T*)dz.a, dz.lda, (const T*)dz.b, dz.ldb, dz.Ka, (const T*)y, ldy,
+                           scale, shift, mean, invstd, M, K, act, rows, partial);
 }
 
 template <typename T, bool FROZEN>
-void bn_bwd_apply_launch(int grid, hipStream_t st, const void* dz, int lddz, const void* y, int ldy, const float* scale, const float* shift,
+void bn_bwd_apply_launch(int grid, hipStream_t st, const Split& dz, const void* y, int ldy, const float* scale, const float* shift,
                          const float* mean, const float* invstd, const float* c1, const float* c2, void* dy, int lddy, int M, int K, int act) {
     if (act == 1)
-        hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, FROZEN, 1>), dim3(grid), dim3(256), 0, st, (const T*)dz, lddz, (const T*)y, ldy, scale, shift, mean,
-                           invstd, c1, c2, (T*)dy, lddy, M, K, act);
+        hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, FROZEN, 1>), dim3(grid), dim3(256), 0, st, (const T*)dz.a, dz.lda, (const T*)dz.b, dz.ldb, dz.Ka,
+                           (const T*)y, ldy, scale, shift, mean, invstd, c1, c2, (T*)dy, lddy, M, K, act);
     else
-        hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, FROZEN, 0>), dim3(grid), dim3(256), 0, st, (const T*)dz, lddz, (const T*)y, ldy, scale, shift, mean,
-                           invstd, c1, c2, (T*)dy, lddy, M, K, act);
+        hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, FROZEN, 0>), dim3(grid), dim3(256), 0, st, (const T*)dz.a, dz.lda, (const T*)dz.b, dz.ldb, dz.Ka,
+                           (const T*)y, ldy, scale, shift, mean, invstd, c1, c2, (T*)dy, lddy, M, K, act);
 }
 
 template <typename T, int ACT>
-void bn_act_fwd_launch(int grid, hipStream_t st, const void* y, int ldy, const float* scale, const float* shift, const void* res, int ldr, void* z,
-                       int ldz, int M, int K, int act) {
+void bn_act_fwd_launch(int grid, hipStream_t st, const void* y, int ldy, const float* scale, const float* shift, const void* res, int ldr,
+                       const Split& z, int M, int K, int act) {
     if (res)
-        hipLaunchKernelGGL((bn_act_fwd_kernel<T, ACT, true>), dim3(grid), dim3(256), 0, st, (const T*)y, ldy, scale, shift, (const T*)res, ldr, (T*)z,
-                           ldz, M, K, act);
+        hipLaunchKernelGGL((bn_act_fwd_kernel<T, ACT, true>), dim3(grid), dim3(256), 0, st, (const T*)y, ldy, scale, shift, (const T*)res, ldr, (T*)z.a,
+                           z.lda, (T*)z.b, z.ldb, z.Ka, M, K, act);
     else
-        hipLaunchKernelGGL((bn_act_fwd_kernel<T, ACT, false>), dim3(grid), dim3(256), 0, st, (const T*)y, ldy, scale, shift, (const T*)res, ldr, (T*)z,
-                           ldz, M, K, act);
+        hipLaunchKernelGGL((bn_act_fwd_kernel<T, ACT, false>), dim3(grid), dim3(256), 0, st, (const T*)y, ldy, scale, shift, (const T*)res, ldr, (T*)z.a,
+                           z.lda, (T*)z.b, z.ldb, z.Ka, M, K, act);
 }
 
 template <typename T>
-void bn_act_fwd_dispatch(int grid, hipStream_t st, const void* y, int ldy, const float* scale, const float* shift, const void* res, int ldr, void* z,
-                         int ldz, int M, int K, int act) {
-    if (act == 1) bn_act_fwd_launch<T, 1>(grid, st, y, ldy, scale, shift, res, ldr, z, ldz, M, K, act);
-    else if (act == 2) bn_act_fwd_launch<T, 2>(grid, st, y, ldy, scale, shift, res, ldr, z, ldz, M, K, act);
-    else bn_act_fwd_launch<T, 0>(grid, st, y, ldy, scale, shift, res, ldr, z, ldz, M, K, act);
+void bn_act_fwd_dispatch(int grid, hipStream_t st, const void* y, int ldy, const float* scale, const float* shift, const void* res, int ldr,
+                         const Split& z, int M, int K, int act) {
+    if (act == 1) bn_act_fwd_launch<T, 1>(grid, st, y, ldy, scale, shift, res, ldr, z, M, K, act);
+    else if (act == 2) bn_act_fwd_launch<T, 2>(grid, st, y, ldy, scale, shift, res, ldr, z, M, K, act);
+    else bn_act_fwd_launch<T, 0>(grid, st, y, ldy, scale, shift, res, ldr, z, M, K, act);
 }
 
 }  // namespace
@@ -434,12 +470,13 @@ extern "C" {
 
 size_t hdy_bn_finalize_workspace_bytes(int mtiles, int K) { return mtiles > 1024 ? (size_t)32 * 2 * K * sizeof(double) : 0; }
 
-int hdy_bn_finalize(const float* stats, int stats_ld, int mtiles, int K, long long count, const float* gamma, const float* beta, float* running_mean,
-                    float* running_var, float eps, float momentum, float* scale, float* shift, float* save_mean, float* save_invstd,
-                    void* workspace, void* stream) {
-    HDY_ARG(stats && gamma && beta && scale && shift && save_mean && save_invstd, "bn_finalize: null pointer");
+static int bn_finalize_impl(const float* stats, int stats_ld, int mtiles, int K, long long count, const BnParams& bn, float eps, float momentum,
+                            float* scale, float* shift, float* save_mean, float* save_invstd, void* workspace, void* stream) {
+    HDY_ARG(stats && bn.gamma && bn.beta && scale && shift && save_mean && save_invstd, "bn_finalize: null pointer");
     HDY_ARG(mtiles > 0 && K > 0 && count > 0 && stats_ld >= K, "bn_finalize: bad sizes");
-    HDY_ARG((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running_mean/var must both be given or both null");
+    HDY_ARG((bn.rmean == nullptr) == (bn.rvar == nullptr), "bn_finalize: running_mean/var must both be given or both null");
+    HDY_ARG(bn.Ka == K || (bn.Ka > 0 && bn.Ka < K && bn.gamma_b && bn.beta_b && (bn.rmean_b == nullptr) == (bn.rvar_b == nullptr)),
+            "bn_finalize_pair: second module's parameters missing or split point outside (0, K)");
     hipStream_t st = (hipStream_t)stream;
     if (mtiles > 1024 && workspace) {
         // two stages: 32 groups of tiles reduced in parallel, then the usual final stage over 32 fp64 partials
@@ -448,13 +485,28 @@ int hdy_bn_finalize(const float* stats, int stats_ld, int mtiles, int K, long lo
         hipLaunchKernelGGL(bn_partial_kernel, dim3(cdiv(K, 32), G), dim3(1024), 0, st, stats, stats_ld, mtiles, K, tpg, part);
         HDY_LAUNCH_CHECK("bn_partial");
         hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3(cdiv(K, 32)), dim3(1024), 0, st, (const double*)part, K, cdiv(mtiles, tpg), K,
-                           (double)count, gamma, beta, running_mean, running_var, eps, momentum, scale, shift, save_mean, save_invstd);
+                           (double)count, bn, eps, momentum, scale, shift, save_mean, save_invstd);
     } else {
-        hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3(cdiv(K, 32)), dim3(1024), 0, st, stats, stats_ld, mtiles, K, (double)count, gamma,
-                           beta, running_mean, running_var, eps, momentum, scale, shift, save_mean, save_invstd);
+        hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3(cdiv(K, 32)), dim3(1024), 0, st, stats, stats_ld, mtiles, K, (double)count, bn, eps,
+                           momentum, scale, shift, save_mean, save_invstd);
     }
     HDY_LAUNCH_CHECK("bn_finalize");
     return HDY_OK;
+}
+
+int hdy_bn_finalize(const float* stats, int stats_ld, int mtiles, int K, long long count, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, float eps, float momentum, float* scale, float* shift, float* save_mean, float* save_invstd,
+                    void* workspace, void* stream) {
+    const BnParams bn = {gamma, beta, running_mean, running_var, nullptr, nullptr, nullptr, nullptr, K};
+    return bn_finalize_impl(stats, stats_ld, mtiles, K, count, bn, eps, momentum, scale, shift, save_mean, save_invstd, workspace, stream);
+}
+
+int hdy_bn_finalize_pair(const float* stats, int stats_ld, int mtiles, int K, int Ka, long long count, const float* gamma_a, const float* beta_a,
+                         float* running_mean_a, float* running_var_a, const float* gamma_b, const float* beta_b, float* running_mean_b,
+                         float* running_var_b, float eps, float momentum, float* scale, float* shift, float* save_mean, float* save_invstd,
+                         void* workspace, void* stream) {
+    const BnParams bn = {gamma_a, beta_a, running_mean_a, running_var_a, gamma_b, beta_b, running_mean_b, running_var_b, Ka};
+    return bn_finalize_impl(stats, stats_ld, mtiles, K, count, bn, eps, momentum, scale, shift, save_mean, save_invstd, workspace, stream);
 }
 
 int hdy_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, int K,
@@ -466,17 +518,28 @@ int hdy_bn_eval_coeffs(const float* gamma, const float* beta, const float* runni
     return HDY_OK;
 }
 
-int hdy_bn_act_fwd(const void* y, int ldy, const float* scale, const float* shift, const void* res, int ldr, void* z, int ldz,
-                   long long M, int K, int act, int dtype, void* stream) {
+static int bn_act_fwd_impl(const void* y, int ldy, const float* scale, const float* shift, const void* res, int ldr, const Split& z, long long M, int K,
+                           int act, int dtype, void* stream) {
     const int VE = dtype == HDY_BF16 ? 8 : 4;
-    HDY_ARG(y && z && scale && shift && M_OK(M) && K > 0, "bn_act_fwd: bad args");
-    HDY_ARG(K % VE == 0 && VEC_OK(y, ldy, VE) && VEC_OK(z, ldz, VE) && (!res || VEC_OK(res, ldr, VE)), "bn_act_fwd: K/pitch/alignment must be multiples of one 16-byte vector");
+    HDY_ARG(y && z.a && scale && shift && M_OK(M) && K > 0, "bn_act_fwd: bad args");
+    HDY_ARG(K % VE == 0 && VEC_OK(y, ldy, VE) && VEC_OK(z.a, z.lda, VE) && (!res || VEC_OK(res, ldr, VE)), "bn_act_fwd: K/pitch/alignment must be multiples of one 16-byte vector");
+    HDY_ARG(z.Ka == K || (z.Ka > 0 && z.Ka < K && z.Ka % VE == 0 && z.b && VEC_OK(z.b, z.ldb, VE)), "bn_act_fwd_pair: second destination missing / unaligned / bad split");
     HDY_ARG(act >= 0 && act <= 2, "bn_act_fwd: unknown activation %d", act);
     const int grid = stream_grid(M, K / VE);
-    if (dtype == HDY_BF16) bn_act_fwd_dispatch<bf16_t>(grid, (hipStream_t)stream, y, ldy, scale, shift, res, ldr, z, ldz, (int)M, K, act);
-    else bn_act_fwd_dispatch<float>(grid, (hipStream_t)stream, y, ldy, scale, shift, res, ldr, z, ldz, (int)M, K, act);
+    if (dtype == HDY_BF16) bn_act_fwd_dispatch<bf16_t>(grid, (hipStream_t)stream, y, ldy, scale, shift, res, ldr, z, (int)M, K, act);
+    else bn_act_fwd_dispatch<float>(grid, (hipStream_t)stream, y, ldy, scale, shift, res, ldr, z, (int)M, K, act);
     HDY_LAUNCH_CHECK("bn_act_fwd");
     return HDY_OK;
+}
+
+int hdy_bn_act_fwd(const void* y, int ldy, const float* scale, const float* shift, const void* res, int ldr, void* z, int ldz,
+                   long long M, int K, int act, int dtype, void* stream) {
+    return bn_act_fwd_impl(y, ldy, scale, shift, res, ldr, Split{z, ldz, nullptr, 0, K}, M, K, act, dtype, stream);
+}
+
+int hdy_bn_act_fwd_pair(const void* y, int ldy, const float* scale, const float* shift, void* z_a, int ldz_a, void* z_b, int ldz_b, int Ka,
+                        long long M, int K, int act, int dtype, void* stream) {
+    return bn_act_fwd_impl(y, ldy, scale, shift, nullptr, 0, Split{z_a, ldz_a, z_b, ldz_b, Ka}, M, K, act, dtype, stream);
 }
 
 // number of row blocks hdy_bn_act_bwd uses (size of the partial slab = blocks*2*K floats)
@@ -493,12 +556,13 @@ int hdy_bn_bwd_blocks(long long M) {
 
 // Full backward of z = act(BN_train(y)) [+ res]:  dy, and dgamma/dbeta (+)=.
 // workspace: (hdy_bn_bwd_blocks(M)*2*K + 2*K) floats.
-int hdy_bn_act_bwd(const void* dz, int lddz, const void* y, int ldy, const float* scale, const float* shift, const float* mean,
-                   const float* invstd, void* dy, int lddy, float* dgamma, float* dbeta, int accumulate, long long M, int K, int act,
-                   int dtype, float* workspace, void* stream) {
+static int bn_act_bwd_impl(const Split& dz, const void* y, int ldy, const float* scale, const float* shift, const float* mean, const float* invstd,
+                           void* dy, int lddy, float* dgamma, float* dbeta, float* dgamma_b, float* dbeta_b, int accumulate, long long M, int K,
+                           int act, int dtype, float* workspace, void* stream) {
     const int VE = dtype == HDY_BF16 ? 8 : 4;
-    HDY_ARG(dz && y && dy && scale && shift && workspace && M_OK(M) && K > 0 && (!mean == !invstd), "bn_act_bwd: bad args");
-    HDY_ARG(K % VE == 0 && VEC_OK(dz, lddz, VE) && VEC_OK(y, ldy, VE) && VEC_OK(dy, lddy, VE), "bn_act_bwd: K/pitch/alignment must be multiples of one 16-byte vector");
+    HDY_ARG(dz.a && y && dy && scale && shift && workspace && M_OK(M) && K > 0 && (!mean == !invstd), "bn_act_bwd: bad args");
+    HDY_ARG(K % VE == 0 && VEC_OK(dz.a, dz.lda, VE) && VEC_OK(y, ldy, VE) && VEC_OK(dy, lddy, VE), "bn_act_bwd: K/pitch/alignment must be multiples of one 16-byte vector");
+    HDY_ARG(dz.Ka == K || (dz.Ka > 0 && dz.Ka < K && dz.Ka % VE == 0 && dz.b && VEC_OK(dz.b, dz.ldb, VE)), "bn_act_bwd_pair: second gradient source missing / unaligned / bad split");
     const int nb = hdy_bn_bwd_blocks(M);
     const int rows = (int)((M + nb - 1) / nb);
     float* partial = workspace;
@@ -510,22 +574,36 @@ int hdy_bn_act_bwd(const void* dz, int lddz, const void* y, int ldy, const float
     if (!mean) {
         // frozen BatchNorm (torchvision FrozenBatchNorm2d after Model.freeze): z = act(y*scale + shift) with constant scale/shift,
         // so dy = scale * dz * act'(u) and there is no statistics gradient: the apply pass alone
-        if (dtype == HDY_BF16) bn_bwd_apply_launch<bf16_t, true>(g2, st, dz, lddz, y, ldy, scale, shift, nullptr, nullptr, nullptr, nullptr, dy, lddy, (int)M, K, act);
-        else bn_bwd_apply_launch<float, true>(g2, st, dz, lddz, y, ldy, scale, shift, nullptr, nullptr, nullptr, nullptr, dy, lddy, (int)M, K, act);
+        if (dtype == HDY_BF16) bn_bwd_apply_launch<bf16_t, true>(g2, st, dz, y, ldy, scale, shift, nullptr, nullptr, nullptr, nullptr, dy, lddy, (int)M, K, act);
+        else bn_bwd_apply_launch<float, true>(g2, st, dz, y, ldy, scale, shift, nullptr, nullptr, nullptr, nullptr, dy, lddy, (int)M, K, act);
         HDY_LAUNCH_CHECK("bn_act_bwd_apply(frozen)");
         return HDY_OK;
     }
     dim3 grid(nb, cdiv(K / VE, 256));
-    if (dtype == HDY_BF16) bn_bwd_reduce_launch<bf16_t>(grid, st, dz, lddz, y, ldy, scale, shift, mean, invstd, (int)M, K, act, rows, partial);
-    else bn_bwd_reduce_launch<float>(grid, st, dz, lddz, y, ldy, scale, shift, mean, invstd, (int)M, K, act, rows, partial);
+    if (dtype == HDY_BF16) bn_bwd_reduce_launch<bf16_t>(grid, st, dz, y, ldy, scale, shift, mean, invstd, (int)M, K, act, rows, partial);
+    else bn_bwd_reduce_launch<float>(grid, st, dz, y, ldy, scale, shift, mean, invstd, (int)M, K, act, rows, partial);
     HDY_LAUNCH_CHECK("bn_act_bwd_reduce");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(K, 32)), dim3(1024), 0, st, partial, nb, K, (double)M, dgamma, dbeta, accumulate, c1,
-                       c2);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(K, 32)), dim3(1024), 0, st, partial, nb, K, (double)M, dgamma, dbeta, dgamma_b, dbeta_b, dz.Ka,
+                       accumulate, c1, c2);
     HDY_LAUNCH_CHECK("bn_bwd_finalize");
-    if (dtype == HDY_BF16) bn_bwd_apply_launch<bf16_t, false>(g2, st, dz, lddz, y, ldy, scale, shift, mean, invstd, c1, c2, dy, lddy, (int)M, K, act);
-    else bn_bwd_apply_launch<float, false>(g2, st, dz, lddz, y, ldy, scale, shift, mean, invstd, c1, c2, dy, lddy, (int)M, K, act);
+    if (dtype == HDY_BF16) bn_bwd_apply_launch<bf16_t, false>(g2, st, dz, y, ldy, scale, shift, mean, invstd, c1, c2, dy, lddy, (int)M, K, act);
+    else bn_bwd_apply_launch<float, false>(g2, st, dz, y, ldy, scale, shift, mean, invstd, c1, c2, dy, lddy, (int)M, K, act);
     HDY_LAUNCH_CHECK("bn_act_bwd_apply");
     return HDY_OK;
+}
+
+int hdy_bn_act_bwd(const void* dz, int lddz, const void* y, int ldy, const float* scale, const float* shift, const float* mean,
+                   const float* invstd, void* dy, int lddy, float* dgamma, float* dbeta, int accumulate, long long M, int K, int act,
+                   int dtype, float* workspace, void* stream) {
+    return bn_act_bwd_impl(Split{dz, lddz, nullptr, 0, K}, y, ldy, scale, shift, mean, invstd, dy, lddy, dgamma, dbeta, nullptr, nullptr, accumulate, M, K,
+                           act, dtype, workspace, stream);
+}
+
+int hdy_bn_act_bwd_pair(const void* dz_a, int lddz_a, const void* dz_b, int lddz_b, int Ka, const void* y, int ldy, const float* scale,
+                        const float* shift, const float* mean, const float* invstd, void* dy, int lddy, float* dgamma_a, float* dbeta_a,
+                        float* dgamma_b, float* dbeta_b, int accumulate, long long M, int K, int act, int dtype, float* workspace, void* stream) {
+    return bn_act_bwd_impl(Split{dz_a, lddz_a, dz_b, lddz_b, Ka}, y, ldy, scale, shift, mean, invstd, dy, lddy, dgamma_a, dbeta_a, dgamma_b, dbeta_b,
+                           accumulate, M, K, act, dtype, workspace, stream);
 }
 
 // out[k] (+)= sum over the M rows of dz[m][k]  (bias gradient of the detection conv).  workspace: hdy_bn_bwd_blocks(M)*2*K floats.
@@ -536,15 +614,12 @@ int hdy_colsum(const void* dz, int lddz, long long M, int K, float* out, int acc
     const int rows = (int)((M + nb - 1) / nb);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(nb, cdiv(K / VE, 256));
-    if (dtype == HDY_BF16)
-        hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<bf16_t, 0>), grid, dim3(256), 0, st, (const bf16_t*)dz, lddz, (const bf16_t*)nullptr, 0,
-                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (int)M, K, 0, rows, workspace);
-    else
-        hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<float, 0>), grid, dim3(256), 0, st, (const float*)dz, lddz, (const float*)nullptr, 0,
-                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (int)M, K, 0, rows, workspace);
+    const Split src = {dz, lddz, nullptr, 0, K};
+    if (dtype == HDY_BF16) bn_bwd_reduce_launch<bf16_t>(grid, st, src, nullptr, 0, nullptr, nullptr, nullptr, nullptr, (int)M, K, 0, rows, workspace);
+    else bn_bwd_reduce_launch<float>(grid, st, src, nullptr, 0, nullptr, nullptr, nullptr, nullptr, (int)M, K, 0, rows, workspace);
     HDY_LAUNCH_CHECK("colsum_reduce");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(K, 32)), dim3(1024), 0, st, workspace, nb, K, (double)M, (float*)nullptr, out, accumulate,
-                       (float*)nullptr, (float*)nullptr);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(K, 32)), dim3(1024), 0, st, workspace, nb, K, (double)M, (float*)nullptr, out, (float*)nullptr,
+                       (float*)nullptr, K, accumulate, (float*)nullptr, (float*)nullptr);
     HDY_LAUNCH_CHECK("colsum_finalize");
     return HDY_OK;
 }

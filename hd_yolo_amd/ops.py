@@ -208,6 +208,14 @@ def rec_bn_finalize(stats, mtiles, K, count, gamma, beta, rmean, rvar, scale, sh
                                 ptr(shift), ptr(save_mean), ptr(save_invstd), ptr(ws)))
 
 
+def rec_bn_finalize_pair(stats, mtiles, K, Ka, count, bn_a, bn_b, scale, shift, save_mean, save_invstd, eps=BN_EPS, momentum=BN_MOMENTUM, ws=None):
+    """One finalize for the two BatchNorms of a merged cv1 | cv2 convolution: bn_a / bn_b = (gamma, beta, running_mean, running_var)."""
+    ga, ba, rma, rva = bn_a
+    gb, bb, rmb, rvb = bn_b
+    return _rec(locals(), 'hdy_bn_finalize_pair', (ptr(stats), K, mtiles, K, Ka, count, ptr(ga), ptr(ba), ptr(rma), ptr(rva), ptr(gb), ptr(bb), ptr(rmb),
+                                     ptr(rvb), eps, momentum, ptr(scale), ptr(shift), ptr(save_mean), ptr(save_invstd), ptr(ws)))
+
+
 def rec_bn_eval_coeffs(gamma, beta, rmean, rvar, scale, shift, eps=BN_EPS):
     return _rec(locals(), 'hdy_bn_eval_coeffs', (ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), eps, gamma.numel(), ptr(scale), ptr(shift)))
 
@@ -221,6 +229,25 @@ def rec_bn_act_fwd(y, scale, shift, z, res=None, act=ACT_SILU):
         rp, _, _, _, Kr, ldr = nhwc(res)
         assert Kr == K and res.dtype == y.dtype
     return _rec(locals(), 'hdy_bn_act_fwd', (yp, ldy, ptr(scale), ptr(shift), rp, ldr, zp, ldz, N * H * W, K, act, dcode(y.dtype)))
+
+
+def rec_bn_act_fwd_pair(y, scale, shift, z_a, z_b, act=ACT_SILU):
+    """z_a = channels [0, Ka), z_b = the rest: the two outputs of a merged cv1 | cv2 unit (different buffers / pitches)."""
+    yp, N, H, W, K, ldy = nhwc(y)
+    zap, _, _, _, Ka, ldza = nhwc(z_a)
+    zbp, _, _, _, Kb, ldzb = nhwc(z_b)
+    assert Ka + Kb == K and z_a.dtype == z_b.dtype == y.dtype and z_a.shape[:3] == z_b.shape[:3] == y.shape[:3]
+    return _rec(locals(), 'hdy_bn_act_fwd_pair', (yp, ldy, ptr(scale), ptr(shift), zap, ldza, zbp, ldzb, Ka, N * H * W, K, act, dcode(y.dtype)))
+
+
+def rec_bn_act_bwd_pair(dz_a, dz_b, y, scale, shift, mean, invstd, dy, dgamma_a, dbeta_a, dgamma_b, dbeta_b, ws, accumulate=False, act=ACT_SILU):
+    dap, N, H, W, Ka, ldda = nhwc(dz_a)
+    dbp, _, _, _, Kb, lddb = nhwc(dz_b)
+    yp, _, _, _, K, ldy = nhwc(y)
+    dyp, _, _, _, _, lddy = nhwc(dy)
+    assert Ka + Kb == K and y.shape == dy.shape and dz_a.dtype == dz_b.dtype == y.dtype == dy.dtype and ws.numel() >= bn_bwd_ws_floats(N * H * W, K)
+    return _rec(locals(), 'hdy_bn_act_bwd_pair', (dap, ldda, dbp, lddb, Ka, yp, ldy, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), dyp, lddy, ptr(dgamma_a),
+                                    ptr(dbeta_a), ptr(dgamma_b), ptr(dbeta_b), int(accumulate), N * H * W, K, act, dcode(dz_a.dtype), ptr(ws)))
 
 
 def bn_bwd_ws_floats(M, K):

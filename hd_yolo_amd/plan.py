@@ -398,6 +398,14 @@ class Plan:
                     M = o0.n * o0.h * o0.w
                     stats = None if u.frozen else self.stats[:u.mtiles * 2 * u.K].view(u.mtiles, 2, u.K)
                     recs.append(ops.rec_conv_fwd(x, u.wp, u.yraw, u.K, u.k, u.k, u.s, u.p, stats=stats, stem_hw=stem_hw))
+                    if len(u.mods) == 2 and not u.frozen and u.res is None:
+                        # the C3 pair: per-channel BatchNorm over the whole 2c-wide raw tensor in one finalize + one apply pass
+                        Ka = u.mods[0].conv.out_channels
+                        assert u.mods[0].bn.eps == u.mods[1].bn.eps and u.mods[0].bn.momentum == u.mods[1].bn.momentum
+                        recs.append(ops.rec_bn_finalize_pair(stats, u.mtiles, u.K, Ka, M, self._bn(u.mods[0]), self._bn(u.mods[1]), u.scale, u.shift,
+                                                             u.mean, u.invstd, eps=u.mods[0].bn.eps, momentum=u.mods[0].bn.momentum, ws=self.fin_ws))
+                        recs.append(ops.rec_bn_act_fwd_pair(u.yraw, u.scale, u.shift, u.outs[0].t(), u.outs[1].t(), act=u.act))
+                        continue
                     k0 = 0
                     for m, o in zip(u.mods, u.outs):
                         K = m.conv.out_channels
@@ -589,8 +597,16 @@ class Plan:
                 if slot in slot_user:              # the weight gradient that last read this ring slot must be done
                     recs.append(('@join', side, slot_user.pop(slot)))
                 dy = self.dy_ring[slot][:o0.n * o0.h * o0.w * u.K].view(o0.n, o0.h, o0.w, u.K)
+                pair = len(u.mods) == 2 and not u.frozen
+                if pair:
+                    ma, mb = u.mods
+                    recs.append(ops.rec_bn_act_bwd_pair(u.outs[0].gread(), u.outs[1].gread(), u.yraw, u.scale, u.shift, u.mean, u.invstd, dy,
+                                                        self._grad_views(ma.bn.weight), self._grad_views(ma.bn.bias),
+                                                        self._grad_views(mb.bn.weight), self._grad_views(mb.bn.bias), self.bn_ws, act=u.act))
                 k0 = 0
                 for m, o in zip(u.mods, u.outs):
+                    if pair:
+                        break
                     K = m.conv.out_channels
                     if u.frozen:
                         recs.append(ops.rec_bn_act_bwd(o.gread(), u.yraw[..., k0:k0 + K], u.scale[k0:k0 + K], u.shift[k0:k0 + K], None, None,

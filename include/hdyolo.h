@@ -114,6 +114,20 @@ int hdy_bn_bwd_blocks(long long M);
 int hdy_bn_act_bwd(const void* dz, int lddz, const void* y, int ldy, const float* scale, const float* shift, const float* mean,
                    const float* invstd, void* dy, int lddy, float* dgamma, float* dbeta, int accumulate, long long M, int K, int act,
                    int dtype, float* workspace, void* stream);
+/* The same three passes for the PAIR of BatchNorms behind a C3's cv1 | cv2 (metayolo/models/layers.py:126-131: both read the same
+ * input, so their convolutions run as one K = Ka + Kb wide launch): BatchNorm is per channel, so the pair is one K-wide layer; only
+ * what the two modules own separately splits at Ka — parameters, running statistics and parameter gradients (finalize), the two
+ * outputs (z_a: cv1's activation, z_b: cv2's slice of the concat buffer) and the two gradient sources (dz_a, dz_b).  One pass over
+ * the 2c-wide raw tensor instead of two passes over half-width slices (K = 32 halves read 64 of every 128 bytes). */
+int hdy_bn_finalize_pair(const float* stats, int stats_ld, int mtiles, int K, int Ka, long long count, const float* gamma_a, const float* beta_a,
+                         float* running_mean_a, float* running_var_a, const float* gamma_b, const float* beta_b, float* running_mean_b,
+                         float* running_var_b, float eps, float momentum, float* scale, float* shift, float* save_mean, float* save_invstd,
+                         void* workspace, void* stream);
+int hdy_bn_act_fwd_pair(const void* y, int ldy, const float* scale, const float* shift, void* z_a, int ldz_a, void* z_b, int ldz_b, int Ka,
+                        long long M, int K, int act, int dtype, void* stream);
+int hdy_bn_act_bwd_pair(const void* dz_a, int lddz_a, const void* dz_b, int lddz_b, int Ka, const void* y, int ldy, const float* scale,
+                        const float* shift, const float* mean, const float* invstd, void* dy, int lddy, float* dgamma_a, float* dbeta_a,
+                        float* dgamma_b, float* dbeta_b, int accumulate, long long M, int K, int act, int dtype, float* workspace, void* stream);
 int hdy_add_inplace(void* out, int ldo, const void* a, int lda, long long M, int K, int dtype, void* stream);
 /* out[k] (+)= sum_m dz[m][k]: bias gradient of Detect's conv (yolo_head.py:112).  workspace: hdy_bn_bwd_blocks(M)*2*K floats */
 int hdy_colsum(const void* dz, int lddz, long long M, int K, float* out, int accumulate, int dtype, float* workspace, void* stream);

@@ -238,6 +238,49 @@ def test_bn_silu_fwd_bwd(shape, dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(2, 20, 20, 32, 32), (3, 9, 7, 16, 48), (4, 40, 40, 64, 64)])
+def test_bn_pair_equals_two_single_calls(shape, dtype):
+    """The pair entry points (one K = Ka + Kb wide pass, parameters / outputs / gradient sources split at Ka) against the single-module
+    calls on the two channel ranges: identical arithmetic per channel (forward exactly; backward up to the summation order)."""
+    N, H, W, Ka, Kb = shape
+    K, M = Ka + Kb, N * H * W
+    y = to_dev_nhwc(q(rnd((N, K, H, W), 1, 2.0) + 0.3, dtype), dtype)
+    stats = torch.stack([from_dev_nhwc(y).sum((0, 2, 3)), (from_dev_nhwc(y) ** 2).sum((0, 2, 3))]).view(1, 2, K).to(DEV)
+    par = {k: (rnd((K,), i + 3).abs() + 0.5).to(DEV) for i, k in enumerate(('gamma', 'beta', 'rm', 'rv'))}
+    dza = to_dev_nhwc(q(rnd((N, Ka, H, W), 8), dtype), dtype, ld=Ka + 8, off=8)
+    dzb = to_dev_nhwc(q(rnd((N, Kb, H, W), 9), dtype), dtype, ld=Kb + 16, off=0)
+
+    def run(pair):
+        p = {k: v.clone() for k, v in par.items()}
+        sl = lambda t, a, b: t[a:b]
+        scale, shift, mean, inv = (torch.empty(K, device=DEV) for _ in range(4))
+        za = torch.zeros((N, H, W, Ka + 8), dtype=dtype, device=DEV)[..., 8:]
+        zb = torch.zeros((N, H, W, Kb), dtype=dtype, device=DEV)
+        dy = torch.zeros((N, H, W, K), dtype=dtype, device=DEV)
+        dg, db = torch.zeros(K, device=DEV), torch.zeros(K, device=DEV)
+        ws = torch.empty(ops.bn_bwd_ws_floats(M, K), device=DEV)
+        if pair:
+            bn = lambda a, b: tuple(sl(p[k], a, b) for k in ('gamma', 'beta', 'rm', 'rv'))
+            ops.run([ops.rec_bn_finalize_pair(stats, 1, K, Ka, M, bn(0, Ka), bn(Ka, K), scale, shift, mean, inv),
+                     ops.rec_bn_act_fwd_pair(y, scale, shift, za, zb),
+                     ops.rec_bn_act_bwd_pair(dza, dzb, y, scale, shift, mean, inv, dy, dg[:Ka], db[:Ka], dg[Ka:], db[Ka:], ws)])
+        else:
+            for a, b, z, dz in ((0, Ka, za, dza), (Ka, K, zb, dzb)):
+                ops.run([ops.rec_bn_finalize(stats[:, :, a:], 1, b - a, M, p['gamma'][a:b], p['beta'][a:b], p['rm'][a:b], p['rv'][a:b], scale[a:], shift[a:],
+                                             mean[a:], inv[a:], stats_ld=K),
+                         ops.rec_bn_act_fwd(y[..., a:b], scale[a:b], shift[a:b], z),
+                         ops.rec_bn_act_bwd(dz, y[..., a:b], scale[a:b], shift[a:b], mean[a:b], inv[a:b], dy[..., a:b], dg[a:b], db[a:b], ws)])
+        torch.cuda.synchronize()
+        return [t.float().cpu() for t in (za, zb, dy, dg, db, p['rm'], p['rv'], scale, shift)]
+
+    for name, a, b in zip(('z_a', 'z_b', 'dy', 'dgamma', 'dbeta', 'running_mean', 'running_var', 'scale', 'shift'), run(True), run(False)):
+        if name in ('dy', 'dgamma', 'dbeta'):        # the K-wide pass partitions the rows differently among lanes: fp32 sums in another order
+            assert_close(a, b, 2e-5 if dtype == torch.float32 else 8e-3, name)
+        else:
+            assert torch.equal(a, b), name
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('shape', [(2, 20, 20, 32), (1, 5, 7, 8), (1, 32, 32, 16)])
 def test_sppf_pool(shape, dtype):
     N, H, W, C = shape
