@@ -22,6 +22,7 @@ import sys
 import time
 
 os.environ.setdefault('YOLOv5_VERBOSE', 'false')
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL across processes needs it on this driver
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
