@@ -180,15 +180,27 @@ class Ensemble(nn.ModuleList):
         res = {}
         for task_id in sorted(set().union(*x)):
             parts = [r[task_id] for r in x if task_id in r]
-            if any('masks' in q for q in parts):
-                raise NotImplementedError('mask branch (SURVEY §8 row f2) is not built yet')
             boxes = torch.cat([q['boxes'] for q in parts])
             scores = torch.cat([q['scores'] for q in parts])
             labels = torch.cat([q['labels'] for q in parts])
+            masks = None
+            with_masks = [q['masks'] for q in parts if 'masks' in q]
+            if with_masks:
+                # masks ride along with their boxes (reference: yolo.py:172-186).  A model that returned none contributes zero masks for
+                # ITS boxes; the reference, marked "not finished" there, appends a single zero mask instead and then fails on the
+                # length mismatch whenever that model had a different number of boxes.
+                m0 = with_masks[0]
+                masks = torch.cat([q['masks'] if 'masks' in q else m0.new_zeros((len(q['boxes']),) + tuple(m0.shape[1:])) for q in parts])
             sel = scores > self.nms_params['conf_thres']
             boxes, scores, labels = boxes[sel], scores[sel], labels[sel]
+            if masks is not None:
+                masks = masks[sel]
             if len(boxes):
                 keep = nms(boxes, scores, self.nms_params['iou_thres'])[:int(self.nms_params['max_det'])]
                 boxes, scores, labels = boxes[keep], scores[keep], labels[keep]
+                if masks is not None:
+                    masks = masks[keep]
             res[task_id] = {'boxes': boxes, 'scores': scores, 'labels': labels}
+            if masks is not None:
+                res[task_id]['masks'] = masks
         return res

@@ -42,6 +42,30 @@ def test_ensemble_merge_matches_reference():
         np.testing.assert_array_equal(out[k].cpu().numpy(), G[f'ens_out_{k}'])
 
 
+def test_ensemble_merge_carries_masks():
+    """Masks ride along with their boxes through the score filter and the NMS (reference: yolo.py:172-199); a model without masks
+    contributes zero masks for its boxes.  Tagging each mask with its box's position in the concatenation makes the selection visible."""
+    ens = Ensemble([], {'conf_thres': 0.3, 'iou_thres': 0.4, 'max_det': 12})
+    parts = [{'det': {k: torch.from_numpy(G[f'ens_in_{j}_{k}']).to(DEV) for k in ('boxes', 'scores', 'labels')}} for j in range(3)]
+    plain = ens.merge(parts)['det']
+    off = 0
+    for j, p in enumerate(parts):
+        n = len(p['det']['boxes'])
+        if j != 1:                                # the middle model has no mask branch
+            p['det']['masks'] = (torch.arange(off, off + n, device=DEV, dtype=torch.float32) + 1)[:, None, None, None].expand(n, 1, 28, 28).contiguous()
+        off += n
+    out = ens.merge(parts)['det']
+    for k in ('boxes', 'scores', 'labels'):
+        assert torch.equal(out[k], plain[k])
+    allb = torch.cat([p['det']['boxes'] for p in parts])
+    n0, n1 = len(parts[0]['det']['boxes']), len(parts[1]['det']['boxes'])
+    assert out['masks'].shape == (len(out['boxes']), 1, 28, 28)
+    for box, m in zip(out['boxes'], out['masks']):
+        src = int((allb == box).all(1).nonzero()[0])
+        want = 0.0 if n0 <= src < n0 + n1 else float(src + 1)
+        assert float(m.min()) == float(m.max()) == want
+
+
 def _model(variant='n', nc=2):
     m = Model(synth.make_cfg(variant, nc), synth.make_hyp(conf_thres=0.05))
     m.load_state_dict(synth.synth_state_dict(synth.shapes_of(m), seed=0), strict=False)
