@@ -229,6 +229,10 @@ size_t hdy_conv_wgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, 
     const int Q = stem ? R * S * 4 : R * S * C;
     int splits = 1, pps = 64;
     hdy_wgrad_plan(K, Q, (long long)N * Ho * Wo, dtype, &splits, &pps);
+    if (stem) {
+        const int g = hdy_wgrad_stem_grid(N, Ho, Wo, K, dtype);        // patch-resident stem kernel: one slab per workgroup
+        if (g > splits) splits = g;
+    }
     return (size_t)splits * K * Q * sizeof(float);
 }
 
@@ -254,8 +258,15 @@ int hdy_conv_wgrad(const void* x, int ldx, const void* dy, int lddy, int N, int 
         a.ih_mul = a.iw_mul = stride; a.dh0 = a.dw0 = -pad; a.TH = R; a.TW = S;
     }
     const int Q = a.TH * a.TW * a.C;
-    hdy_wgrad_plan(K, Q, (long long)N * a.Ho * a.Wo, dtype, &a.splits, &a.pix_per_split);
-    int rc = hdy_wgrad_launch(a, dtype, (hipStream_t)stream);
+    const int stem_grid = stem ? hdy_wgrad_stem_grid(N, a.Ho, a.Wo, K, dtype) : 0;
+    int rc;
+    if (stem_grid > 0) {
+        a.splits = stem_grid;
+        rc = hdy_wgrad_stem_launch(a, stem_grid, (hipStream_t)stream);
+    } else {
+        hdy_wgrad_plan(K, Q, (long long)N * a.Ho * a.Wo, dtype, &a.splits, &a.pix_per_split);
+        rc = hdy_wgrad_launch(a, dtype, (hipStream_t)stream);
+    }
     if (rc) return rc;
     const int mode = stem ? 1 : 0;
     rc = hdy_wgrad_reduce_launch(a.partial, a.splits, (size_t)K * Q, K_a, Q, mode, C, R, S, grad_a, accumulate, (hipStream_t)stream);

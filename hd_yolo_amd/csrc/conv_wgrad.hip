@@ -222,6 +222,115 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
         }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the 6x6 / stride 2 / pad 2 RGB stem as a patch-resident kernel (bf16).
+// Through wgrad_kernel the stem gathers, per output pixel, six 48-byte window rows of the 4-channel padded image: 288 B of x per
+// 64 B of dy, 2.3 GB of L2->LDS traffic per 64-tile batch -> 484 us against an HBM bound of ~130 us — and it is the LAST weight
+// gradient of the backward pass, with nothing left on the main stream to hide behind.  Here a workgroup stages, per 16 x 32 output
+// tile, the (2*16+4) x (2*32+4) input patch (19.6 KB, read once) and the dy tile (512 pixels x K), and both MFMA operands are
+// transposed LDS reads (ds_read_b64_tr_b16, reduction = the 32 pixels of one tile row):
+//   * A (dy): rows = pixels of the tile row, pitch K*2 bytes;
+//   * B (x):  rows = the same pixels' windows, i.e. patch row 2*ty + r at a row pitch of 16 bytes (two input pixels per output pixel):
+//     overlapping rows, which a transposed read does not mind; columns = (s, c) = 24 contiguous bf16, padded to 32 (the 8 extra
+//     columns read the neighbouring pixels and are dropped at the end).
+// Workgroups are persistent over ~17 tiles and write ONE fp32 slab [K][144] each, summed by wgrad_reduce_kernel as before.
+namespace stemw {
+
+constexpr int TOH = 16, TOW = 32;
+constexpr int PH = 2 * TOH + 4, PWX = 2 * TOW + 4;      // 36 x 68 input pixels (padded image coordinates)
+constexpr int PROW = PWX * 8, PATCH_B = PH * PROW;      // 544, 19584
+constexpr int PCH = PATCH_B / 16;                       // 1224 16-byte pieces
+constexpr int Q = 144;                                  // 6 x 6 x 4
+
+template <int MT>   // K = 16 * MT
+__global__ __launch_bounds__(256) void wgrad_stem_kernel(const WgradArgs p) {
+    constexpr int K = MT * 16, DROW = K * 2;             // bytes per dy pixel
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sP = smem;                            // [36][68][8 B]
+    unsigned char* sD = smem + PATCH_B + 64;             // [512 pixels][DROW]  (+64: the padded B columns of the last patch row read past it)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3;
+    const int tiles_w = p.Wo / TOW, tiles_h = p.Ho / TOH;
+    const int per_img = tiles_w * tiles_h;
+    const int tiles_total = p.N * per_img;
+    const unsigned char* __restrict__ x = (const unsigned char*)p.x;
+    const bf16_t* __restrict__ dy = (const bf16_t*)p.dy;
+
+    f32x4 acc[MT][3];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // this wave's three 16-column tiles of the 6 x 32 column space: nt = 3*wave + b -> (filter row r, column half j)
+    int boff[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        const int nt = wave * 3 + b, r = nt >> 1, j = nt & 1;
+        boff[b] = r * PROW + j * 32 + p4 * 8 + (8 * g + q4) * 16;
+    }
+    const int aoff = (8 * g + q4) * DROW + p4 * 8;
+
+    for (int t = blockIdx.x; t < tiles_total; t += gridDim.x) {
+        const int n = t / per_img, rem = t - n * per_img;
+        const int th = rem / tiles_w, tw = rem - th * tiles_w;
+        const unsigned char* org = x + (((long long)n * p.Hin + 2 * th * TOH) * p.Win + 2 * tw * TOW) * 8;
+        for (int pos = tid; pos < PCH; pos += 256) {
+            const int row = pos / (PROW / 16), c = pos - row * (PROW / 16);
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(org + (long long)row * p.Win * 8 + c * 16),
+                                             (void __attribute__((address_space(3)))*)(sP + (pos - lane) * 16), 16, 0, 0);
+        }
+        const bf16_t* dorg = dy + (((long long)n * p.Ho + th * TOH) * p.Wo + tw * TOW) * p.lddy;
+#pragma unroll
+        for (int i = 0; i < TOH * TOW * (K / 8) / 256; ++i) {
+            const int pos = tid + 256 * i;
+            const int pix = pos / (K / 8), part = pos - pix * (K / 8);
+            const int py = pix / TOW, px = pix - py * TOW;
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(dorg + ((long long)py * p.Wo + px) * p.lddy + part * 8),
+                                             (void __attribute__((address_space(3)))*)(sD + (pos - lane) * 16), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll 4
+        for (int ty = 0; ty < TOH; ++ty) {                 // one MFMA k-step = the 32 pixels of tile row ty
+            V16 af[MT], bf[3];
+            const unsigned char* da = sD + ty * TOW * DROW + aoff;
+#pragma unroll
+            for (int a = 0; a < MT; ++a) {
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(da + a * 32));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(da + a * 32 + 4 * DROW));
+                af[a].h = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+            const unsigned char* xb = sP + 2 * ty * PROW;
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(xb + boff[b]));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(xb + boff[b] + 4 * 16));
+                bf[b].h = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a].h, bf[b].h, acc[a][b], 0, 0, 0);
+        }
+        __syncthreads();                                   // everyone is done with this tile's LDS image
+    }
+
+    float* out = p.partial + (size_t)blockIdx.x * K * Q;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        const int nt = wave * 3 + b, r = nt >> 1, col = (nt & 1) * 16 + i16;
+        if (col >= 24) continue;                           // padding columns
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) out[(size_t)(a * 16 + g * 4 + rr) * Q + r * 24 + col] = acc[a][b][rr];
+    }
+}
+
+}  // namespace stemw
+
 // grad[k][c][r][s] (+)= sum_split partial[split][k][q]
 // mode 0: q = (r*S + s)*C + c          mode 1 (stem): q = r*(S*4) + s*4 + c, c < 3
 // block = 64 outputs x 16 split-lanes: slabs are read coalesced along q and 16 splits are in flight per output
@@ -366,6 +475,30 @@ int hdy_wgrad_launch(WgradArgs a, int dtype, hipStream_t st) {
     if (dtype == HDY_BF16) wgrad_dispatch<bf16_t>(a, sd, sx, grid, st);
     else wgrad_dispatch<float>(a, sd, sx, grid, st);
     HDY_LAUNCH_CHECK("wgrad");
+    return HDY_OK;
+}
+
+// Workgroups (= fp32 slabs) of the patch-resident stem weight gradient, 0 = shape not eligible (generic kernel).
+int hdy_wgrad_stem_grid(int N, int Ho, int Wo, int K, int dtype) {
+    static const bool disabled = getenv("HDY_NO_STEM_WGRAD") != nullptr;
+    if (disabled || dtype != HDY_BF16 || K % 16 != 0 || K > 64 || Ho % stemw::TOH != 0 || Wo % stemw::TOW != 0) return 0;
+    const long long tiles = (long long)N * (Ho / stemw::TOH) * (Wo / stemw::TOW);
+    const int cap = K <= 32 ? 768 : 256;                 // 52 KB of LDS per workgroup at K = 32: three per CU
+    return (int)(tiles < cap ? tiles : cap);
+}
+
+int hdy_wgrad_stem_launch(const WgradArgs& a, int grid, hipStream_t st) {
+    HDY_ARG(((uintptr_t)a.x & 15) == 0 && ((uintptr_t)a.dy & 15) == 0 && a.lddy % 8 == 0 && a.Win % 2 == 0, "wgrad(stem): x/dy alignment");
+    const size_t smem = stemw::PATCH_B + 64 + (size_t)stemw::TOH * stemw::TOW * a.K * 2;
+    const int mt = a.K / 16;
+#define STEMW_LAUNCH(MT)                                                                                                         \
+    {                                                                                                                          \
+        (void)hipFuncSetAttribute((const void*)stemw::wgrad_stem_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+        hipLaunchKernelGGL(stemw::wgrad_stem_kernel<MT>, dim3(grid), dim3(256), smem, st, a);                                  \
+    }
+    if (mt == 1) STEMW_LAUNCH(1) else if (mt == 2) STEMW_LAUNCH(2) else if (mt == 3) STEMW_LAUNCH(3) else STEMW_LAUNCH(4)
+#undef STEMW_LAUNCH
+    HDY_LAUNCH_CHECK("wgrad(stem)");
     return HDY_OK;
 }
 

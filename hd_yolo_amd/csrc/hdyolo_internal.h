@@ -37,6 +37,8 @@ struct WgradArgs {
 };
 
 int hdy_conv_bn_tile(int K);
+int hdy_wgrad_stem_grid(int N, int Ho, int Wo, int K, int dtype);
+int hdy_wgrad_stem_launch(const WgradArgs& a, int grid, hipStream_t st);
 int hdy_conv_igemm_slabs(long long M, int K, int taps);
 int hdy_conv3x3_c64_try(const ConvArgs& a, int dtype, int out_f32, hipStream_t st, int* rc);
 int hdy_conv3x3_c64_slabs(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dtype);

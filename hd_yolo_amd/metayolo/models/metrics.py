@@ -78,7 +78,7 @@ class APMeter:
 
     def add(self, output, target, iou_type='boxes'):
         if iou_type == 'masks' and 'masks' in output and 'masks' in target:
-            raise NotImplementedError('mask IoU belongs to the mask branch (SURVEY §8 row f2)')
+            raise NotImplementedError('mask IoU: the reference calls get_mask_ious here (metrics.py:275), a function its metrics module neither defines nor imports')
         scores, order = torch.sort(output['scores'].detach().float().cpu(), descending=True)
         boxes = output['boxes'].detach().float().cpu()[order]
         labels = output['labels'].detach().cpu()[order]

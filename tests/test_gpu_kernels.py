@@ -167,8 +167,10 @@ def test_stem_patch_kernel_bf16(K):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-def test_stem_conv(dtype):
-    N, H, W, K = 2, 32, 48, 16
+# output sizes that are multiples of 16 x 32 take the patch-resident weight-gradient kernel in bf16 (K = 16, 32, 48, 64; ragged tile counts)
+@pytest.mark.parametrize('shape', [(2, 32, 48, 16), (2, 64, 128, 32), (3, 32, 64, 16), (1, 96, 64, 48), (2, 32, 192, 64)])
+def test_stem_conv(shape, dtype):
+    N, H, W, K = shape
     img = q(rnd((N, 3, H, W), 1).abs(), dtype)
     w = rnd((K, 3, 6, 6), 2, 0.2)
     wq = q(w, dtype)
