@@ -33,7 +33,11 @@
 // and NOT adopted, all within +-0.5 us of 36.9 or worse: patch pieces issued from inside the MFMA loop (38.4: an LDS-DMA costs the
 // wave ~350 cycles of issue time wherever it sits); the patch through registers (global_load + ds_write, 38.0) and the same with two
 // register sets = two items of lead (37.0); inline-asm reads with exact lgkmcnt waits (38.3); starting the second workgroup of
-// a CU on its band item to shift its phase (37.5); first generation with 8-byte stores straight from the accumulators (43.3).
+// a CU on its band item to shift its phase (37.5); first generation with 8-byte stores straight from the accumulators (43.3);
+// deterministic anti-phasing — ONE 8-wave workgroup whose two 4-wave groups alternate "MFMAs of item s" and "epilogue of item s-1 +
+// patch issue" in barrier-closed half-steps (46.7): a lone MFMA wave per SIMD reaches only ~62 % of the pipe rate (1.8-1.9k cycles
+// per half item against 1.15k), which two independently scheduled workgroups hide by overlapping their MFMA phases, and 28 % of
+// the cycles went to waiting at the half-step barriers.
 // Ablation: without the patch fetch 35.1, without the output stores 34.8, without both 32.9 us — the kernel is not memory bound;
 // the MFMA pipe is busy ~45 % of the cycles (1.7 GHz under this load), the rest is per-item work that two waves per SIMD do
 // not overlap completely (patch issue ~2.0k cycles, statistics + staging ~0.6k, row stores ~0.5k, barriers ~0.4k per 8-row item).
