@@ -30,9 +30,10 @@
 //   39.6  first generation: one 8-wave workgroup per CU, filter in LDS (72 KB), 16x16 tiles, 6 LDS reads per 8 MFMAs
 //   40.0  this design with the compiler's schedule (ds_read -> wait -> 3 MFMAs: a wave is LDS-latency bound, 4.4k cycles per item)
 //   36.9  + fragment reads software-pipelined by hand (sched_barrier fences; 3.0k cycles per item alone, 2.3k = MFMA rate)
+//   36.0  + those reads as inline asm with hand-counted lgkmcnt(3) waits (the compiler waits lgkmcnt(0) after every second group)
 // and NOT adopted, all within +-0.5 us of 36.9 or worse: patch pieces issued from inside the MFMA loop (38.4: an LDS-DMA costs the
 // wave ~350 cycles of issue time wherever it sits); the patch through registers (global_load + ds_write, 38.0) and the same with two
-// register sets = two items of lead (37.0); inline-asm reads with exact lgkmcnt waits (38.3); starting the second workgroup of
+// register sets = two items of lead (37.0); a fragment prefetch distance of two groups (36.5 against 35.9); starting the second workgroup of
 // a CU on its band item to shift its phase (37.5); first generation with 8-byte stores straight from the accumulators (43.3);
 // deterministic anti-phasing — ONE 8-wave workgroup whose two 4-wave groups alternate "MFMAs of item s" and "epilogue of item s-1 +
 // patch issue" in barrier-closed half-steps (46.7): a lone MFMA wave per SIMD reaches only ~62 % of the pipe rate (1.8-1.9k cycles
@@ -223,15 +224,32 @@ __global__ __launch_bounds__(NTHR, 2) void conv3x3_c64_kernel(const ConvArgs p) 
         // and the scheduler is fenced from sinking them next to their uses (left alone it emits read -> wait -> 3 MFMAs, which
         // leaves a lone wave LDS-latency bound: 4.4k instead of 3.0k cycles per 8-row item; 2.3k is the MFMA rate).
         V16 fa[2][3];
-        auto load_half = [&](int g, V16* f) {            // group g = (patch row g >> 1, k-half g & 1): its 3 column shifts
+        const unsigned pb_lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)pb;
+        unsigned abase[3][2];
 #pragma unroll
-            for (int s = 0; s < 3; ++s) f[s].i = *(const i32x4*)(pb + aoff[s][g & 1] + (g >> 1) * PW * 128);
-        };
-        load_half(0, fa[0]);
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) abase[s][ks] = pb_lds + aoff[s][ks];
+        // inline-asm reads with hand-counted waits: the compiler's counter insertion waits lgkmcnt(0) right after every second
+        // group's reads were issued and exposes their latency (a lone wave: 3.0k cycles per item instead of 2.3k)
+#define C3_LOAD(G, F)                                                                                                              \
+    {                                                                                                                              \
+        _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_) {                                                                         \
+            i32x4 v_;                                                                                                              \
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v_) : "v"(abase[s_][(G) & 1]), "n"(((G) >> 1) * PW * 128));      \
+            (F)[s_].i = v_;                                                                                                        \
+        }                                                                                                                          \
+    }
+        C3_LOAD(0, fa[0])
 #pragma unroll
         for (int g = 0; g < 2 * (AR + 2); ++g) {         // patch row q serves tile row a with filter row r = q - a
             const int q = g >> 1, ks = g & 1;
-            if (g + 1 < 2 * (AR + 2)) load_half(g + 1, fa[(g + 1) & 1]);
+            if (g + 1 < 2 * (AR + 2)) {
+                C3_LOAD(g + 1, fa[(g + 1) & 1])
+                asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fa[g & 1][0].i), "+v"(fa[g & 1][1].i), "+v"(fa[g & 1][2].i));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[g & 1][0].i), "+v"(fa[g & 1][1].i), "+v"(fa[g & 1][2].i));
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < 3; ++s)
@@ -242,6 +260,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv3x3_c64_kernel(const ConvArgs p) 
                 }
             __builtin_amdgcn_sched_barrier(0);
         }
+#undef C3_LOAD
         if (STATS) {
 #pragma unroll
             for (int a = 0; a < AR; ++a)
