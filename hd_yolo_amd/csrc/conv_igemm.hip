@@ -448,17 +448,37 @@ __global__ __launch_bounds__(2 * BM, (BM == 256 || BN == 128) ? 2 : (BN == 64 ? 
         if (issued < total) { loader_issue(issued % NS); ++issued; }
         const unsigned char* a_s = smem + (it % NS) * STAGE;
         const unsigned char* b_s = a_s + ASZ;
+        if constexpr (BN >= 64 && sizeof(T) == 2) {
+            // both k-halves' fragments are requested before the first half's MFMAs start (the wide tiles have the registers for it)
+            V16 af[2][MT], bf[2][NT];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            V16 af[MT], bf[NT];
+            for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-            for (int a = 0; a < MT; ++a) af[a].i = *(const i32x4*)(a_s + swz(wm * 64 + a * 16 + fr, ks * 4 + fq));
+                for (int a = 0; a < MT; ++a) af[ks][a].i = *(const i32x4*)(a_s + swz(wm * 64 + a * 16 + fr, ks * 4 + fq));
 #pragma unroll
-            for (int b = 0; b < NT; ++b) bf[b].i = *(const i32x4*)(b_s + swz(wn * (BN / 2) + b * 16 + fr, ks * 4 + fq));
+                for (int b = 0; b < NT; ++b) bf[ks][b].i = *(const i32x4*)(b_s + swz(wn * (BN / 2) + b * 16 + fr, ks * 4 + fq));
+                if (ks == 0) __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int a = 0; a < MT; ++a)
+            for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int b = 0; b < NT; ++b) acc[a][b] = mma16<T>(bf[b], af[a], acc[a][b]);
+                for (int a = 0; a < MT; ++a)
+#pragma unroll
+                    for (int b = 0; b < NT; ++b) acc[a][b] = mma16<T>(bf[ks][b], af[ks][a], acc[a][b]);
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                V16 af[MT], bf[NT];
+#pragma unroll
+                for (int a = 0; a < MT; ++a) af[a].i = *(const i32x4*)(a_s + swz(wm * 64 + a * 16 + fr, ks * 4 + fq));
+#pragma unroll
+                for (int b = 0; b < NT; ++b) bf[b].i = *(const i32x4*)(b_s + swz(wn * (BN / 2) + b * 16 + fr, ks * 4 + fq));
+#pragma unroll
+                for (int a = 0; a < MT; ++a)
+#pragma unroll
+                    for (int b = 0; b < NT; ++b) acc[a][b] = mma16<T>(bf[b], af[a], acc[a][b]);
+            }
         }
         if (++c_kb == nkb) {
             __syncthreads();                       // every wave is done reading stage `it`: its slot is scratch until the next barrier
