@@ -32,7 +32,8 @@ def limit_host_threads(max_threads=8):
     the launch thread gets throttled for tens of ms every 100 ms period — measured as a 38 ms stall every third training
     step.  The reference caps its threads for the same reason (metayolo/__init__.py:21,31)."""
     import torch
-    n = max(1, min(max_threads, host_cpu_quota()))
+    ranks = max(1, int(os.environ.get('LOCAL_WORLD_SIZE', '1') or 1))       # one process per GPU shares the node's quota
+    n = max(1, min(max_threads, host_cpu_quota() // ranks))
     if torch.get_num_threads() > n:
         torch.set_num_threads(n)
     os.environ.setdefault('OMP_NUM_THREADS', str(n))
