@@ -53,7 +53,13 @@ def describe(rec):
 
 rows = []
 for phase, recs in (('F', plan.fwd), ('B', plan.bwd or [])):
-    for rec in recs:
+    flat = []
+    for rec in recs:                      # side-stream brackets: time the bracketed launches themselves, on the main stream
+        if rec[0] == '@fork':
+            flat.extend(rec[2])
+        elif rec[0][0] != '@':
+            flat.append(rec)
+    for rec in flat:
         for _ in range(2):
             ops.run([rec])
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
