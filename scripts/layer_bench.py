@@ -49,6 +49,12 @@ def describe(rec):
     if name == 'hdy_bn_act_bwd':
         M, K = a[13], a[14]
         return f'bnbw K={K} M={M}', 0.0, 2.0 * M * K * 5
+    if name == 'hdy_bn_act_fwd_pair':
+        M, K = a[9], a[10]
+        return f'bnfw K={K} M={M} (pair)', 0.0, 2.0 * M * K * 2
+    if name == 'hdy_bn_act_bwd_pair':
+        M, K = a[18], a[19]
+        return f'bnbw K={K} M={M} (pair)', 0.0, 2.0 * M * K * 5
     return name[4:], 0.0, 0.0
 
 rows = []
