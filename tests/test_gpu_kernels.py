@@ -142,6 +142,8 @@ def test_stacked_pack_matches_cat(dtype):
 def test_stem_patch_kernel_bf16(K):
     """Shapes the patch-resident stem kernel takes (bf16, Ho % 16 == 0, Wo % 32 == 0): raw output + statistic slabs (train mode),
     scale/shift + SiLU (eval mode), against torch and against the generic kernel's path for an ineligible width."""
+    if os.environ.get('HDY_NO_STEM_KERNEL'):
+        pytest.skip('the patch-resident stem kernel is switched off')
     dtype = torch.bfloat16
     N, H, W = 3, 64, 192                      # 3 x 2 x 3 = 18 tiles of 16 x 32 outputs
     img = q(rnd((N, 3, H, W), 1).abs(), dtype)
