@@ -69,6 +69,37 @@ __global__ __launch_bounds__(256) void sppf_pool_fwd_kernel(const T* __restrict_
     __syncthreads();
     T* outs[3] = {y1, y2, y3};
     unsigned char* idxs[3] = {i1, i2, i3};
+    if (!i1) {
+        // inference: no window positions wanted, so each 5x5 maximum is a row maximum followed by a column maximum (10 taps for 25;
+        // same values, NaN included: a NaN anywhere in the window wins both stages)
+        auto vmax = [](const f32x4& m, const f32x4& v) {
+            f32x4 r;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r[i] = (v[i] > m[i] || v[i] != v[i]) ? v[i] : m[i];
+            return r;
+        };
+#pragma unroll
+        for (int pass = 0; pass < 3; ++pass) {
+            for (PlaneWalk q(W); q.pix < HW; q.next(W)) {          // rows: a -> b
+                const float* ctr = a + ((q.h + PB) * WP + q.w + PB) * CG + cl;
+                f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+                for (int dx = -2; dx <= 2; ++dx) m = vmax(m, *(const f32x4*)(ctr + dx * CG));
+                *(f32x4*)(b + ((q.h + PB) * WP + q.w + PB) * CG + cl) = m;
+            }
+            __syncthreads();
+            for (PlaneWalk q(W); q.pix < HW; q.next(W)) {          // columns: b -> a (the next pool's source)
+                const float* ctr = b + ((q.h + PB) * WP + q.w + PB) * CG + cl;
+                f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+                for (int dy = -2; dy <= 2; ++dy) m = vmax(m, *(const f32x4*)(ctr + dy * WP * CG));
+                *(f32x4*)(a + ((q.h + PB) * WP + q.w + PB) * CG + cl) = m;
+                store4<T>(outs[pass] + (base + q.pix) * ld + c0, m);
+            }
+            __syncthreads();
+        }
+        return;
+    }
 #pragma unroll
     for (int pass = 0; pass < 3; ++pass) {
         for (PlaneWalk q(W); q.pix < HW; q.next(W)) {

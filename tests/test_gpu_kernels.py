@@ -302,6 +302,18 @@ def test_sppf_pool(shape, dtype):
     idx = [torch.empty((N, H, W, C), dtype=torch.uint8, device=DEV) for _ in range(3)]
     ops.run([ops.rec_sppf_pool_fwd(sl[0], sl[1], sl[2], sl[3], idx)])
     assert torch.equal(from_dev_nhwc(buf), cat.detach()), 'sppf forward must be exact'
+    # inference form (no window positions): row maximum then column maximum, same values; a NaN must poison its whole window
+    buf2 = torch.zeros_like(buf)
+    sl2 = [buf2[..., i * C:(i + 1) * C] for i in range(4)]
+    sl2[0].copy_(sl[0])
+    ops.run([ops.rec_sppf_pool_fwd(sl2[0], sl2[1], sl2[2], sl2[3], None)])
+    assert torch.equal(buf2, buf), 'sppf forward without argmax must equal the training form'
+    xn = x.clone()
+    xn[0, 0, H // 2, W // 2] = float('nan')
+    sl2[0].copy_(xn.permute(0, 2, 3, 1).to(dtype))
+    ops.run([ops.rec_sppf_pool_fwd(sl2[0], sl2[1], sl2[2], sl2[3], None)])
+    want = torch.cat([xn] + [F.max_pool2d(xn, k, 1, k // 2) for k in (5, 9, 13)], 1)
+    assert torch.equal(torch.isnan(from_dev_nhwc(buf2)), torch.isnan(want))
     gd = to_dev_nhwc(g, dtype)
     gs = [gd[..., i * C:(i + 1) * C] for i in range(4)]
     dx = torch.empty((N, H, W, C), dtype=dtype, device=DEV)
