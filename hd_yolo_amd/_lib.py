@@ -37,6 +37,7 @@ SIGNATURES = {
     'hdy_bn_finalize_workspace_bytes': (_Z, [_I, _I]),
     'hdy_bn_finalize': (_I, [_P, _I, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P]),
     'hdy_bn_eval_coeffs': (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
+    'hdy_bn_eval_coeffs_batch': (_I, [_P, _I, _P]),
     'hdy_bn_act_fwd': (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _L, _I, _I, _I, _P]),
     'hdy_bn_bwd_blocks': (_I, [_L]),
     'hdy_bn_finalize_pair': (_I, [_P, _I, _I, _I, _I, _L] + [_P] * 8 + [_F, _F, _P, _P, _P, _P, _P, _P]),
@@ -72,6 +73,11 @@ class PackDesc(ctypes.Structure):
     _fields_ = [('w_a', c_void_p), ('w_b', c_void_p), ('out', c_void_p)] + [(n, c_int) for n in (
         'K_a', 'K_b', 'Kl', 'C', 'R', 'S', 'transpose', 'TH', 'TW', 'rbase', 'rstep', 'sbase', 'sstep', 'stem', 'rows_total', 'Kdp',
         'dtype', 'first_block', 'nblocks', 'pad_')]
+
+
+class BnEvalDesc(ctypes.Structure):
+    """mirror of hdy_bn_eval_desc (include/hdyolo.h)"""
+    _fields_ = [(n, c_void_p) for n in ('gamma', 'beta', 'running_mean', 'running_var', 'scale', 'shift')] + [('K', c_int), ('eps', c_float)]
 
 
 _lib = None

@@ -21,6 +21,7 @@
 // and nn.SiLU inside Conv.forward (metayolo/models/layers.py:37-38), the Bottleneck residual add (:97),
 // and their autograd backward.
 #include "common.h"
+#include "hdyolo.h"
 
 namespace {
 
@@ -178,6 +179,15 @@ __global__ void bn_eval_coeffs_kernel(const float* __restrict__ gamma, const flo
     const float sc = gamma[k] / sqrtf(rvar[k] + eps);
     scale[k] = sc;
     shift[k] = beta[k] - rmean[k] * sc;
+}
+
+__global__ __launch_bounds__(256) void bn_eval_coeffs_batch_kernel(const hdy_bn_eval_desc* __restrict__ table) {
+    const hdy_bn_eval_desc d = table[blockIdx.x];           // one workgroup per BatchNorm
+    for (int k = threadIdx.x; k < d.K; k += 256) {
+        const float sc = d.gamma[k] / sqrtf(d.running_var[k] + d.eps);
+        d.scale[k] = sc;
+        d.shift[k] = d.beta[k] - d.running_mean[k] * sc;
+    }
 }
 
 // ---------------------------------------------------------------- forward apply
@@ -515,6 +525,13 @@ int hdy_bn_eval_coeffs(const float* gamma, const float* beta, const float* runni
     hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(cdiv(K, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta, running_mean,
                        running_var, eps, K, scale, shift);
     HDY_LAUNCH_CHECK("bn_eval_coeffs");
+    return HDY_OK;
+}
+
+int hdy_bn_eval_coeffs_batch(const hdy_bn_eval_desc* descs_device, int ndesc, void* stream) {
+    HDY_ARG(descs_device && ndesc > 0, "bn_eval_coeffs_batch: bad args");
+    hipLaunchKernelGGL(bn_eval_coeffs_batch_kernel, dim3(ndesc), dim3(256), 0, (hipStream_t)stream, descs_device);
+    HDY_LAUNCH_CHECK("bn_eval_coeffs_batch");
     return HDY_OK;
 }
 

@@ -167,6 +167,29 @@ def rec_conv_wgrad(x, dy, grad_a, grad_b, R, S, stride, pad, ws, accumulate=Fals
                                ptr(ws), ws.numel() * ws.element_size(), dcode(x.dtype), stem))
 
 
+class BnEvalTable:
+    """The eval-mode scale / shift of every BatchNorm of a plan in one launch (hdy_bn_eval_coeffs_batch): descriptors are built once,
+    live in a small device table and are replayed before every forward (the running statistics and parameters may have changed)."""
+
+    def __init__(self, device):
+        self.device, self.descs, self.keep, self.table = device, [], [], None
+
+    def add(self, gamma, beta, rmean, rvar, scale, shift, eps=BN_EPS):
+        for t in (gamma, beta, rmean, rvar, scale, shift):
+            assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() >= gamma.numel()
+        self.descs.append(_lib.BnEvalDesc(ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), ptr(scale), ptr(shift), gamma.numel(), float(eps)))
+        self.keep += [gamma, beta, rmean, rvar, scale, shift]
+        self.table = None
+
+    def run(self):
+        if not self.descs:
+            return
+        if self.table is None:
+            raw = b''.join(bytes(d) for d in self.descs)
+            self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+        _lib.call('hdy_bn_eval_coeffs_batch', self.table.data_ptr(), len(self.descs), stream_ptr())
+
+
 class PackTable:
     """All weight re-packing jobs of a plan as ONE launch: descriptors are built once (hdy_conv_pack_describe), live in a small
     device table, and hdy_conv_pack_run replays them after every optimizer step."""

@@ -121,6 +121,7 @@ class Plan:
         self._trace(backbone, neck, head)
         self._allocate()
         self.packs = ops.PackTable(device)          # every weight re-pack of the plan, one launch per step
+        self.bn_eval = ops.BnEvalTable(device)      # eval plans: every BatchNorm's folded scale / shift, one launch per forward
         self.fwd = self._compile_forward()
         self.bwd = self._compile_backward() if training else None
         # the two launch lists have fixed pointers and shapes: after one eager run each they are captured into hipGraphs and
@@ -423,7 +424,7 @@ class Plan:
                     self.packs.add(m.conv.weight, None, u.s, u.p, kind, u.wp)
                     if u.has_bn:
                         g, b, rm, rv = self._bn(m)
-                        recs.append(ops.rec_bn_eval_coeffs(g, b, rm, rv, u.scale, u.shift, eps=m.bn.eps))
+                        self.bn_eval.add(g, b, rm, rv, u.scale, u.shift, eps=m.bn.eps)
                         scale, shift = u.scale, u.shift
                     else:
                         scale, shift = None, m.conv.bias
@@ -466,6 +467,7 @@ class Plan:
             assert tuple(f.shape) == (v.n, v.c, v.h, v.w), (k, tuple(f.shape), (v.n, v.c, v.h, v.w))
             ops.run([ops.rec_nchw_to_nhwc(f.float().contiguous(), v.t())])
         self.packs.run()
+        self.bn_eval.run()
         self._replay('fwd', self.fwd)
         return self.det_views()
 
@@ -480,6 +482,7 @@ class Plan:
         else:
             ops.run([ops.rec_nchw_to_nhwc(images, self.input.t())])
         self.packs.run()
+        self.bn_eval.run()
         self._replay('fwd', self.fwd)
         if self.training:
             torch._foreach_add_(self.bn_counters(), 1)

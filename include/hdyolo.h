@@ -105,6 +105,19 @@ int hdy_bn_finalize(const float* stats, int stats_ld, int mtiles, int K, long lo
                     void* workspace, void* stream);
 int hdy_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, int K,
                        float* scale, float* shift, void* stream);
+/* The same for every BatchNorm of an inference plan in ONE launch: the caller fills the descriptors on the host, copies them into
+ * device memory once and replays hdy_bn_eval_coeffs_batch before every forward (57 launches of 5 us otherwise for yolov5s). */
+typedef struct hdy_bn_eval_desc {
+    const float* gamma;
+    const float* beta;
+    const float* running_mean;
+    const float* running_var;
+    float* scale;
+    float* shift;
+    int K;
+    float eps;
+} hdy_bn_eval_desc;
+int hdy_bn_eval_coeffs_batch(const hdy_bn_eval_desc* descs_device, int ndesc, void* stream);
 int hdy_bn_act_fwd(const void* y, int ldy, const float* scale, const float* shift, const void* res, int ldr, void* z, int ldz,
                    long long M, int K, int act, int dtype, void* stream);
 int hdy_bn_bwd_blocks(long long M);
