@@ -171,41 +171,52 @@ class Engine:
     def __reduce__(self):
         return (type(None), ())
 
-    def _params(self):
-        seen, out = set(), []
+    def _scan(self):
+        """One walk over the module trees of the parts: (parameters in registration order, their ids, requires_grad flags, which Conv
+        modules still own a BatchNorm).  Done on every call (a caller may have swapped parameters or fused / frozen modules since
+        the last one) — hence a bare stack walk over `_modules` / `_parameters`: nn.Module.parameters() + .modules() cost 1 ms per
+        call on yolov5s, more than the whole inference launch list."""
+        params, seen, fused = [], set(), []
+        stack = []
         for part in self.parts:
             if part is None:
                 continue
-            mods = part if not isinstance(part, nn.Module) else [part]
-            for m in mods:
-                for p in m.parameters():
-                    if id(p) not in seen:
-                        seen.add(id(p))
-                        out.append(p)
-        return out
+            stack.extend(reversed(list(part) if not isinstance(part, nn.Module) else [part]))
+        mods_seen = set()
+        while stack:
+            m = stack.pop()
+            if id(m) in mods_seen:
+                continue
+            mods_seen.add(id(m))
+            if type(m).__name__ == 'Conv':
+                fused.append('bn' in m._modules)
+            for q in m._parameters.values():
+                if q is not None and id(q) not in seen:
+                    seen.add(id(q))
+                    params.append(q)
+            stack.extend(reversed([c for c in m._modules.values() if c is not None]))
+        return params, tuple(id(q) for q in params), tuple(q.requires_grad for q in params), tuple(fused)
 
-    def _signature(self):
-        b, n, h = self.parts
-        fused = tuple(hasattr(m, 'bn') for part in (b, n) if part is not None for m in part.modules() if type(m).__name__ == 'Conv')
-        # requires_grad flags select which backward launches a training plan contains (Model.freeze)
-        return hash((fused, tuple(p.requires_grad for p in self._params())))
+    def _params(self):
+        return self._scan()[0]
 
-    def _check_parameters(self):
+    def _check_and_sign(self):
         """Plans and the flat gradient store hold the parameter OBJECTS they were traced with: when a caller swaps some (e.g.
-        manipulate_header_label_order replaces the header's detection convs) everything is rebuilt."""
-        ids = tuple(id(p) for p in self._params())
+        manipulate_header_label_order replaces the header's detection convs) everything is rebuilt.  Returns the plan-cache
+        signature: which convs are fused, and the requires_grad flags that select the backward launches (Model.freeze)."""
+        _, ids, flags, fused = self._scan()
         if ids != self.__dict__.get('_param_ids'):
             if '_param_ids' in self.__dict__:
                 self.plans.clear()
                 self.store = None
                 self.hook = None
             self._param_ids = ids
+        return hash((fused, flags))
 
     def plan_for(self, x, training, dtype):
         ops.require_gpu(x)
         _lib.load()
-        self._check_parameters()
-        key = (tuple(x.shape), dtype, bool(training), x.device.index, self._signature())
+        key = (tuple(x.shape), dtype, bool(training), x.device.index, self._check_and_sign())
         plan = self.plans.get(key)
         if plan is None:
             if training and self.store is None:
@@ -221,10 +232,9 @@ class Engine:
     def plan_for_features(self, feats, dtype):
         """Eval plan of (neck, head) fed with bare feature maps {layer index: NCHW tensor} (FPN.forward / Detect.forward)."""
         _lib.load()
-        self._check_parameters()
         shapes = {k: tuple(v.shape) for k, v in feats.items() if isinstance(k, int) and k >= 0}
         dev = next(iter(feats.values())).device
-        key = ('features', tuple(sorted(shapes.items())), dtype, dev.index, self._signature())
+        key = ('features', tuple(sorted(shapes.items())), dtype, dev.index, self._check_and_sign())
         plan = self.plans.get(key)
         if plan is None:
             if len(self.plans) >= self.max_plans:

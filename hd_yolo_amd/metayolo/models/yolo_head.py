@@ -163,6 +163,9 @@ class Detect(nn.Module):
         else:
             want_loss, want_out = targets is not None, True
         compute_masks = bool(compute_masks) and self.nc_masks > 0 and mask_ctx is not None
+        if want_out and not want_loss:
+            # plain inference: all levels are decoded straight into the (bs, N, no + 1) tensor the NMS kernel reads
+            return {}, self.compute_outputs(self.decode_all(dets), mask_ctx, compute_masks=compute_masks)
         preds = self.compute_proposals(dets) if (want_out or (want_loss and compute_masks)) else []
         losses = self.compute_losses(dets, preds, mask_ctx, targets, compute_masks=compute_masks) if want_loss else {}
         outputs = self.compute_outputs(preds, mask_ctx, compute_masks=compute_masks) if want_out else []
@@ -178,15 +181,26 @@ class Detect(nn.Module):
         for i, d in enumerate(dets):
             bs, na, ny, nx, no = d.shape
             out = torch.empty((bs, na * ny * nx, no + 1), dtype=torch.float32, device=d.device)
-            _ops.decode_level(d, self._anchor_px_cached(i), float(self.anchors[i].stride), out, 0, i)
+            _ops.decode_level(d, self._anchor_px_cached(i), self._stride_cached(i), out, 0, i)
             preds.append(out[..., :no].view(bs, na, ny, nx, no))
         return preds
 
+    def _stride_cached(self, i):
+        """Stride of level i as a python float (the buffer lives on the GPU: float(buffer) is a device-to-host sync per call).
+        Cached against the buffer's version counter, which load_state_dict bumps."""
+        buf = self.anchors[i].stride
+        cache = self.__dict__.setdefault('_strides', {})
+        if cache.get(i, (None, None))[0] != (id(buf), buf._version):
+            cache[i] = ((id(buf), buf._version), float(buf))
+        return cache[i][1]
+
     def _anchor_px_cached(self, i):
+        bufs = self.anchors[i]
+        key = (id(bufs.anchor), bufs.anchor._version, id(bufs.stride), bufs.stride._version)
         cache = self.__dict__.setdefault('_apx', {})
-        if i not in cache:
-            cache[i] = self.anchor_px(i)
-        return cache[i]
+        if cache.get(i, (None, None))[0] != key:
+            cache[i] = (key, self.anchor_px(i))
+        return cache[i][1]
 
     def decode_all(self, dets: List[torch.Tensor]) -> torch.Tensor:
         """All levels decoded straight into one (bs, sum na*ny*nx, no+1) tensor with the level id in the last column
@@ -196,7 +210,7 @@ class Detect(nn.Module):
         out = torch.empty((bs, sum(rows), self.no + 1), dtype=torch.float32, device=dets[0].device)
         off = 0
         for i, d in enumerate(dets):
-            _ops.decode_level(d, self._anchor_px_cached(i), float(self.anchors[i].stride), out, off, i)
+            _ops.decode_level(d, self._anchor_px_cached(i), self._stride_cached(i), out, off, i)
             off += rows[i]
         return out
 
@@ -247,7 +261,7 @@ class Detect(nn.Module):
         for l in range(self.nl):
             sel = (levels == l).nonzero().flatten()
             pos.append(sel)
-            parts.append(_ops.roi_align(feats[l], rois[sel], 1.0 / float(self.anchors[l].stride), P, 2, self.aligned))
+            parts.append(_ops.roi_align(feats[l], rois[sel], 1.0 / self._stride_cached(l), P, 2, self.aligned))
         order = torch.empty(len(rois), dtype=torch.long, device=dev)
         order[torch.cat(pos)] = torch.arange(len(rois), device=dev)
         logits = MaskHeadRun(self.seg_h, dtype).forward(torch.cat(parts)[order].contiguous())        # (R, 28, 28, nc_masks) fp32

@@ -7,6 +7,7 @@ device addresses.  Records are either executed at once (`run`) or stored in a st
 (hd_yolo_amd/plan.py) and replayed every step with no further Python-side work.
 """
 import ctypes
+import os
 
 import torch
 
@@ -167,6 +168,13 @@ def rec_conv_wgrad(x, dy, grad_a, grad_b, R, S, stride, pad, ws, accumulate=Fals
                                ptr(ws), ws.numel() * ws.element_size(), dcode(x.dtype), stem))
 
 
+ALWAYS_REPACK = os.environ.get('HDY_ALWAYS_REPACK') is not None
+
+
+def _versions(tensors):
+    return tuple((t.data_ptr(), t._version) for t in tensors if t is not None)
+
+
 class BnEvalTable:
     """The eval-mode scale / shift of every BatchNorm of a plan in one launch (hdy_bn_eval_coeffs_batch): descriptors are built once,
     live in a small device table and are replayed before every forward (the running statistics and parameters may have changed)."""
@@ -181,12 +189,18 @@ class BnEvalTable:
         self.keep += [gamma, beta, rmean, rvar, scale, shift]
         self.table = None
 
-    def run(self):
+    def run(self, skip_unchanged=False):
         if not self.descs:
             return
         if self.table is None:
             raw = b''.join(bytes(d) for d in self.descs)
             self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+            self.seen = None
+        if skip_unchanged and not ALWAYS_REPACK:
+            now = _versions(self.keep)
+            if now == self.seen:
+                return
+            self.seen = now
         _lib.call('hdy_bn_eval_coeffs_batch', self.table.data_ptr(), len(self.descs), stream_ptr())
 
 
@@ -214,12 +228,21 @@ class PackTable:
         self.keep += [w_a, w_b, out]
         self.table = None
 
-    def run(self):
+    def run(self, skip_unchanged=False):
+        """skip_unchanged (inference plans): re-pack only when a source tensor's version counter moved since the last run.  Every
+        in-place write through the parameter itself (optimizer steps, load_state_dict, EMA updates on state_dict() tensors) bumps
+        it; writes through `param.data` do not — after those, call model.train(); model.eval() or set HDY_ALWAYS_REPACK=1."""
         if not self.descs:
             return
         if self.table is None:
             raw = b''.join(bytes(d) for d in self.descs)
             self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+            self.seen = None
+        if skip_unchanged and not ALWAYS_REPACK:
+            now = _versions(self.keep[0::3] + self.keep[1::3])
+            if now == self.seen:
+                return
+            self.seen = now
         _lib.call('hdy_conv_pack_run', self.table.data_ptr(), len(self.descs), self.blocks, stream_ptr())
 
 

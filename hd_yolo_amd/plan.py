@@ -466,8 +466,8 @@ class Plan:
             ops.require_gpu(f)
             assert tuple(f.shape) == (v.n, v.c, v.h, v.w), (k, tuple(f.shape), (v.n, v.c, v.h, v.w))
             ops.run([ops.rec_nchw_to_nhwc(f.float().contiguous(), v.t())])
-        self.packs.run()
-        self.bn_eval.run()
+        self.packs.run(skip_unchanged=not self.training)
+        self.bn_eval.run(skip_unchanged=not self.training)
         self._replay('fwd', self.fwd)
         return self.det_views()
 
@@ -481,8 +481,8 @@ class Plan:
             ops.run([ops.rec_stem_prep(images, self.prep)])
         else:
             ops.run([ops.rec_nchw_to_nhwc(images, self.input.t())])
-        self.packs.run()
-        self.bn_eval.run()
+        self.packs.run(skip_unchanged=not self.training)
+        self.bn_eval.run(skip_unchanged=not self.training)
         self._replay('fwd', self.fwd)
         if self.training:
             torch._foreach_add_(self.bn_counters(), 1)

@@ -313,3 +313,23 @@ def test_bf16_training_on_a_fixed_batch_reduces_the_loss():
     assert all(l == l and abs(l) < 1e6 for l in losses), losses
     assert losses[-1] < 0.7 * losses[0], (losses[0], losses[-1])
     assert min(losses[-5:]) < min(losses[:5])
+
+
+def test_eval_plan_follows_weight_updates():
+    """Inference plans skip the weight re-pack and the folded BatchNorm coefficients while the version counters of their sources stand
+    still; an in-place update of a weight or of a running statistic (what optimizers, load_state_dict and EMA do) must show."""
+    m = build('n', 2).eval()
+    x = synth.synth_images(1, 64, seed=7).to(DEV)
+    with torch.no_grad():
+        plan = m._eng().plan_for(x, False, torch.float32)
+        plan.run_forward(x)
+        a = plan.feature(9).clone()
+        plan.run_forward(x)
+        assert torch.equal(plan.feature(9), a)
+        m.backbone[0].conv.weight.mul_(1.5)
+        plan.run_forward(x)
+        b = plan.feature(9).clone()
+        assert not torch.equal(a, b)
+        m.backbone[1].bn.running_var.mul_(4.0)
+        plan.run_forward(x)
+        assert not torch.equal(plan.feature(9), b)
