@@ -37,8 +37,6 @@ class Model(nn.Module):
             LOGGER.info(f'Overriding model.cfg anchors with anchors={anchors}')
             self.cfg['anchors'] = round(anchors)
         self.backbone, self.neck, self.headers = build_network(self.cfg, self.hyp, is_scripting=is_scripting)
-        if len(self.headers) != 1:
-            raise NotImplementedError('multi-header models are outside this round\'s hot path (one Detect header)')
         initialize_weights(self)
         self.info()
         LOGGER.info('')
@@ -47,8 +45,8 @@ class Model(nn.Module):
     def _eng(self):
         eng = self.__dict__.get('_hdy_engine')
         if eng is None:
-            head = next(iter(self.headers.values()))
-            eng = _engine.Engine(self.backbone, self.neck, head)
+            heads = list(self.headers.values())
+            eng = _engine.Engine(self.backbone, self.neck, heads[0] if len(heads) == 1 else heads)
             object.__setattr__(self, '_hdy_engine', eng)
         return eng
 
@@ -72,7 +70,7 @@ class Model(nn.Module):
     # ------------------------------------------------------------------ forward
     def forward(self, x: torch.Tensor, targets=None, visualize=False, compute_masks=False):
         dtype = _engine.compute_dtype(self, x)
-        if self.training and targets is not None and torch.is_grad_enabled():
+        if self.training and targets is not None and torch.is_grad_enabled() and len(self.headers) == 1:
             task_id, header = next(iter(self.headers.items()))
             if header.fused_loss_ok() and all(task_id in t['anns'] and len(t['anns'][task_id]) == 1 for t in targets):
                 # forward launch list, then target assignment + loss + logits gradient in one fused launch sequence
@@ -81,8 +79,14 @@ class Model(nn.Module):
                 return {task_id: losses}, self.post_processing([{task_id: o} for o in []])
         plan, dets = self._eng().forward(x, self.training, dtype)
         losses, outputs = {}, {}
+        first = 0
         for task_id, header in self.headers.items():
-            task_dets, task_gts = dets, None
+            # the plan lists the logits header after header (several headers: each runs its own matcher / DetLoss / outputs on its
+            # levels; the shared backbone and neck receive the sum of their gradients — reference: yolo.py:62-81)
+            nl = len(header.m)
+            task_dets, task_gts = dets[first:first + nl], None
+            first += nl
+            all_dets = task_dets
             if targets is not None:
                 task_gts, keep = [], []
                 for idx, t in enumerate(targets):
@@ -91,8 +95,8 @@ class Model(nn.Module):
                         keep.extend([idx] * len(t['anns'][task_id]))
                 if keep != list(range(x.shape[0])):
                     sel = torch.tensor(keep, device=x.device, dtype=torch.long)
-                    task_dets = [d.index_select(0, sel) for d in dets]
-            mask_ctx = (self._eng(), plan, dtype) if getattr(header, 'nc_masks', 0) > 0 else None
+                    task_dets = [d.index_select(0, sel) for d in all_dets]
+            mask_ctx = (self._eng(), plan, dtype) if getattr(header, 'nc_masks', 0) > 0 and len(self.headers) == 1 else None
             losses[task_id], outputs[task_id] = header.forward_dets(task_dets, task_gts, compute_masks=compute_masks, mask_ctx=mask_ctx)
         outputs = [dict(zip(outputs.keys(), per_image)) for per_image in zip(*outputs.values())]
         return losses, self.post_processing(outputs)

@@ -260,15 +260,24 @@ class Plan:
                 outs[m.i] = cur
             self.feature_keys = list(neck.save)
         self.outs = outs
-        self.det_units = []
-        if head is not None:
-            f = head.f if isinstance(head.f, (list, tuple)) else [head.f]
-            for l, (j, conv) in enumerate(zip(f, head.m)):
+        # one or several Detect headers on the same feature maps (yolo.py:62-81 loops over self.headers): their 1x1 detection convs are
+        # all units of this plan; det_views() lists the logits header after header, level after level
+        heads = [] if head is None else (list(head) if isinstance(head, (list, tuple)) else [head])
+        self.det_units, self.det_split = [], []
+        for hi, hd in enumerate(heads):
+            f = hd.f if isinstance(hd.f, (list, tuple)) else [hd.f]
+            for l, (j, conv) in enumerate(zip(f, hd.m)):
                 self._use(outs[j])
                 u = DetUnit(conv, outs[j], l)
+                u.head, u.na, u.no = hi, hd.na, hd.no
                 self.units.append(u)
                 self.det_units.append(u)
-            self.na, self.no = head.na, head.no
+            self.det_split.append(len(f))
+        if heads:
+            self.na, self.no = heads[0].na, heads[0].no
+        if len(heads) > 1 and any(getattr(hd, 'seg', None) is not None for hd in heads):
+            raise _lib.HdyError('a mask branch is supported on single-header models only')
+        head = heads[0] if len(heads) == 1 else None       # the mask branch below belongs to a lone header
         # mask branch: one 3x3 Conv per level, top-down module order (yolo_head.py:123-124, :170-173); their outputs
         # feed roi_align outside the plan and their output gradients arrive from there (MaskBranch in engine.py)
         self.mask_vals = []
@@ -492,7 +501,7 @@ class Plan:
         views = []
         for u in self.det_units:
             x = u.x
-            views.append(u.logits[..., :u.K].view(x.n, x.h, x.w, self.na, self.no).permute(0, 3, 1, 2, 4))
+            views.append(u.logits[..., :u.K].view(x.n, x.h, x.w, u.na, u.no).permute(0, 3, 1, 2, 4))
         return views
 
     def mask_features(self):
@@ -670,7 +679,7 @@ class Plan:
                 if g is None:
                     u.gdet.zero_()
                 else:
-                    pre.append(ops.rec_det_grad_pack(g, u.gdet, self.na, self.no))
+                    pre.append(ops.rec_det_grad_pack(g, u.gdet, u.na, u.no))
         ops.run(pre)
         if self.mask_vals and not self.mask_grads_ready:
             for v in self.mask_vals:                 # no mask loss in this step: the branch contributes nothing
