@@ -50,9 +50,19 @@ def model_info(model, verbose=False, img_size=640):
 
 
 def scale_img(img, ratio=1.0, same_shape=False, gs=32):
+    """Test-time-augmentation helper (reference: utils_torch.py:127-137): bilinear resize of a (bs, 3, H, W) batch by `ratio`, then
+    grey (0.447) padding on the right / bottom up to the next multiple of `gs` of the scaled size (same_shape: up to the old size).
+    Image preprocessing on the caller's device with stock torch ops — not part of the HIP path."""
     if ratio == 1.0:
         return img
-    raise NotImplementedError('scale_img (test-time augmentation) is outside the hot path')
+    old_h, old_w = img.shape[2:]
+    new_h, new_w = int(old_h * ratio), int(old_w * ratio)
+    out = torch.nn.functional.interpolate(img, size=(new_h, new_w), mode='bilinear', align_corners=False)
+    if same_shape:
+        tgt_h, tgt_w = old_h, old_w
+    else:
+        tgt_h, tgt_w = (math.ceil(v * ratio / gs) * gs for v in (old_h, old_w))
+    return torch.nn.functional.pad(out, [0, tgt_w - new_w, 0, tgt_h - new_h], value=0.447)
 
 
 def freeze_params(model, layers=()):

@@ -466,10 +466,26 @@ def gen_masks():
           'mask grad l2', float(out['gradsum'][names.index('headers.det.seg_h.maskrcnn_heads.mask_fcn1.weight'), 2]))
 
 
+def gen_scale_img():
+    """utils_torch.scale_img (test-time augmentation resize + pad) on a seeded batch, three (ratio, same_shape) settings."""
+    ut = importlib.import_module('metayolo.models.utils_torch')
+    g = torch.Generator().manual_seed(21)
+    x = torch.rand((2, 3, 64, 96), generator=g)
+    out = {'x': npf(x)}
+    for i, (r, ss) in enumerate(((0.83, False), (0.67, True), (1.5, False))):
+        out[f'y{i}'] = npf(ut.scale_img(x, r, ss, gs=32))
+        out[f'arg{i}'] = np.array([r, float(ss)])
+    np.savez_compressed(os.path.join(HERE, 'scale_img.npz'), **out)
+    print('wrote scale_img.npz', [out[f'y{i}'].shape for i in range(3)])
+
+
 def main():
     assert os.path.isdir(REF), 'the reference is only mounted in the build container'
     torch.set_num_threads(8)
     install_shims()
+    if sys.argv[1:] == ['scale_img']:
+        gen_scale_img()
+        return
     if sys.argv[1:] == ['p6']:                 # only the P6 fixtures (the others are unchanged by construction)
         gen_stages('n6_128', 'n6', 3, 2, 128, full=False)
         gen_train('n6_128', 'n6', 3, 2, 128, 4, 12)
@@ -487,6 +503,7 @@ def main():
     gen_f3()
     gen_nms_options()
     gen_masks()
+    gen_scale_img()
 
 
 if __name__ == '__main__':
