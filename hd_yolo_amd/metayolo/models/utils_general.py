@@ -178,6 +178,39 @@ def box_iou(box1, box2):
     return inter / (box_area(box1.T)[:, None] + box_area(box2.T) - inter)
 
 
+def wh_iou(wh1, wh2):
+    """(n, m) IoU of boxes given by width / height only, as if they shared a corner (reference: utils_general.py:234-239)."""
+    a, b = wh1[:, None, :], wh2[None, :, :]
+    overlap = torch.minimum(a, b).prod(-1)
+    return overlap / (a.prod(-1) + b.prod(-1) - overlap)
+
+
+def mask_iou(y_pred, y_true, factor=0.0, axis=(2, 3), eps=0.):
+    """Soft overlap of two mask stacks: (2 + factor) * sum(t*p) / (sum(t + p) + factor * sum(t*p) + eps); factor 0 (or 'dice') is
+    the Dice coefficient, -1 (or 'iou') the IoU (reference: utils_general.py:268-280; SegLoss type 'dice' uses factor 0)."""
+    factor = {'dice': 0.0, 'iou': -1.0}.get(factor, factor) if isinstance(factor, str) else factor
+    both = (y_true * y_pred).sum(list(axis))
+    total = (y_true + y_pred).sum(list(axis))
+    return (2 + factor) * both / (total + factor * both + eps)
+
+
+def xyn2xy(x, w=640, h=640, padw=0, padh=0):
+    """Normalised (n, 2) points -> pixels, with an offset (reference: utils_general.py:153-158)."""
+    y = x.clone() if isinstance(x, torch.Tensor) else np.copy(x)
+    y[:, 0] = x[:, 0] * w + padw
+    y[:, 1] = x[:, 1] * h + padh
+    return y
+
+
+def check_anchor_order(m):
+    """Stock-YOLOv5 Detect layout (m.anchors (nl, na, 2), m.stride (nl,)): flip the anchor rows when their mean area runs against the
+    stride order (reference: utils_general.py:31-38; metayolo's own Detect keeps per-level buffers and does not call it)."""
+    area = m.anchors.prod(-1).mean(-1).view(-1)
+    da, ds = area[-1] - area[0], m.stride[-1] - m.stride[0]
+    if da and da.sign() != ds.sign():
+        m.anchors[:] = m.anchors.flip(0)
+
+
 def paired_box_iou(boxes1, boxes2):
     """Row-wise IoU of two (N,4) xyxy sets."""
     wh = (torch.min(boxes1[:, 2:], boxes2[:, 2:]) - torch.max(boxes1[:, :2], boxes2[:, :2])).clamp(min=0)
