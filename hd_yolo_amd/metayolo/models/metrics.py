@@ -37,6 +37,64 @@ def ap_per_class(tp, conf, pred_cls, target_cls, eps=1e-16):
     return p, r, ap, f1, classes.astype(int)
 
 
+class ConfusionMatrix:
+    """Detection confusion matrix with a background row / column (reference: metrics.py:114-169; val_nuclei.py:123 builds one per
+    task).  matrix[predicted class, true class]; index nc = background (a missed label counts in row nc, a detection that matched
+    nothing in column nc).  Matching: pairs with IoU > iou_thres; every detection keeps its best label, then every label its best
+    detection."""
+
+    def __init__(self, nc, conf=0.25, iou_thres=0.45):
+        self.matrix = np.zeros((nc + 1, nc + 1))
+        self.nc, self.conf, self.iou_thres = nc, conf, iou_thres
+
+    def process_batch(self, detections, labels):
+        """detections (n, 6) x1, y1, x2, y2, conf, class; labels (m, 5) class, x1, y1, x2, y2."""
+        detections = detections[detections[:, 4] > self.conf]
+        true_cls = labels[:, 0].int().tolist()
+        det_cls = detections[:, 5].int().tolist()
+        iou = box_iou(labels[:, 1:].float().cpu(), detections[:, :4].float().cpu()).numpy()       # (labels, detections)
+        li, di = np.nonzero(iou > self.iou_thres)
+        order = np.argsort(-iou[li, di], kind='stable')
+        label_of = {}                                   # detection -> its best label
+        for k in order:
+            label_of.setdefault(int(di[k]), (int(li[k]), float(iou[li[k], di[k]])))
+        det_of = {}                                     # label -> its best detection among those
+        for d, (l, v) in sorted(label_of.items(), key=lambda kv: -kv[1][1]):
+            det_of.setdefault(l, d)
+        for l, c in enumerate(true_cls):
+            if l in det_of:
+                self.matrix[det_cls[det_of[l]], c] += 1
+            else:
+                self.matrix[self.nc, c] += 1
+        if det_of:                                      # (with no match at all the reference counts no unmatched detections)
+            used = set(det_of.values())
+            for d, c in enumerate(det_cls):
+                if d not in used:
+                    self.matrix[c, self.nc] += 1
+
+    def tp_fp(self):
+        tp = self.matrix.diagonal()
+        return tp[:-1], (self.matrix.sum(1) - tp)[:-1]
+
+
+def summarize_precision_recall(stats_list, labels_text):
+    """Pool per-image rows {label: (n_matched, n_true, n_pred, mean IoU)} into per-label precision / recall / F1 / mean IoU
+    (reference: metrics.py:601-616)."""
+    pooled = {}
+    for stat in stats_list:
+        for k, v in stat.items():
+            pooled.setdefault(k, []).append(v)
+    out = {}
+    for k, rows in pooled.items():
+        rows = np.array(rows)
+        matched, n_true, n_pred = rows[:, 0].sum(), rows[:, 1].sum(), rows[:, 2].sum()
+        precision = matched / n_pred if n_pred > 0 else np.nan
+        recall = matched / n_true if n_true > 0 else np.nan
+        out[labels_text[k]] = {'precision': precision, 'recall': recall, 'f1': 2 * precision * recall / (precision + recall),
+                               'miou': rows[:, 3].mean()}
+    return out
+
+
 class APMeter:
     """Dataset-level detection AP with the reference's accumulation and matching rules (metayolo/models/metrics.py:251-375).
 

@@ -479,10 +479,44 @@ def gen_scale_img():
     print('wrote scale_img.npz', [out[f'y{i}'].shape for i in range(3)])
 
 
+def gen_confusion():
+    """metrics.ConfusionMatrix.process_batch over three seeded images (jittered copies of the labels + clutter), and tp_fp()."""
+    mt = importlib.import_module('metayolo.models.metrics')
+    g = torch.Generator().manual_seed(33)
+    nc = 4
+    cm = mt.ConfusionMatrix(nc=nc, conf=0.25, iou_thres=0.45)
+    out = {'nc': np.array(nc)}
+    for i in range(3):
+        m = 12 + 3 * i
+        xy = torch.rand((m, 2), generator=g) * 400
+        wh = torch.rand((m, 2), generator=g) * 60 + 10
+        lab_boxes = torch.cat([xy, xy + wh], 1)
+        labels = torch.cat([torch.randint(0, nc, (m, 1), generator=g).float(), lab_boxes], 1)
+        jit = lab_boxes[: m - 3] + (torch.rand((m - 3, 4), generator=g) - 0.5) * 14
+        clutter_xy = torch.rand((5, 2), generator=g) * 400
+        clutter = torch.cat([clutter_xy, clutter_xy + 30], 1)
+        boxes = torch.cat([jit, clutter, lab_boxes[:2] + 1.0])                 # two labels get a second, near-duplicate detection
+        conf = torch.rand((len(boxes), 1), generator=g)
+        cls = torch.cat([labels[: m - 3, :1], torch.randint(0, nc, (7, 1), generator=g).float()])
+        flip = torch.rand((len(boxes), 1), generator=g) < 0.25
+        cls = torch.where(flip, (cls + 1) % nc, cls)
+        det = torch.cat([boxes, conf, cls], 1)
+        cm.process_batch(det, labels)
+        out[f'det{i}'], out[f'lab{i}'] = npf(det), npf(labels)
+    out['matrix'] = np.array(cm.matrix)
+    tp, fp = cm.tp_fp()
+    out['tp'], out['fp'] = np.array(tp), np.array(fp)
+    np.savez_compressed(os.path.join(HERE, 'confusion.npz'), **out)
+    print('wrote confusion.npz', out['matrix'].sum(), out['tp'], out['fp'])
+
+
 def main():
     assert os.path.isdir(REF), 'the reference is only mounted in the build container'
     torch.set_num_threads(8)
     install_shims()
+    if sys.argv[1:] == ['confusion']:
+        gen_confusion()
+        return
     if sys.argv[1:] == ['scale_img']:
         gen_scale_img()
         return
@@ -504,6 +538,7 @@ def main():
     gen_nms_options()
     gen_masks()
     gen_scale_img()
+    gen_confusion()
 
 
 if __name__ == '__main__':
