@@ -33,7 +33,8 @@
 //   36.0  + those reads as inline asm with hand-counted lgkmcnt(3) waits (the compiler waits lgkmcnt(0) after every second group)
 // and NOT adopted, all within +-0.5 us of 36.9 or worse: patch pieces issued from inside the MFMA loop (38.4: an LDS-DMA costs the
 // wave ~350 cycles of issue time wherever it sits); the patch through registers (global_load + ds_write, 38.0) and the same with two
-// register sets = two items of lead (37.0); a fragment prefetch distance of two groups (36.5 against 35.9); starting the second workgroup of
+// register sets = two items of lead (37.0); a fragment prefetch distance of two groups (36.5 against 35.9); pairing each top-half fragment
+// group with a bottom-half one so that no accumulator takes back-to-back MFMAs (35.8 against 35.9: the pipe forwards them); starting the second workgroup of
 // a CU on its band item to shift its phase (37.5); first generation with 8-byte stores straight from the accumulators (43.3);
 // deterministic anti-phasing — ONE 8-wave workgroup whose two 4-wave groups alternate "MFMAs of item s" and "epilogue of item s-1 +
 // patch issue" in barrier-closed half-steps (46.7): a lone MFMA wave per SIMD reaches only ~62 % of the pipe rate (1.8-1.9k cycles
