@@ -1,4 +1,4 @@
-// 3x3 / stride 1 / pad 1 convolution for 64 input channels (bf16), filter resident in REGISTERS — the kernel behind the
+// 3x3 / stride 1 / pad 1 convolution for 64 (or 32) input channels (bf16), filter resident in REGISTERS — the kernel behind the
 // layer BASELINE.json names ("fused 3x3 conv at batch 64 x 640 x 640": yolov5s' 64->64 @80x80) and its dgrad.
 //
 // Why a second conv kernel: the generic implicit GEMM (conv_igemm.hip) fetches the A operand once per tap — 9x the
@@ -44,7 +44,11 @@
 // the MFMA pipe is busy ~45 % of the cycles (1.7 GHz under this load), the rest is per-item work that two waves per SIMD do
 // not overlap completely (patch issue ~2.0k cycles, statistics + staging ~0.6k, row stores ~0.5k, barriers ~0.4k per 8-row item).
 //
-// Requirements (checked by the launcher, otherwise the generic kernel runs): bf16 in/out, C == 64, K <= 64, R = S = 3,
+// The same kernel is instantiated for C == 32 (yolov5s' 32->32 3x3 at 160x160 and its dgrad): 64-byte patch rows need no swizzle, one
+// MFMA k-step per tap, 36 filter VGPRs; for K == 32 two of the four waves carry zero filters.  64 x 160 x 160, 32->32: 75 us against
+// 134 us through the generic kernel (in the train step 70 + 58 us for forward + dgrad against 2 x ~103 us).
+//
+// Requirements (checked by the launcher, otherwise the generic kernel runs): bf16 in/out, C == 64 or 32, K <= 64, R = S = 3,
 // stride 1, pad 1, H % 8 == 0, W % 16 == 0, 16-byte aligned rows.
 #include <stdlib.h>
 
@@ -81,17 +85,22 @@ struct Item { int n, th, tw, row0, nrows; };   // rows [row0, row0 + nrows) of t
 
 constexpr int NTHR = 256;                                            // 4 waves: wave = 16-channel group
 constexpr int TH = 8, TW = 16, PW = TW + 2, PPIX = (TH + 2) * PW;    // 180 patch pixels
-constexpr int PATCH_B = PPIX * 128;                                  // 23040
 constexpr int STAGE_B = TH * TW * 128;                               // 16384
-constexpr int SMEM_B = 2 * PATCH_B + STAGE_B;                        // 62464: two workgroups per CU
-constexpr int NPASS = (PPIX * 8 + NTHR - 1) / NTHR;                  // 6 loader passes (last partial)
+// per input-channel count C (64, or 32: the 3x3 of yolov5s' first C3): pixel row C*2 bytes = C/8 16-byte chunks, C/32 MFMA k-steps per tap
+template <int C> struct Geo {
+    static constexpr int CB = C * 2, CPP = C / 8, KS = C / 32;
+    static constexpr int PATCH_B = PPIX * CB;                        // 23040 (C = 64)
+    static constexpr int SMEM_B = 2 * PATCH_B + STAGE_B;             // 62464: two workgroups per CU
+    static constexpr int NPASS = (PPIX * CPP + NTHR - 1) / NTHR;     // 6 loader passes (last partial)
+};
 
 // EPI: 0 = raw convolution out (train-mode forward, dgrad), 1 = scale/shift, 2 = scale/shift + SiLU
 // STATS: accumulate BatchNorm partial sums (one slab per workgroup)
-template <int EPI, bool STATS>
+template <int C, int EPI, bool STATS>
 __global__ __launch_bounds__(NTHR, 2) void conv3x3_c64_kernel(const ConvArgs p) {
+    constexpr int CB = Geo<C>::CB, CPP = Geo<C>::CPP, KS = Geo<C>::KS, PATCH_B = Geo<C>::PATCH_B, NPASS = Geo<C>::NPASS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* sP = smem;                    // [2][180][128 B]
+    unsigned char* sP = smem;                    // [2][180][C*2 B]
     unsigned char* sS = smem + 2 * PATCH_B;      // [128][128 B] staging tile
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -107,14 +116,14 @@ __global__ __launch_bounds__(NTHR, 2) void conv3x3_c64_kernel(const ConvArgs p) 
     const unsigned char* zero = (const unsigned char*)g_hdy_zero16_c3;
 
     // ---- filter slice -> registers: row operand of tap t, k-half ks = w[wave*16 + fr][t*64 + (ks*4 + fq)*8 .. +7]
-    V16 bw[9][2];
+    V16 bw[9][KS];
     {
         const int k = wave * 16 + fr;
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const void* src = (k < p.K) ? (const void*)(w + (size_t)k * p.Kdp + t * 64 + (ks * 4 + fq) * 8) : (const void*)zero;
+            for (int ks = 0; ks < KS; ++ks) {
+                const void* src = (k < p.K) ? (const void*)(w + (size_t)k * p.Kdp + t * C + (ks * 4 + fq) * 8) : (const void*)zero;
                 bw[t][ks].i = *(const i32x4*)src;
             }
     }
@@ -125,9 +134,11 @@ __global__ __launch_bounds__(NTHR, 2) void conv3x3_c64_kernel(const ConvArgs p) 
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
         const int pos = tid + NTHR * i;
-        const int pix = pos >> 3;
+        const int pix = pos / CPP;
         const int py = pix / PW, px = pix - py * PW;
-        const int lcp = (tid & 7) ^ (((px >> 1) & 3) << 1);
+        // 128-byte pixel rows (C = 64) are XOR-swizzled by the patch column; 64-byte rows (C = 32) need none: the 64 lanes of a fragment
+        // read (16 consecutive pixels) x (4 chunks) = 1 KB contiguous
+        const int lcp = CPP == 8 ? (tid & 7) ^ (((px >> 1) & 3) << 1) : (tid & (CPP - 1));
         prel[i] = (py * p.Win + px) * p.ldx + lcp * 8;
         pyx[i] = py | (px << 8);
     }
@@ -180,7 +191,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv3x3_c64_kernel(const ConvArgs p) 
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
             const int py = pyx[i] & 255;
-            if (((wave * 64 + NTHR * i) >> 3) >= prow * PW) break;         // wave-uniform: whole 1 KB pieces past the patch
+            if ((wave * 64 + NTHR * i) / CPP >= prow * PW) break;          // wave-uniform: whole 1 KB pieces past the patch
             if (py >= prow) continue;                                     // lanes past the last pixel: no LDS write
             const int h = h0 + py, ww = w0 + (pyx[i] >> 8);
             const void* src = ((unsigned)h < (unsigned)p.Hin && (unsigned)ww < (unsigned)p.Win) ? (const void*)(org + prel[i]) : (const void*)zero;
@@ -188,13 +199,13 @@ __global__ __launch_bounds__(NTHR, 2) void conv3x3_c64_kernel(const ConvArgs p) 
         }
     };
 
-    int aoff[3][2];
+    int aoff[3][KS];
 #pragma unroll
     for (int s = 0; s < 3; ++s)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
             const int px = fr + s;
-            aoff[s][ks] = px * 128 + (((ks * 4 + fq) ^ (((px >> 1) & 3) << 1)) << 4);
+            aoff[s][ks] = px * CB + ((CPP == 8 ? (ks * 4 + fq) ^ (((px >> 1) & 3) << 1) : fq) << 4);
         }
 
     float sc[4], sh[4], s1[4], s2[4];
@@ -226,26 +237,26 @@ __global__ __launch_bounds__(NTHR, 2) void conv3x3_c64_kernel(const ConvArgs p) 
         // leaves a lone wave LDS-latency bound: 4.4k instead of 3.0k cycles per 8-row item; 2.3k is the MFMA rate).
         V16 fa[2][3];
         const unsigned pb_lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)pb;
-        unsigned abase[3][2];
+        unsigned abase[3][KS];
 #pragma unroll
         for (int s = 0; s < 3; ++s)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) abase[s][ks] = pb_lds + aoff[s][ks];
+            for (int ks = 0; ks < KS; ++ks) abase[s][ks] = pb_lds + aoff[s][ks];
         // inline-asm reads with hand-counted waits: the compiler's counter insertion waits lgkmcnt(0) right after every second
         // group's reads were issued and exposes their latency (a lone wave: 3.0k cycles per item instead of 2.3k)
 #define C3_LOAD(G, F)                                                                                                              \
     {                                                                                                                              \
         _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_) {                                                                         \
             i32x4 v_;                                                                                                              \
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v_) : "v"(abase[s_][(G) & 1]), "n"(((G) >> 1) * PW * 128));      \
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v_) : "v"(abase[s_][(G) % KS]), "n"(((G) / KS) * PW * CB));      \
             (F)[s_].i = v_;                                                                                                        \
         }                                                                                                                          \
     }
         C3_LOAD(0, fa[0])
 #pragma unroll
-        for (int g = 0; g < 2 * (AR + 2); ++g) {         // patch row q serves tile row a with filter row r = q - a
-            const int q = g >> 1, ks = g & 1;
-            if (g + 1 < 2 * (AR + 2)) {
+        for (int g = 0; g < KS * (AR + 2); ++g) {        // group g = (patch row g / KS, k-step g % KS); patch row q serves tile row a with filter row r = q - a
+            const int q = g / KS, ks = g % KS;
+            if (g + 1 < KS * (AR + 2)) {
                 C3_LOAD(g + 1, fa[(g + 1) & 1])
                 asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fa[g & 1][0].i), "+v"(fa[g & 1][1].i), "+v"(fa[g & 1][2].i));
             } else {
@@ -357,14 +368,27 @@ __global__ __launch_bounds__(NTHR, 2) void conv3x3_c64_kernel(const ConvArgs p) 
     }
 }
 
-template <int EPI, bool STATS>
+template <int C, int EPI, bool STATS>
 static void launch_c3(const ConvArgs& a, int grid, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_c64_kernel<EPI, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B);
+        (void)hipFuncSetAttribute((const void*)conv3x3_c64_kernel<C, EPI, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<C>::SMEM_B);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3x3_c64_kernel<EPI, STATS>), dim3(grid), dim3(NTHR), SMEM_B, st, a);
+    hipLaunchKernelGGL((conv3x3_c64_kernel<C, EPI, STATS>), dim3(grid), dim3(NTHR), Geo<C>::SMEM_B, st, a);
+}
+
+template <int C>
+static void launch_c3_c(const ConvArgs& a, int grid, int epi, hipStream_t st) {
+    if (a.stats) {
+        if (epi == 2) launch_c3<C, 2, true>(a, grid, st);
+        else if (epi == 1) launch_c3<C, 1, true>(a, grid, st);
+        else launch_c3<C, 0, true>(a, grid, st);
+    } else {
+        if (epi == 2) launch_c3<C, 2, false>(a, grid, st);
+        else if (epi == 1) launch_c3<C, 1, false>(a, grid, st);
+        else launch_c3<C, 0, false>(a, grid, st);
+    }
 }
 
 }  // namespace
@@ -373,7 +397,7 @@ static void launch_c3(const ConvArgs& a, int grid, hipStream_t st) {
 // Shape test shared by the launcher and the statistics-slab query (the two must agree on who writes the slabs).
 static bool conv3x3_shape_ok(int C, int K, int R, int S, int stride, int pad, int H, int W, int dtype) {
     static const bool disabled = getenv("HDY_NO_CONV3X3") != nullptr;      // tests: force the generic kernel for A/B comparison
-    return !disabled && dtype == HDY_BF16 && R == 3 && S == 3 && stride == 1 && pad == 1 && C == 64 && K <= 64 && K % 8 == 0 && H % TH == 0 &&
+    return !disabled && dtype == HDY_BF16 && R == 3 && S == 3 && stride == 1 && pad == 1 && (C == 64 || C == 32) && K <= 64 && K % 8 == 0 && H % TH == 0 &&
            W % TW == 0;
 }
 
@@ -404,15 +428,8 @@ int hdy_conv3x3_c64_try(const ConvArgs& a, int dtype, int out_f32, hipStream_t s
     }
     const int grid = conv3x3_grid(a.N * (a.Ho / TH) * (a.Wo / TW));
     const int epi = a.act == 1 ? 2 : ((a.scale || a.shift) ? 1 : 0);
-    if (a.stats) {
-        if (epi == 2) launch_c3<2, true>(a, grid, st);
-        else if (epi == 1) launch_c3<1, true>(a, grid, st);
-        else launch_c3<0, true>(a, grid, st);
-    } else {
-        if (epi == 2) launch_c3<2, false>(a, grid, st);
-        else if (epi == 1) launch_c3<1, false>(a, grid, st);
-        else launch_c3<0, false>(a, grid, st);
-    }
+    if (a.C == 32) launch_c3_c<32>(a, grid, epi, st);
+    else launch_c3_c<64>(a, grid, epi, st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         hdy_set_error("conv3x3_c64: launch failed: %s", hipGetErrorString(e));

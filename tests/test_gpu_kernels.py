@@ -65,6 +65,9 @@ CONV_CASES = [
     (2, 16, 32, 64, 64, 3, 1, 1),        # qualifies for the filter-resident 3x3 kernel (bf16): C=64, H%8==0, W%16==0
     (3, 32, 48, 64, 32, 3, 1, 1),
     (2, 24, 32, 64, 64, 3, 1, 1),        # H % 16 != 0
+    (2, 16, 32, 32, 32, 3, 1, 1),        # the same kernel with 32 input channels (64-byte patch rows, one k-step per tap)
+    (3, 40, 48, 32, 64, 3, 1, 1),
+    (5, 128, 128, 32, 32, 3, 1, 1),      # band split, 32 channels
     # filter-resident kernel, more 8x16 tiles than its 512 workgroups: 640 tiles = 1 whole + a 2-row band each; 704 -> 4-row bands; 832 -> whole
     (5, 128, 128, 64, 64, 3, 1, 1),
     (2, 176, 256, 64, 48, 3, 1, 1),
