@@ -333,3 +333,54 @@ def test_eval_plan_follows_weight_updates():
         m.backbone[1].bn.running_var.mul_(4.0)
         plan.run_forward(x)
         assert not torch.equal(plan.feature(9), b)
+
+
+def _empty_like(t):
+    a = t['anns']['det'][0]
+    return {'anns': {'det': [{'boxes': a['boxes'][:0].clone(), 'labels': a['labels'][:0].clone()}]}}
+
+
+@pytest.mark.parametrize('which', ['one image without targets', 'no targets at all'])
+@pytest.mark.parametrize('fused', ['1', '0'])
+def test_images_without_targets_match_oracle(which, fused, monkeypatch):
+    """Ragged / empty ground truth (the reference handles a tile without nuclei: datasets.py:462-519 emits empty boxes): the loss is
+    the objectness term alone where nothing matches, and it must be the oracle's, gradients included."""
+    from oracle.ref_net import RefNet
+    monkeypatch.setenv('HDY_FUSED_LOSS', fused)
+    nc, B, S = 2, 2, 64
+    cfg, hyp = synth.make_cfg('n', nc), synth.make_hyp()
+    model = build('n', nc).train()
+    net = RefNet(cfg, hyp)
+    sd = net.init_state()
+    names = [k for k in sd if 'running' not in k]
+    for k in names:
+        sd[k].requires_grad_(True)
+    x = synth.synth_images(B, S, seed=11)
+
+    def make():
+        t = synth.synth_targets(B, S, nc, nmin=3, nmax=8, seed=5)
+        return [_empty_like(t[0]), t[1]] if which.startswith('one') else [_empty_like(q) for q in t]
+
+    lg, _ = model(x.to(DEV), make())
+    lg['det']['det_loss'].backward()
+    lc, items, _ = net.train_forward(sd, x, make())
+    lc.backward()
+    a, b = float(lg['det']['det_loss'].detach()), float(lc.detach())
+    assert a == a and abs(a - b) <= 2e-4 * abs(b), (a, b)
+    if not which.startswith('one'):
+        assert float(lg['det']['loss_items']['box']) == 0.0 and float(lg['det']['loss_items']['cls']) == 0.0
+    params = dict(model.named_parameters())
+    for k in ('backbone.0.conv.weight', 'neck.13.cv3.conv.weight', 'headers.det.m.0.bias', 'headers.det.m.2.weight'):
+        assert relmax(params[k].grad, sd[k].grad) < 2e-3, k
+
+
+def test_no_detection_above_threshold_gives_empty_outputs():
+    m = build('n', 2, synth.make_hyp(conf_thres=0.9999)).eval()
+    with torch.no_grad():
+        _, out = m(synth.synth_images(3, 64, seed=7).to(DEV))
+    assert len(out) == 3
+    for o in out:
+        assert tuple(o['det']['boxes'].shape) == (0, 4) and tuple(o['det']['scores'].shape) == (0,) and tuple(o['det']['labels'].shape) == (0,)
+    with torch.no_grad():
+        _, one = m(synth.synth_images(1, 64, seed=7).to(DEV))            # batch of one tile
+    assert len(one) == 1
