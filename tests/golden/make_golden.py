@@ -180,12 +180,15 @@ STAT_KEYS = ['backbone.0.bn.running_mean', 'backbone.0.bn.running_var',
              'neck.20.cv3.bn.running_mean', 'neck.20.cv3.bn.running_var']
 
 
-def gen_train(tag, variant, nc, batch, size, nmin, nmax):
+def gen_train(tag, variant, nc, batch, size, nmin, nmax, empty_first=False):
     """Train-mode: loss dict, BN running stats after one forward, gradients."""
     hyp = synth.make_hyp()
     model = ref_model(variant, nc, hyp).train()
     x = synth.synth_images(batch, size, seed=11)
     targets = synth.synth_targets(batch, size, nc, nmin=nmin, nmax=nmax, seed=5)
+    if empty_first:                           # a tile without nuclei: empty boxes / labels (datasets.py:462-519)
+        a = targets[0]['anns']['det'][0]
+        a['boxes'], a['labels'] = a['boxes'][:0], a['labels'][:0]
     losses, _ = model(x, targets, compute_masks=True)
     loss = losses['det']['det_loss'] + losses['det']['mask_loss']
     loss.backward()
@@ -514,6 +517,9 @@ def main():
     assert os.path.isdir(REF), 'the reference is only mounted in the build container'
     torch.set_num_threads(8)
     install_shims()
+    if sys.argv[1:] == ['ragged']:
+        gen_train('n_64_ragged', 'n', 2, 2, 64, 3, 8, empty_first=True)
+        return
     if sys.argv[1:] == ['confusion']:
         gen_confusion()
         return
@@ -539,6 +545,7 @@ def main():
     gen_masks()
     gen_scale_img()
     gen_confusion()
+    gen_train('n_64_ragged', 'n', 2, 2, 64, 3, 8, empty_first=True)
 
 
 if __name__ == '__main__':
