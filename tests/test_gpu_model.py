@@ -392,3 +392,37 @@ def test_no_detection_above_threshold_gives_empty_outputs():
     with torch.no_grad():
         _, one = m(synth.synth_images(1, 64, seed=7).to(DEV))            # batch of one tile
     assert len(one) == 1
+
+
+def test_non_square_tiles_match_oracle():
+    """Rectangular tiles (96 x 160): every level's grid is 3:5, the NHWC pitches and the decode's (ny, nx) differ — eval detections,
+    training loss and gradients against the oracle on the same tensors (normalised targets do not depend on the shape)."""
+    from oracle.ref_net import RefNet
+    nc, B, H, W = 2, 2, 96, 160
+    cfg, hyp = synth.make_cfg('n', nc), synth.make_hyp(conf_thres=0.05)
+    g = torch.Generator().manual_seed(77)
+    x = torch.rand((B, 3, H, W), generator=g)
+    net = RefNet(cfg, hyp)
+    sd = net.init_state()
+    model = build('n', nc, hyp).eval()
+    with torch.no_grad():
+        _, out = model(x.to(DEV))
+        _, _, _, ref = net.eval_forward(sd, x)
+    for o, r in zip(out, ref):
+        assert o['det']['boxes'].shape == r['boxes'].shape and len(r['boxes']) > 0
+        np.testing.assert_allclose(o['det']['boxes'].cpu().numpy(), r['boxes'].numpy(), rtol=1e-4, atol=1e-3)
+        assert np.array_equal(o['det']['labels'].cpu().numpy(), r['labels'].numpy())
+    model.train()
+    names = [k for k in sd if 'running' not in k]
+    for k in names:
+        sd[k].requires_grad_(True)
+    t = lambda: synth.synth_targets(B, 128, nc, nmin=3, nmax=8, seed=5)
+    lg, _ = model(x.to(DEV), t())
+    lg['det']['det_loss'].backward()
+    lc, _, _ = net.train_forward(sd, x, t())
+    lc.backward()
+    a, b = float(lg['det']['det_loss'].detach()), float(lc.detach())
+    assert abs(a - b) <= 2e-4 * abs(b), (a, b)
+    params = dict(model.named_parameters())
+    for k in ('backbone.0.conv.weight', 'backbone.4.cv3.conv.weight', 'neck.13.cv3.conv.weight', 'headers.det.m.1.weight'):
+        assert relmax(params[k].grad, sd[k].grad) < 2e-3, k
