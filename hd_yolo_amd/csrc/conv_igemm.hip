@@ -516,11 +516,14 @@ inline int igemm_grid(long long M, int ntiles, int BM, int BN, int NS) {
     return (int)(grid > tiles ? tiles : grid);
 }
 
-// 256-row tiles pay where the filter is re-fetched many times per output (multi-tap, wide K) and there is enough work to
-// give every CU one of them; the single-tap layers prefer many small workgroups in flight (measured)
+// 256-row tiles pay where the filter is re-fetched many times per output (multi-tap, wide K) AND there are many rounds of them:
+// one 8-wave workgroup per CU leaves a long tail.  Measured with both tile shapes on one box: 256->256 3x3 @64x64 B=128 (4096 big
+// tiles) 904 vs 934 us, 128->128 3x3 @128x128 (8192) 992 vs 1016 us in favour of the big tile; 512->512 @32x32 (2048) 884 vs 872 us,
+// every 3x3 layer of yolov5s at B=64 (400-1600) 4-13 % against it; the yolov5s train step 14.93 -> 14.80 ms and the yolov5l
+// inference network 64.2 -> 63.3 ms with the threshold at 4096.  The single-tap layers prefer many small workgroups in flight.
 inline bool igemm_big(long long M, int bn, int ntiles, int taps) {
     static const bool no_big = getenv("HDY_NO_BIG_TILES") != nullptr;
-    return bn == 128 && taps > 1 && (M + 255) / 256 * ntiles >= 256 && !no_big;
+    return bn == 128 && taps > 1 && (M + 255) / 256 * ntiles >= 4096 && !no_big;
 }
 
 template <typename T, typename OT, int BM, int BN, int NS>
