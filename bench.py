@@ -26,6 +26,33 @@ os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+
+def _requested_gpus(argv):
+    for i, a in enumerate(argv):
+        if a == '--gpus' and i + 1 < len(argv):
+            return int(argv[i + 1])
+        if a.startswith('--gpus='):
+            return int(a.split('=', 1)[1])
+    return 1
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a rendezvous in the environment: start N fresh rank processes (one per GPU) under
+    torch.distributed.run — before this process has imported torch or touched the GPU — relay their output and exit with their
+    code.  Rank 0's JSON line is the only thing they print on stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=dict(os.environ, HDY_BENCH_SPAWNED='1'))
+
+
+if __name__ == '__main__' and 'RANK' not in os.environ and _requested_gpus(sys.argv[1:]) > 1:
+    sys.exit(spawn_ranks(_requested_gpus(sys.argv[1:]), sys.argv[1:]))
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -139,12 +166,16 @@ def main():
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.cuda.set_device(local % torch.cuda.device_count())
-        backend = os.environ.get('HDY_DIST_BACKEND', 'nccl')      # 'gloo' lets two ranks share one GPU when rehearsing the N>1 path
+        # 'gloo' lets several ranks share one GPU when rehearsing the N>1 path; it is also what a box with fewer GPUs than ranks gets
+        backend = os.environ.get('HDY_DIST_BACKEND', 'nccl' if torch.cuda.device_count() >= world else 'gloo')
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device('cuda', local))
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+    else:
+        backend = 'none'
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree')
     device = torch.device('cuda', local % torch.cuda.device_count())
     torch.cuda.set_device(device)
 
@@ -233,7 +264,8 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if args.dtype == 'bf16' else 'f32', 'data': 'synthetic',
             'config': {'workload': f'metayolo yolov5{args.variant} {args.nc}-class nuclei, {args.size}x{args.size} RGB tiles, '
                                    f'batch {args.batch}/GPU, train step = fwd + DetLoss + bwd + all-reduce + SGD(nesterov)',
-                       'global_batch': args.batch * world, 'parallelism': f'dp{world}'},
+                       'global_batch': args.batch * world, 'parallelism': f'dp{world}',
+                       'world_size': dist.get_world_size() if world > 1 else 1, 'backend': backend},
             'final_loss': round(final_loss, 4),
         }
         if not args.no_roofline:

@@ -119,6 +119,14 @@ __device__ __forceinline__ bool iou_gt(float ax1, float ay1, float ax2, float ay
 
 struct Cand { float x1, y1, x2, y2, area, score; int cls; };
 
+// 32-bit key whose ASCENDING unsigned order is DESCENDING score order for every float (negative scores included: explicit-box calls
+// carry caller scores of any sign; -0.0 ranks as +0.0).  For the positive scores of the thresholded paths this is ~bits, as before.
+__device__ __forceinline__ unsigned desc_key(float s) {
+    unsigned u = s == 0.0f ? 0u : __float_as_uint(s);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);      // ascending order-preserving map of the float line
+    return ~u;
+}
+
 __device__ __forceinline__ Cand make_cand(const float* p, int nc, int class_aware, int xyxy = 0) {
     Cand c;
     c.cls = 0;
@@ -170,7 +178,7 @@ __global__ __launch_bounds__(NT) void nms_kernel(const NmsArgs p) {
             if (p.xyxy) ok = true;
             else if (p.class_aware) ok = (r[4] > p.conf) && (c.score > p.conf);
             else ok = (__fsub_rn(c.x2, c.x1) >= p.min_wh) && (__fsub_rn(c.y2, c.y1) >= p.min_wh) && (c.score > p.conf);
-            key = ((unsigned long long)(~__float_as_uint(c.score)) << 32) | (unsigned)i;
+            key = ((unsigned long long)desc_key(c.score) << 32) | (unsigned)i;
         }
         const unsigned long long m = __ballot(ok);
         const int pos = __popcll(m & ((1ull << lane) - 1ull));

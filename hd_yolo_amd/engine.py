@@ -161,6 +161,7 @@ class Engine:
         self.store = None
         self.hook = None
         self.grad_hooks = []          # callables run after every backward, before publish (data-parallel all-reduce)
+        self.bucket_hooks = []        # callables (store, a, b, side_stream) run DURING backward when flat gradient range [a, b) is final
         self.mask_token = None
 
     # An engine is a cache of device buffers and marshalled launch records for the module OBJECTS it was traced from: a copied or
@@ -176,7 +177,7 @@ class Engine:
         modules still own a BatchNorm).  Done on every call (a caller may have swapped parameters or fused / frozen modules since
         the last one) — hence a bare stack walk over `_modules` / `_parameters`: nn.Module.parameters() + .modules() cost 1 ms per
         call on yolov5s, more than the whole inference launch list."""
-        params, seen, fused = [], set(), []
+        params, seen, fused, bufs = [], set(), [], []
         stack = []
         for part in self.parts:
             if part is None:
@@ -194,8 +195,13 @@ class Engine:
                 if q is not None and id(q) not in seen:
                     seen.add(id(q))
                     params.append(q)
+            for q in m._buffers.values():               # BatchNorm running statistics: the launch records hold their addresses too
+                if q is not None and q.is_floating_point():
+                    bufs.append(q.data_ptr())
             stack.extend(reversed([c for c in m._modules.values() if c is not None]))
-        return params, tuple(id(q) for q in params), tuple(q.requires_grad for q in params), tuple(fused)
+        # identity AND storage: `model.cpu(); model.cuda()` or `.to(dtype)` round trips keep the parameter objects but move their data,
+        # and the launch records / pack tables / gradient views of a plan bake raw device addresses
+        return params, (tuple((id(q), q.data_ptr()) for q in params), tuple(bufs)), tuple(q.requires_grad for q in params), tuple(fused)
 
     def _params(self):
         return self._scan()[0]
@@ -226,8 +232,13 @@ class Engine:
                 self.plans.pop(next(iter(self.plans)))
             b, n, h = self.parts
             plan = Plan(b, n, h, tuple(x.shape), dtype, training, x.device, grad_store=self.store)
+            plan.bucket_hook = self._bucket_ready
             self.plans[key] = plan
         return plan
+
+    def _bucket_ready(self, a, b, side_stream):
+        for fn in self.bucket_hooks:
+            fn(self.store, a, b, side_stream)
 
     def plan_for_features(self, feats, dtype):
         """Eval plan of (neck, head) fed with bare feature maps {layer index: NCHW tensor} (FPN.forward / Detect.forward)."""

@@ -48,6 +48,19 @@ def intersect_dicts(da, db, exclude=()):
     return OrderedDict((k, v) for k, v in da.items() if k in db and v.shape == db[k].shape and not any(x in k for x in exclude))
 
 
+def checkpoint_state(ckpt, prefer_ema=False):
+    """state_dict out of any checkpoint form: a bare state_dict, this build's {'model': state_dict, 'ema': state_dict}, or the
+    reference's {'model': nn.Module.half(), 'ema': nn.Module.half()} (train.py:145-166, :530-540: loads
+    `ckpt['model'].float().state_dict()`, EMA weights when restarting from a finished run)."""
+    if not isinstance(ckpt, dict) or 'model' not in ckpt:
+        m = ckpt
+    else:
+        m = ckpt['ema'] if prefer_ema and ckpt.get('ema') is not None else ckpt['model']
+    if hasattr(m, "state_dict") and callable(m.state_dict):
+        m = m.float().state_dict()
+    return {k: (v.float() if hasattr(v, "is_floating_point") and v.is_floating_point() else v) for k, v in m.items()}
+
+
 def convert_yolo_weights(model, weights):
     """Re-key a stock YOLOv5 state_dict (`model.<layer>.<rest>`, layers numbered through backbone, neck and Detect) to this
     package's `backbone.<i>` / `neck.<i - len(backbone)>` / `headers.<tag>.<rest>` keys (reference: engines/general.py:530-560).

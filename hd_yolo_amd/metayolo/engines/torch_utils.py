@@ -24,9 +24,15 @@ def select_device(device='', batch_size=None):
         raise RuntimeError('hd_yolo_amd has no CPU execution path: pass a GPU index')
     if not torch.cuda.is_available():
         raise RuntimeError('no MI355X visible (torch.cuda.is_available() is False)')
-    if device:
-        os.environ.setdefault('HIP_VISIBLE_DEVICES', str(device))
-    return torch.device('cuda', 0)
+    # The reference narrows CUDA_VISIBLE_DEVICES before its first CUDA query (torch_utils.py:60-62); here the runtime may already be
+    # initialised (and a visibility variable set afterwards is ignored), so the first listed index is selected explicitly.
+    idx = 0
+    if str(device).strip():
+        idx = int(str(device).replace(' ', '').split(',')[0])
+        if idx < 0 or idx >= torch.cuda.device_count():
+            raise RuntimeError(f'--device {device}: this process sees {torch.cuda.device_count()} GPU(s)')
+    torch.cuda.set_device(idx)
+    return torch.device('cuda', idx)
 
 
 def time_sync():

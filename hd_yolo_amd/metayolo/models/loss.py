@@ -101,6 +101,9 @@ class DetLoss(nn.Module):
                 iou = bbox_iou(torch.cat((pxy, pwh), 1), tbox[i], CIoU=True).squeeze(-1)
                 lbox = lbox + (1.0 - iou).mean()
                 t = iou.detach().clamp(0).type(tobj.dtype)
+                if self.sort_obj_iou:                   # loss.py:212-214: ascending IoU order, so the cell keeps its best match (last write wins)
+                    j = t.argsort(stable=True)
+                    b, a, gj, gi, t = b[j], a[j], gj[j], gi[j], t[j]
                 if self.gr < 1:
                     t = (1.0 - self.gr) + self.gr * t
                 scatter_last(tobj, (b, a, gj, gi), t)

@@ -296,7 +296,7 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
             det = det[det[:, 4].argsort(descending=True, stable=True)[:30000]]
         if det.shape[0]:
             offs = det[:, 5:6] * (0.0 if agnostic else 7680.0)
-            keep = _ops.nms(det[:, :4] + offs, det[:, 4], iou_thres, max_det=min(int(max_det), 4096))
+            keep = _ops.nms(det[:, :4] + offs, det[:, 4], iou_thres, max_det=int(max_det))
             det = det[keep[:max_det]]
         out.append(det)
     return out

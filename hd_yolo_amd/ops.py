@@ -96,7 +96,9 @@ def run(records, stream=None):
         name, args = rec[0], rec[1]
         if name[0] == '@':
             side = rec[1]
-            if name == '@fork':
+            if name == '@call':
+                rec[1]()
+            elif name == '@fork':
                 side.fork(rec[2], rec[3], torch.cuda.current_stream())
             elif name == '@join':
                 side.join(rec[2], torch.cuda.current_stream())
@@ -417,13 +419,11 @@ def nms_batched(preds, nc, conf_thres, iou_thres, max_det, min_wh=2.0, class_awa
     return {'keep': keep, 'n_keep': n_keep, 'boxes': boxes, 'scores': scores, 'extra': extra[:, :, :nex], 'conf': conf, 'cls': cls}
 
 
-def nms(boxes, scores, iou_thres, max_det=4096):
-    """torchvision.ops.nms(boxes xyxy (N,4), scores (N,) >= 0, iou) on the GPU: kept indices (int64) in descending score order
-    (ties: lower index first), at most max_det <= 4096 of them."""
-    require_gpu(boxes)
+NMS_LAUNCH_KEEP = 4096          # kept boxes one hdy_nms_boxes launch can hold (its LDS kept-list)
+
+
+def _nms_launch(boxes, scores, iou_thres, max_det):
     N = boxes.shape[0]
-    if N == 0:
-        return torch.empty((0,), dtype=torch.int64, device=boxes.device)
     bs = torch.cat([boxes.float(), scores.float().reshape(N, 1)], 1).contiguous()
     keep = torch.empty((1, max_det), dtype=torch.int64, device=boxes.device)
     n_keep = torch.empty((1,), dtype=torch.int32, device=boxes.device)
@@ -432,6 +432,51 @@ def nms(boxes, scores, iou_thres, max_det=4096):
     _lib.call('hdy_nms_boxes', bs.data_ptr(), 1, N, float(iou_thres), int(max_det), keep.data_ptr(), n_keep.data_ptr(), ws.data_ptr(),
               ws.numel() * 8, stream_ptr())
     return keep[0, :int(n_keep.item())]
+
+
+def nms(boxes, scores, iou_thres, max_det=None):
+    """torchvision.ops.nms(boxes xyxy (N,4), scores (N,), iou) on the GPU: ALL kept indices (int64) in descending score order (ties:
+    lower index first), or the first `max_det` of them.  One launch holds 4096 kept boxes; when that fills up the greedy pass is
+    continued on what is left — the candidates ranked behind the last kept box that none of the kept boxes suppresses — so whole-slide
+    merges of many tiles lose nothing (the reference's torchvision call returns every survivor)."""
+    require_gpu(boxes)
+    N = boxes.shape[0]
+    if N == 0:
+        return torch.empty((0,), dtype=torch.int64, device=boxes.device)
+    want = N if max_det is None else int(max_det)
+    out = _nms_launch(boxes, scores, iou_thres, min(want, NMS_LAUNCH_KEEP))
+    if len(out) < NMS_LAUNCH_KEEP or want <= NMS_LAUNCH_KEEP:
+        return out
+    boxes, scores = boxes.float(), scores.float().reshape(N)
+    cand = torch.arange(N, device=boxes.device)
+    chunks, got = [out], len(out)
+    while True:
+        chunk = chunks[-1]
+        last = chunk[-1]
+        cs = scores[cand]
+        live = (cs < scores[last]) | ((cs == scores[last]) & (cand > last))          # ranked behind the last kept box
+        cand = cand[live]
+        kb = boxes[chunk]
+        karea = (kb[:, 2] - kb[:, 0]) * (kb[:, 3] - kb[:, 1])
+        keep_mask = torch.ones(len(cand), dtype=torch.bool, device=boxes.device)
+        for i in range(0, len(cand), 8192):                                          # IoU against the kept chunk, the kernel's fp32 arithmetic
+            cb = boxes[cand[i:i + 8192]]
+            w = (torch.minimum(cb[:, None, 2], kb[None, :, 2]) - torch.maximum(cb[:, None, 0], kb[None, :, 0])).clamp_(min=0)
+            h = (torch.minimum(cb[:, None, 3], kb[None, :, 3]) - torch.maximum(cb[:, None, 1], kb[None, :, 1])).clamp_(min=0)
+            inter = w * h
+            carea = (cb[:, 2] - cb[:, 0]) * (cb[:, 3] - cb[:, 1])
+            keep_mask[i:i + 8192] = ~((inter / (carea[:, None] + karea[None, :] - inter)) > iou_thres).any(1)
+        cand = cand[keep_mask]
+        if len(cand) == 0 or got >= want:
+            break
+        sub = _nms_launch(boxes[cand], scores[cand], iou_thres, min(want - got, NMS_LAUNCH_KEEP))
+        if len(sub) == 0:
+            break
+        chunks.append(cand[sub])
+        got += len(sub)
+        if len(sub) < NMS_LAUNCH_KEEP:
+            break
+    return torch.cat(chunks)[:want]
 
 
 # ------------------------------------------------------------------------------------------ mask branch primitives (row f2)

@@ -54,44 +54,100 @@ def bucket_bounds(numel, nbuckets, align=1024):
 
 
 class GradAllReduce:
-    """Sum-all-reduce of a flat gradient buffer in a few large buckets on a communication stream."""
+    """Sum-all-reduce of the flat gradient buffer on a communication stream, overlapped with the backward pass.
 
-    BUCKET_BYTES = 64 << 20       # nothing overlaps these calls, so each extra one only adds its fixed RCCL latency: as few as possible,
-                                  # split only to bound the message size (yolov5s: 29 MB -> 1 call, yolov5l: 185 MB -> 3)
+    The backward launch list carries marks "flat range [a, b) is final" (plan.Plan._mark_buckets: ranges of a few MB, completing
+    from the end of the buffer because the list runs the layers in reverse).  `bucket()` is called at such a mark: the
+    communication stream waits for what the compute streams have been given so far (events, no host sync) and gets that range's
+    all-reduce, while the main stream goes on with the earlier layers.  `__call__` runs after the list: it reduces whatever no
+    mark covered and makes the main stream wait for the communication stream.  Adjacent ready ranges are sent as one call up to
+    BUCKET_BYTES (xGMI is point-to-point: a few large messages beat many small ring steps)."""
 
-    def __init__(self, nbuckets=None, group=None):
-        self.nbuckets, self.group = nbuckets, group
+    BUCKET_BYTES = 64 << 20       # upper bound of one RCCL call
+    MIN_BYTES = 4 << 20           # a ready range smaller than this waits for its neighbour (fixed RCCL latency per call)
+
+    def __init__(self, nbuckets=None, group=None, overlap=True):
+        self.nbuckets, self.group, self.overlap = nbuckets, group, overlap
         self.stream = None
+        self.sent = []            # ranges already given to the communication stream in this backward pass
+        self.pending = None       # a ready range not yet sent (too small on its own)
+        self.calls = 0            # all_reduce calls issued (tests / diagnostics)
 
-    def __call__(self, store):
-        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
-            return
-        flat = store.cur
-        nb = self.nbuckets or max(1, -(-flat.numel() * flat.element_size() // self.BUCKET_BYTES))
-        bounds = bucket_bounds(flat.numel(), nb)
+    def _active(self):
+        return dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def _send(self, flat, a, b, waits):
         if flat.is_cuda:
             if self.stream is None:
                 self.stream = torch.cuda.Stream(device=flat.device)
-            cur = torch.cuda.current_stream(flat.device)
-            self.stream.wait_stream(cur)
+            for s in waits:
+                if s is not None:
+                    self.stream.wait_stream(s)
             with torch.cuda.stream(self.stream):
-                for a, b in bounds:
-                    dist.all_reduce(flat[a:b], op=dist.ReduceOp.SUM, group=self.group)
-            cur.wait_stream(self.stream)
+                for x in range(a, b, self.BUCKET_BYTES // 4):
+                    dist.all_reduce(flat[x:min(b, x + self.BUCKET_BYTES // 4)], op=dist.ReduceOp.SUM, group=self.group)
+                    self.calls += 1
         else:
-            for a, b in bounds:
-                dist.all_reduce(flat[a:b], op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(flat[a:b], op=dist.ReduceOp.SUM, group=self.group)
+            self.calls += 1
+        self.sent.append((a, b))
+
+    def bucket(self, store, a, b, side_stream=None):
+        """Engine bucket hook: gradient elements [a, b) of store.cur are final once the work issued so far has run."""
+        if not self._active() or not self.overlap:
+            return
+        flat = store.cur
+        self._side = side_stream
+        p, self.pending = self.pending, None
+        if p is not None and p[1] == a:                 # contiguous with the range kept back: one message
+            a = p[0]
+        elif p is not None and p[0] == b:
+            b = p[1]
+        elif p is not None:
+            self._send(flat, *p, waits=self._streams(flat, side_stream))
+        if (b - a) * 4 >= self.MIN_BYTES:
+            self._send(flat, a, b, waits=self._streams(flat, side_stream))
+        else:
+            self.pending = (a, b)
+
+    def _streams(self, flat, side_stream):
+        return [torch.cuda.current_stream(flat.device), side_stream] if flat.is_cuda else []
+
+    def __call__(self, store):
+        if not self._active():
+            return
+        flat = store.cur
+        waits = self._streams(flat, getattr(self, '_side', None))
+        if self.pending is not None:
+            self._send(flat, *self.pending, waits=waits)
+            self.pending = None
+        # whatever no mark covered (overlap off, or a plan without marks): the gaps between the ranges already sent
+        gaps, x = [], 0
+        for a, b in sorted(self.sent):
+            if a > x:
+                gaps.append((x, a))
+            x = max(x, b)
+        if x < flat.numel():
+            gaps.append((x, flat.numel()))
+        if self.nbuckets and not self.sent:
+            gaps = bucket_bounds(flat.numel(), self.nbuckets)
+        for a, b in gaps:
+            self._send(flat, a, b, waits=waits)
+        self.sent = []
+        if flat.is_cuda:
+            torch.cuda.current_stream(flat.device).wait_stream(self.stream)
 
 
 class DataParallel:
     """Thin wrapper with the call surface the entry points need (`model(x, targets)`, `.module`-style access through
     hdy_dp_module): broadcasts rank 0's state once and installs the flat all-reduce as the engine's gradient hook."""
 
-    def __init__(self, model, nbuckets=None):
+    def __init__(self, model, nbuckets=None, overlap=True):
         self.hdy_dp_module = model
         broadcast_state(model, 0)
-        self.reducer = GradAllReduce(nbuckets)
+        self.reducer = GradAllReduce(nbuckets, overlap=overlap)
         model._eng().grad_hooks.append(self.reducer)
+        model._eng().bucket_hooks.append(self.reducer.bucket)
 
     def __call__(self, *a, **k):
         return self.hdy_dp_module(*a, **k)

@@ -28,6 +28,7 @@ from . import _lib, ops
 USE_GRAPHS = os.environ.get('HDY_GRAPH', '0') == '1'   # hipGraph replay of ~400-node graphs measured slower than eager on ROCm 7.2
 SIDE_WGRAD = os.environ.get('HDY_SIDE_WGRAD', '1') == '1' and not USE_GRAPHS      # weight gradients on a second stream
 DY_RING = int(os.environ.get('HDY_DY_RING', '4'))
+GRAD_BUCKET_BYTES = int(os.environ.get('HDY_GRAD_BUCKET_MB', '6')) << 20      # granularity of the "these gradients are final" marks
 
 
 class Val:
@@ -117,6 +118,8 @@ class Plan:
         self.ext = {}
         self.vals, self.units = [], []
         self.grad_store = grad_store
+        self._grad_log = None
+        self.bucket_hook = None         # engine: called as hook(a, b, side_stream) when gradient elements [a, b) of the flat buffer are final
         self._order = 0
         self._trace(backbone, neck, head)
         self._allocate()
@@ -390,6 +393,9 @@ class Plan:
         return m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var
 
     def _grad_views(self, p):
+        # compiling the backward list: remember which launch record produces this parameter's gradient (the one appended next)
+        if self._grad_log is not None:
+            self._grad_log.append((p, self._grad_pos()))
         return self.grad_store.view_of(p)
 
     # ------------------------------------------------------------------ forward
@@ -528,6 +534,8 @@ class Plan:
 
     def _compile_backward(self):
         recs = []
+        self._grad_log = []
+        self._grad_pos = lambda: len(recs)
         for v in self.vals:
             v.ginit = False
         # Weight gradients are consumed only by the optimizer: with SIDE_WGRAD they run on a second stream beside the
@@ -583,10 +591,12 @@ class Plan:
         for u in reversed(self.units):
             if isinstance(u, DetUnit):
                 x = u.x
-                gw, gb = self._grad_views(u.conv.weight), self._grad_views(u.conv.bias)
-                recs.append(ops.rec_colsum(u.gdet, self._det_bias_tmp(u), self.bn_ws))
+                tmp = self._det_bias_tmp(u)
+                recs.append(ops.rec_colsum(u.gdet, tmp, self.bn_ws))
+                gb = self._grad_views(u.conv.bias)
+                recs.append(('@call', (lambda gb=gb, tmp=tmp, K=u.K: gb.copy_(tmp[:K]))))       # Kp-padded column sums -> the bias gradient
+                gw = self._grad_views(u.conv.weight)
                 wgrad(ops.rec_conv_wgrad(x.t(), u.gdet, gw, None, 1, 1, 1, 0, self.wg_ws))
-                u.gb = gb
                 if not up(x):
                     continue
                 self.packs.add(u.conv.weight, None, 1, 0, ops.PACK_DGRAD, u.wpd, K=u.Kp)
@@ -647,9 +657,40 @@ class Plan:
                     else:
                         acc = self._contrib(xv)
                     recs.append(ops.rec_conv_dgrad(dy, u.wpd, xv.g(), u.k, u.k, u.s, u.p, accumulate=acc))
+        self._mark_buckets(recs, side)
         if side is not None and nfork[0]:
             recs.append(('@join', side, nfork[0] - 1))          # side-stream work is in order: the last fork covers all
         return recs
+
+    def _mark_buckets(self, recs, side):
+        """Data-parallel overlap (reference: DDP's autograd-hook buckets, train.py:331): cut the flat gradient buffer into ranges of
+        about GRAD_BUCKET_BYTES and insert, behind the launch record that completes a range, a '@call' that tells the engine so.
+        Parameters are laid out in registration (= forward) order and the backward list runs in reverse, so ranges complete from the
+        end of the buffer; a range's mark sits behind the LAST record writing into it whatever the order.  Gradients this list does
+        not produce (frozen parameters, the mask head's, which MaskBranchFn writes before the list runs) are final from the start."""
+        log, self._grad_log = self._grad_log, None
+        store = self.grad_store
+        done = {}
+        for q, pos in log:
+            done[id(q)] = max(done.get(id(q), -1), pos)
+        items = sorted((store.offsets[id(q)], q) for q in store.params)
+        marks, hi, acc, ready = [], store.numel, 0, -1
+        for off, q in reversed(items):
+            acc += q.numel() * 4
+            ready = max(ready, done.get(id(q), -1))
+            if acc >= GRAD_BUCKET_BYTES or off == 0:
+                marks.append((ready, off, hi))
+                hi, acc, ready = off, 0, -1
+        # a range whose last writer comes later than that of a range cut after it can only go out with it: merge by position
+        by_pos = {}
+        for ready, a, b in marks:
+            by_pos.setdefault(ready, []).append((a, b))
+        self.grad_marks = []
+        for pos in sorted(by_pos, reverse=True):              # insert from the back so earlier positions stay valid
+            for a, b in by_pos[pos]:
+                fn = (lambda a=a, b=b: self.bucket_hook(a, b, side.stream if side is not None else None) if self.bucket_hook else None)
+                recs.insert(pos + 1, ('@call', fn))
+                self.grad_marks.append((pos + 1, a, b))
 
     def _det_bias_tmp(self, u):
         if not hasattr(u, 'gbias_pad'):
@@ -688,5 +729,3 @@ class Plan:
                 self.grad_store.view_of(q).zero_()
         self.mask_grads_ready = False
         self._replay('bwd', self.bwd)
-        for u in self.det_units:
-            u.gb.copy_(u.gbias_pad[:u.K])

@@ -58,6 +58,20 @@ def _worker(rank, world, port, q):
             s2.cur.copy_(store.cur)
             parallel.GradAllReduce(nbuckets=nb)(s2)
             results.append(s2.cur.clone())
+        # the overlapped path: ranges reported final from the end of the buffer while "backward" is still running, the rest at the end
+        n = store.cur.numel()
+        for min_bytes in (0, 1 << 20):
+            s2 = _Store(n)
+            s2.cur.copy_(store.cur)
+            red = parallel.GradAllReduce()
+            red.MIN_BYTES = min_bytes
+            assert n > 200
+            red.bucket(s2, n - 100, n)
+            red.bucket(s2, 120, n - 100)
+            red.bucket(s2, 40, 80)               # not adjacent to the previous range
+            red(s2)                              # [0, 40) and [80, 120) were never marked
+            assert red.sent == [] and red.pending is None
+            results.append(s2.cur.clone())
         net.zero_grad()
         net(x_all).pow(2).sum().backward()
         ref = torch.cat([p.grad.reshape(-1) for p in params])

@@ -8,7 +8,15 @@ Replaced: DistributedDataParallel -> hd_yolo_amd.parallel.DataParallel (flat-buc
 multiplied by WORLD_SIZE, cf. :467); amp.autocast/GradScaler -> bf16 operands with fp32 masters (no loss scaling needed);
 datasets/loggers/plots/evolve/W&B -> out of scope.
 
+Entry-point surface kept from the reference's argument_parser (:594-639): --weights --cfg --hyp --epochs --batch-size --imgsz
+--resume --nosave --noval --device --optimizer --sync-bn --project --name --exist-ok --cos-lr --label-smoothing --patience
+--freeze --save-period --masks --restart.  --cfg takes a metayolo-schema yaml (backbone / fpn / headers, as the hub files
+metayolo/hub/yolov5{m6,l6}-multihead.yaml, yolov5l6-mask.yaml) or is replaced by --variant n|s|m|l|n6|m6|l6 for the stock graphs.
+Checkpoints: state_dicts by default ('model', 'ema'); `--weights` also reads the reference's pickled-module checkpoints
+(`ckpt['model'].float().state_dict()`, EMA preferred with --restart) and stock YOLOv5 key layouts (convert_yolo_weights).
+
     python train.py --variant s --nc 8 --batch-size 64 --imgsz 640 --epochs 2 --steps-per-epoch 20
+    python train.py --cfg my_model.yaml --hyp my_hyp.yaml --freeze backbone --masks --save-period 5
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train.py --batch-size 512 ...
 """
 import argparse
@@ -33,7 +41,7 @@ from hd_yolo_amd.parallel import DataParallel  # noqa: E402
 from metayolo import LOGGER  # noqa: E402
 from metayolo.common import ModelEMA, de_parallel  # noqa: E402
 from metayolo.datasets import SyntheticTiles  # noqa: E402
-from metayolo.engines.general import increment_path, init_seeds, one_cycle  # noqa: E402
+from metayolo.engines.general import checkpoint_state, convert_yolo_weights, increment_path, init_seeds, intersect_dicts, one_cycle  # noqa: E402
 from metayolo.engines.torch_utils import select_device  # noqa: E402
 from metayolo.models.utils_general import check_img_size  # noqa: E402
 from metayolo.models.utils_torch import EarlyStopping  # noqa: E402
@@ -64,6 +72,18 @@ def build_optimizer(model, hyp, name):
     return opt
 
 
+def load_pretrained(model, path, resume=False, restart=False, has_cfg=True):
+    ckpt = torch.load(path, map_location='cpu', weights_only=False)
+    csd = checkpoint_state(ckpt, prefer_ema=restart)
+    if any(k.startswith('model.') for k in csd):                    # stock YOLOv5 key layout (train.py:170-173)
+        csd = convert_yolo_weights(model, csd)
+    exclude = ['anchor'] if has_cfg and not resume else []          # train.py:169
+    csd = intersect_dicts(csd, model.state_dict(), exclude=exclude)
+    model.load_state_dict(csd, strict=False)
+    LOGGER.info(f'Transferred {len(csd)}/{len(model.state_dict())} items from {path}')
+    return ckpt if isinstance(ckpt, dict) and 'model' in ckpt else None
+
+
 def train(hyp, opt, device):
     save_dir = Path(opt.save_dir)
     w = save_dir / 'weights'
@@ -71,17 +91,33 @@ def train(hyp, opt, device):
         w.mkdir(parents=True, exist_ok=True)
         with open(save_dir / 'opt.json', 'w') as f:
             json.dump(vars(opt), f, indent=1, default=str)
+        import yaml
+        with open(save_dir / 'hyp.yaml', 'w') as f:
+            yaml.safe_dump(hyp, f, sort_keys=False)
     init_seeds(1 + RANK)
-    cfg = synth.make_cfg(opt.variant, opt.nc)
-    model = Model(cfg, hyp).to(device)
+    if opt.cfg:
+        cfg = opt.cfg                                                  # metayolo-schema yaml: Model reads it (metayolo.load_cfg)
+    else:
+        cfg = synth.make_cfg(opt.variant, opt.nc)
+        if opt.masks:                                                  # stock graph + the mask branch (one shared mask class, yolov5l6-mask.yaml:64)
+            cfg['headers'][0][3][3] = 1
+    model = Model(cfg, hyp, ch=3, anchors=hyp.get('anchors'))
     start_epoch, best_fitness = 0, 0.0
     ckpt = None
     if opt.weights:
-        ckpt = torch.load(opt.weights, map_location='cpu')
-        sd = ckpt['model'] if isinstance(ckpt, dict) and 'model' in ckpt else ckpt
-        sd = {k: v for k, v in sd.items() if k in model.state_dict() and v.shape == model.state_dict()[k].shape and 'anchor' not in k}
-        model.load_state_dict(sd, strict=False)
-        LOGGER.info(f'Transferred {len(sd)}/{len(model.state_dict())} items from {opt.weights}')
+        ckpt = load_pretrained(model, opt.weights, resume=bool(opt.resume), restart=opt.restart, has_cfg=True)
+        if opt.restart:
+            ckpt = None
+    model = model.to(device)
+    model = model.freeze(opt.freeze)                                   # train.py:182, `--freeze backbone neck.0 headers.det.m ...`
+    task0 = next(iter(model.headers))
+    nc = model.headers[task0].nc
+    with_masks = opt.masks and any(getattr(h, 'nc_masks', 0) > 0 for h in model.headers.values())
+    if opt.masks and not with_masks:
+        raise SystemExit('--masks: the model config has no mask branch (Detect args[3] must be >= 0)')
+    if opt.sync_bn:
+        # The reference's optional SyncBatchNorm (train.py:281-283) is not built: BatchNorm statistics stay per rank (its default)
+        raise SystemExit('--sync-bn is not supported on this path: BatchNorm statistics are per GPU (the reference default)')
     gs = 32
     imgsz = check_img_size(opt.imgsz, gs, floor=gs * 2)
     batch_size = opt.batch_size // WORLD_SIZE                         # per-rank batch, as train.py:287
@@ -97,10 +133,10 @@ def train(hyp, opt, device):
         if ckpt.get('optimizer') is not None:
             optimizer.load_state_dict(ckpt['optimizer'])
             best_fitness = ckpt.get('best_fitness', 0.0)
-        if ema and ckpt.get('ema'):
-            ema.ema.load_state_dict(ckpt['ema'])
+        if ema and ckpt.get('ema') is not None:
+            ema.ema.load_state_dict(intersect_dicts(checkpoint_state({'model': ckpt['ema']}), ema.ema.state_dict()), strict=False)
             ema.updates = ckpt.get('updates', 0)
-        start_epoch = ckpt.get('epoch', -1) + 1
+        start_epoch = ckpt.get('epoch', 0)                             # checkpoints store epoch + 1, as the reference (train.py:531)
 
     # per-header loss gains scaled to layers / classes / image size (train.py:335-345)
     for header in model.headers.values():
@@ -112,8 +148,11 @@ def train(hyp, opt, device):
     model.half()                                                       # bf16 operands, fp32 master weights
     net = DataParallel(model) if WORLD_SIZE > 1 else model
 
-    loader = SyntheticTiles(batch_size, imgsz, opt.nc, opt.steps_per_epoch, rank=max(RANK, 0), seed=opt.seed, device=device)
-    val_loader = SyntheticTiles(batch_size, imgsz, opt.nc, opt.val_batches, rank=0, seed=opt.seed + 99, device=device)
+    mk = dict(task=task0, masks=with_masks)
+    if with_masks:
+        mk.update(nmin=4, nmax=24)                                     # every object carries a 28x28 mask target
+    loader = SyntheticTiles(batch_size, imgsz, nc, opt.steps_per_epoch, rank=max(RANK, 0), seed=opt.seed, device=device, **mk)
+    val_loader = SyntheticTiles(batch_size, imgsz, nc, opt.val_batches, rank=0, seed=opt.seed + 99, device=device, task=task0)
     nb = len(loader)
     nw = max(round(hyp['warmup_epochs'] * nb), 100)
     last_opt_step = -1
@@ -138,8 +177,8 @@ def train(hyp, opt, device):
                     g['lr'] = lo + (g['initial_lr'] * lf(epoch) - lo) * ni / nw
                     if 'momentum' in g:
                         g['momentum'] = hyp['warmup_momentum'] + (hyp['momentum'] - hyp['warmup_momentum']) * ni / nw
-            losses, _ = net(imgs, targets, compute_masks=False)
-            loss = sum(v['det_loss'] + v['mask_loss'] for v in losses.values())
+            losses, _ = net(imgs, targets, compute_masks=with_masks)
+            loss = sum(v['det_loss'] + (v['mask_loss'] if with_masks and 'mask_loss' in v else 0.0) for v in losses.values())   # train.py:459-462
             loss.backward()
             if ni - last_opt_step >= accumulate:
                 optimizer.step()
@@ -154,6 +193,7 @@ def train(hyp, opt, device):
                 LOGGER.info(f'epoch {epoch}/{opt.epochs - 1} it {i}/{nb - 1} loss {float(loss):.4f} ' +
                             ' '.join(f'{k} {v:.4f}' for k, v in mloss.items()))
         scheduler.step()
+        stop = False
         if RANK in (-1, 0):
             final = epoch + 1 == opt.epochs
             fitness = 0.0
@@ -163,7 +203,7 @@ def train(hyp, opt, device):
             best_fitness = max(best_fitness, fitness)
             if not opt.nosave or final:
                 eng = model.__dict__.pop('_hdy_engine', None)          # device plans are not checkpoint state
-                ckpt = {'epoch': epoch, 'best_fitness': best_fitness, 'model': deepcopy(de_parallel(model)).state_dict(),
+                ckpt = {'epoch': epoch + 1, 'best_fitness': best_fitness, 'model': deepcopy(de_parallel(model)).state_dict(),
                         'ema': deepcopy(ema.ema).state_dict(), 'updates': ema.updates, 'optimizer': optimizer.state_dict(),
                         'date': time.strftime('%Y-%m-%d %H:%M:%S')}
                 if eng is not None:
@@ -171,8 +211,17 @@ def train(hyp, opt, device):
                 torch.save(ckpt, w / 'last.pt')
                 if best_fitness == fitness:
                     torch.save(ckpt, w / 'best.pt')
-            if stopper(epoch=epoch, fitness=fitness):
-                break
+                if opt.save_period > 0 and (epoch + 1) % opt.save_period == 0:          # train.py:544
+                    torch.save(ckpt, w / f'epoch{epoch + 1}.pt')
+            stop = bool(stopper(epoch=epoch, fitness=fitness))
+        # The reference stops early only in single-GPU runs (train.py:550: under DDP only rank 0 would leave the loop and the others
+        # would hang in the next all-reduce).  Here rank 0's decision is shared, so every rank leaves together.
+        if WORLD_SIZE > 1 and dist.is_initialized():
+            flag = [stop]
+            dist.broadcast_object_list(flag, 0)
+            stop = flag[0]
+        if stop:
+            break
     if RANK in (-1, 0):
         LOGGER.info(f'{opt.epochs - start_epoch} epochs completed in {(time.time() - t0) / 3600:.3f} hours.')
     return best_fitness
@@ -180,16 +229,23 @@ def train(hyp, opt, device):
 
 def argument_parser():
     p = argparse.ArgumentParser()
-    p.add_argument('--weights', default='')
-    p.add_argument('--variant', default='s', help='n | s | m | l (stock depth/width multiples in the metayolo schema)')
+    p.add_argument('--weights', default='', help='initial weights: this build\'s or the reference\'s checkpoint, or a bare state_dict')
+    p.add_argument('--cfg', default='', help='model.yaml path in the metayolo schema (backbone / fpn / headers); overrides --variant / --nc')
+    p.add_argument('--variant', default='s', help='n | s | m | l | n6 | m6 | l6 (stock depth/width multiples in the metayolo schema)')
     p.add_argument('--nc', type=int, default=8)
-    p.add_argument('--hyp', default='', help='optional hyp yaml; defaults to the YOLOv5 scratch values')
+    p.add_argument('--hyp', default='', help='hyperparameters yaml (train keys + one sub-dict per header tag); defaults to the YOLOv5 scratch values')
     p.add_argument('--epochs', type=int, default=2)
     p.add_argument('--steps-per-epoch', type=int, default=20)
     p.add_argument('--val-batches', type=int, default=2)
     p.add_argument('--batch-size', type=int, default=64, help='total batch size for all GPUs')
     p.add_argument('--imgsz', '--img', '--img-size', type=int, default=640)
-    p.add_argument('--resume', action='store_true')
+    p.add_argument('--resume', action='store_true', help='continue from --weights: optimizer, EMA, epoch counter')
+    p.add_argument('--restart', action='store_true', help='keep only the (EMA) weights of --weights, reinitialise everything else')
+    p.add_argument('--freeze', nargs='+', type=str, default=[], help='Freeze layers: `backbone`, `neck.0`, `headers.det.m`, etc')
+    p.add_argument('--masks', action='store_true', help='Train mask header.')
+    p.add_argument('--label-smoothing', type=float, default=0.0, help='Label smoothing epsilon')
+    p.add_argument('--save-period', type=int, default=-1, help='Save checkpoint every x epochs (disabled if < 1)')
+    p.add_argument('--sync-bn', action='store_true', help='(reference flag) SyncBatchNorm: not built, exits with a message')
     p.add_argument('--nosave', action='store_true')
     p.add_argument('--noval', action='store_true')
     p.add_argument('--device', default='')
@@ -209,7 +265,21 @@ def main(opt):
     if opt.hyp:
         import yaml
         with open(opt.hyp) as f:
-            hyp.update(yaml.safe_load(f))
+            user = yaml.safe_load(f)
+        for k, v in user.items():                                       # header sub-dicts are merged key by key
+            if isinstance(v, dict) and isinstance(hyp.get(k), dict):
+                hyp[k].update(v)
+            else:
+                hyp[k] = v
+    hyp['label_smoothing'] = opt.label_smoothing                         # train.py:102
+    for v in hyp.values():                                               # the per-header loss dicts are what DetLoss reads (yolov5.py:104-108)
+        if isinstance(v, dict) and 'box' in v:
+            v['label_smoothing'] = opt.label_smoothing
+    if opt.cfg:
+        # a cfg may name header tags the default hyp has no sub-dict for: they start from the 'det' defaults
+        from metayolo import load_cfg
+        for row in load_cfg(opt.cfg).get('headers', []):
+            hyp.setdefault(row[4], deepcopy(hyp['det']))
     opt.save_dir = str(increment_path(Path(opt.project) / opt.name, exist_ok=opt.exist_ok or RANK not in (-1, 0)))
     device = select_device(opt.device)
     if LOCAL_RANK != -1:

@@ -115,8 +115,10 @@ def main():
     device = select_device(opt.device)
     model = Model(synth.make_cfg(opt.variant, opt.nc), synth.make_hyp())
     if opt.weights:
-        ck = torch.load(opt.weights, map_location='cpu')
-        model.load_state_dict(ck['model'] if isinstance(ck, dict) and 'model' in ck else ck, strict=False)
+        from metayolo.engines.general import checkpoint_state, intersect_dicts
+        ck = torch.load(opt.weights, map_location='cpu', weights_only=False)
+        sd = checkpoint_state(ck, prefer_ema=True)        # this build's or the reference's checkpoint form; EMA weights as val.run gets them in train.py:487
+        model.load_state_dict(intersect_dicts(sd, model.state_dict()), strict=False)
     else:
         model.load_state_dict(synth.synth_state_dict(synth.shapes_of(model), seed=0), strict=False)
     model = model.to(device)
