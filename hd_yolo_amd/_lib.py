@@ -34,6 +34,10 @@ SIGNATURES = {
     'hdy_conv_dgrad': (_I, [_P, _I, _P, _P, _I] + [_I] * 11 + [_P]),
     'hdy_conv_wgrad_workspace_bytes': (_Z, [_I] * 11),
     'hdy_conv_wgrad': (_I, [_P, _I, _P, _I] + [_I] * 9 + [_P, _I, _P, _I, _I, _P, _Z, _I, _I, _P]),
+    'hdy_conv1x1_bwd_fused_ok': (_I, [_I, _I, _I]),
+    'hdy_conv1x1_bwd_fused_grid': (_I, [_L, _I]),
+    'hdy_conv1x1_bwd_fused_workspace_bytes': (_Z, [_L, _I, _I]),
+    'hdy_conv1x1_bwd_fused': (_I, [_P, _I, _P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P, _I, _P, _I, _I, _L, _I, _I, _P, _Z, _I, _P]),
     'hdy_bn_finalize_workspace_bytes': (_Z, [_I, _I]),
     'hdy_bn_finalize': (_I, [_P, _I, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P]),
     'hdy_bn_eval_coeffs': (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),

@@ -577,8 +577,9 @@ static int bn_act_bwd_impl(const Split& dz, const void* y, int ldy, const float*
                            void* dy, int lddy, float* dgamma, float* dbeta, float* dgamma_b, float* dbeta_b, int accumulate, long long M, int K,
                            int act, int dtype, float* workspace, void* stream) {
     const int VE = dtype == HDY_BF16 ? 8 : 4;
-    HDY_ARG(dz.a && y && dy && scale && shift && workspace && M_OK(M) && K > 0 && (!mean == !invstd), "bn_act_bwd: bad args");
-    HDY_ARG(K % VE == 0 && VEC_OK(dz.a, dz.lda, VE) && VEC_OK(y, ldy, VE) && VEC_OK(dy, lddy, VE), "bn_act_bwd: K/pitch/alignment must be multiples of one 16-byte vector");
+    HDY_ARG(dz.a && y && scale && shift && workspace && M_OK(M) && K > 0 && (!mean == !invstd), "bn_act_bwd: bad args");
+    HDY_ARG(dy || mean, "bn_act_bwd: dy == NULL (statistics only) needs live BatchNorm statistics");
+    HDY_ARG(K % VE == 0 && VEC_OK(dz.a, dz.lda, VE) && VEC_OK(y, ldy, VE) && (!dy || VEC_OK(dy, lddy, VE)), "bn_act_bwd: K/pitch/alignment must be multiples of one 16-byte vector");
     HDY_ARG(dz.Ka == K || (dz.Ka > 0 && dz.Ka < K && dz.Ka % VE == 0 && dz.b && VEC_OK(dz.b, dz.ldb, VE)), "bn_act_bwd_pair: second gradient source missing / unaligned / bad split");
     const int nb = hdy_bn_bwd_blocks(M);
     const int rows = (int)((M + nb - 1) / nb);
@@ -603,6 +604,7 @@ static int bn_act_bwd_impl(const Split& dz, const void* y, int ldy, const float*
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(K, 32)), dim3(1024), 0, st, partial, nb, K, (double)M, dgamma, dbeta, dgamma_b, dbeta_b, dz.Ka,
                        accumulate, c1, c2);
     HDY_LAUNCH_CHECK("bn_bwd_finalize");
+    if (!dy) return HDY_OK;                               // statistics only: the consumer applies c1 / c2 itself (conv1x1_bwd.hip)
     if (dtype == HDY_BF16) bn_bwd_apply_launch<bf16_t, false>(g2, st, dz, y, ldy, scale, shift, mean, invstd, c1, c2, dy, lddy, (int)M, K, act);
     else bn_bwd_apply_launch<float, false>(g2, st, dz, y, ldy, scale, shift, mean, invstd, c1, c2, dy, lddy, (int)M, K, act);
     HDY_LAUNCH_CHECK("bn_act_bwd_apply");

@@ -10,9 +10,9 @@ class SyntheticTiles:
     """Iterable of (imgs: tuple of (3,H,W) float tensors in 0..1, targets: tuple of target dicts).  Each rank draws from its
     own seed offset (what DistributedSampler gives the reference: disjoint shards)."""
 
-    def __init__(self, batch_size, imgsz, nc, steps, rank=0, seed=0, task='det', nmin=50, nmax=400, device=None):
+    def __init__(self, batch_size, imgsz, nc, steps, rank=0, seed=0, task='det', nmin=50, nmax=400, device=None, masks=False):
         self.batch_size, self.imgsz, self.nc, self.steps = batch_size, imgsz, nc, steps
-        self.rank, self.seed, self.task, self.nmin, self.nmax, self.device = rank, seed, task, nmin, nmax, device
+        self.rank, self.seed, self.task, self.nmin, self.nmax, self.device, self.masks = rank, seed, task, nmin, nmax, device, masks
         self.epoch = 0
 
     def set_epoch(self, epoch):
@@ -25,7 +25,7 @@ class SyntheticTiles:
         for i in range(self.steps):
             s = self.seed + 1000003 * self.rank + 7919 * self.epoch + i
             x = synth.synth_images(self.batch_size, self.imgsz, seed=s)
-            t = synth.synth_targets(self.batch_size, self.imgsz, self.nc, nmin=self.nmin, nmax=self.nmax, seed=s, task=self.task)
+            t = synth.synth_targets(self.batch_size, self.imgsz, self.nc, nmin=self.nmin, nmax=self.nmax, seed=s, task=self.task, masks=self.masks)
             if self.device is not None:
                 x = x.to(self.device, non_blocking=True)
             yield tuple(x.unbind(0)), t

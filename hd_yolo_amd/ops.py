@@ -292,8 +292,11 @@ def rec_bn_act_bwd_pair(dz_a, dz_b, y, scale, shift, mean, invstd, dy, dgamma_a,
     dap, N, H, W, Ka, ldda = nhwc(dz_a)
     dbp, _, _, _, Kb, lddb = nhwc(dz_b)
     yp, _, _, _, K, ldy = nhwc(y)
-    dyp, _, _, _, _, lddy = nhwc(dy)
-    assert Ka + Kb == K and y.shape == dy.shape and dz_a.dtype == dz_b.dtype == y.dtype == dy.dtype and ws.numel() >= bn_bwd_ws_floats(N * H * W, K)
+    dyp, lddy = None, 0
+    if dy is not None:                                 # None: statistics only (the fused 1x1 backward applies them)
+        dyp, _, _, _, _, lddy = nhwc(dy)
+        assert y.shape == dy.shape and y.dtype == dy.dtype
+    assert Ka + Kb == K and dz_a.dtype == dz_b.dtype == y.dtype and ws.numel() >= bn_bwd_ws_floats(N * H * W, K)
     return _rec(locals(), 'hdy_bn_act_bwd_pair', (dap, ldda, dbp, lddb, Ka, yp, ldy, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), dyp, lddy, ptr(dgamma_a),
                                     ptr(dbeta_a), ptr(dgamma_b), ptr(dbeta_b), int(accumulate), N * H * W, K, act, dcode(dz_a.dtype), ptr(ws)))
 
@@ -305,10 +308,50 @@ def bn_bwd_ws_floats(M, K):
 def rec_bn_act_bwd(dz, y, scale, shift, mean, invstd, dy, dgamma, dbeta, ws, accumulate=False, act=ACT_SILU):
     dzp, N, H, W, K, lddz = nhwc(dz)
     yp, _, _, _, _, ldy = nhwc(y)
-    dyp, _, _, _, _, lddy = nhwc(dy)
-    assert dz.shape == y.shape == dy.shape and dz.dtype == y.dtype == dy.dtype and ws.numel() >= bn_bwd_ws_floats(N * H * W, K)
+    dyp, lddy = None, 0
+    if dy is not None:
+        dyp, _, _, _, _, lddy = nhwc(dy)
+        assert y.shape == dy.shape and y.dtype == dy.dtype
+    assert dz.shape == y.shape and dz.dtype == y.dtype and ws.numel() >= bn_bwd_ws_floats(N * H * W, K)
     return _rec(locals(), 'hdy_bn_act_bwd', (dzp, lddz, yp, ldy, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), dyp, lddy, ptr(dgamma), ptr(dbeta),
                                int(accumulate), N * H * W, K, act, dcode(dz.dtype), ptr(ws)))
+
+
+def bn_bwd_coeffs(ws, M, K):
+    """(c1, c2) views of the BatchNorm-backward workspace that hdy_bn_act_bwd's finalize stage fills"""
+    o = _lib.query('hdy_bn_bwd_blocks', M) * 2 * K
+    return ws[o:o + K], ws[o + K:o + 2 * K]
+
+
+def fused_1x1_ok(C, K, dtype):
+    return bool(_lib.query('hdy_conv1x1_bwd_fused_ok', C, K, dcode(dtype)))
+
+
+def fused_1x1_ws_bytes(M, C, K):
+    return _lib.query('hdy_conv1x1_bwd_fused_workspace_bytes', M, C, K)
+
+
+def rec_conv1x1_bwd_fused(dz_a, dz_b, y, scale, shift, mean, invstd, c1, c2, x, wp_d, dx, grad_a, grad_b, ws, accumulate_dx=False):
+    """One pass: dy from (dz, y, BatchNorm coefficients) -> dx (+)= dy*W and grad_a / grad_b = dy^T * x.  dx / grad_a may be None."""
+    dap, N, H, W, Ka, ldda = nhwc(dz_a)
+    dbp, lddb = None, 0
+    K = Ka
+    if dz_b is not None:
+        dbp, _, _, _, Kb, lddb = nhwc(dz_b)
+        K = Ka + Kb
+    yp, _, _, _, Ky, ldy = nhwc(y)
+    xp, _, _, _, C, ldx = nhwc(x)
+    assert Ky == K and y.shape[:3] == x.shape[:3] == dz_a.shape[:3] and y.dtype == x.dtype == dz_a.dtype == torch.bfloat16
+    dxp, lddx = None, 0
+    if dx is not None:
+        dxp, _, _, _, Cd, lddx = nhwc(dx)
+        assert Cd == C and dx.dtype == x.dtype and dx.shape[:3] == x.shape[:3]
+    K_a = 0 if grad_a is None else grad_a.shape[0]
+    K_b = 0 if grad_b is None else grad_b.shape[0]
+    assert grad_a is None or (grad_a.is_contiguous() and grad_a.dtype == torch.float32 and tuple(grad_a.shape[1:]) == (C, 1, 1))
+    return _rec(locals(), 'hdy_conv1x1_bwd_fused', (dap, ldda, dbp, lddb, Ka, yp, ldy, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(c1), ptr(c2),
+                                                    xp, ldx, ptr(wp_d), dxp, lddx, int(accumulate_dx), ptr(grad_a), K_a, ptr(grad_b), K_b, 0,
+                                                    N * H * W, C, K, ptr(ws), ws.numel() * ws.element_size(), dcode(x.dtype)))
 
 
 def rec_colsum(dz, out, ws, accumulate=False):

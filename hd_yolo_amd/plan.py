@@ -28,6 +28,7 @@ from . import _lib, ops
 USE_GRAPHS = os.environ.get('HDY_GRAPH', '0') == '1'   # hipGraph replay of ~400-node graphs measured slower than eager on ROCm 7.2
 SIDE_WGRAD = os.environ.get('HDY_SIDE_WGRAD', '1') == '1' and not USE_GRAPHS      # weight gradients on a second stream
 DY_RING = int(os.environ.get('HDY_DY_RING', '4'))
+FUSED_1X1 = os.environ.get('HDY_FUSED_1X1', '1') == '1'     # BN-apply + wgrad + dgrad of eligible 1x1 units in one kernel (conv1x1_bwd.hip)
 GRAD_BUCKET_BYTES = int(os.environ.get('HDY_GRAD_BUCKET_MB', '6')) << 20      # granularity of the "these gradients are final" marks
 
 
@@ -291,6 +292,13 @@ class Plan:
         self.mask_grads_ready = False
         self.seg_h_params = list(head.seg_h.parameters()) if self.mask_vals else []
 
+    def _fusable_1x1(self, u):
+        """Backward of this unit as ONE launch after the statistics pass (hdy_conv1x1_bwd_fused): 1x1 / stride 1 Conv + live BatchNorm +
+        SiLU in bf16 with a kernel instance for its widths."""
+        return (FUSED_1X1 and not USE_GRAPHS and self.training and self.dtype == torch.bfloat16 and not u.stem and u.k == 1 and u.s == 1
+                and u.p == 0 and u.has_bn and not u.frozen and u.act == ops.ACT_SILU and ops.fused_1x1_ok(u.C, u.K, self.dtype)
+                and all(m.conv.out_channels % 8 == 0 for m in u.mods))
+
     # ------------------------------------------------------------------ memory
     def _new(self, *shape, dtype=None, zero=False):
         f = torch.zeros if zero else torch.empty
@@ -306,7 +314,7 @@ class Plan:
                 v.buf = v.cat.buf
         self.prep = self._new(self.B, self.H + 4, self.W + 4, 4)
         f32 = torch.float32
-        max_stats = max_dy = max_wg = max_bnws = 1
+        max_stats = max_dy = max_wg = max_bnws = max_f1 = 1
         for u in self.units:
             if isinstance(u, ConvUnit):
                 o = u.outs[0]
@@ -331,7 +339,9 @@ class Plan:
                     max_stats = max(max_stats, u.mtiles * 2 * u.K)
                     max_dy = max(max_dy, M * u.K)
                     max_wg = max(max_wg, ops.wgrad_ws_bytes(o.n, hin, win, u.C, u.K, u.k, u.k, u.s, u.p, dt, stem=u.stem))
-                    max_bnws = max(max_bnws, ops.bn_bwd_ws_floats(M, max(u.Ks)))
+                    max_bnws = max(max_bnws, ops.bn_bwd_ws_floats(M, u.K))
+                    if self._fusable_1x1(u):
+                        max_f1 = max(max_f1, ops.fused_1x1_ws_bytes(M, u.C, u.K))
                     if not u.stem:
                         u.wpd = ops.pack_alloc(u.K, u.C, u.k, u.k, u.s, u.p, ops.PACK_DGRAD, dt, self.device)
             elif isinstance(u, DetUnit):
@@ -364,6 +374,7 @@ class Plan:
         self.dy_ring = [self._new(max_dy) for _ in range(DY_RING if SIDE_WGRAD else 1)]
         self.dy = self.dy_ring[0]
         self.wg_ws = self._new(max_wg // 4 + 16, dtype=f32)
+        self.f1_ws = self._new(max_f1 // 4 + 16, dtype=f32)      # weight-gradient slabs of the fused 1x1 backward (main stream: not shared with wg_ws)
         self.bn_ws = self._new(max_bnws, dtype=f32)
         kmax = max(u.K for u in self.units if isinstance(u, ConvUnit))
         self.fin_ws = self._new(32 * 2 * kmax, dtype=torch.float64)
@@ -614,12 +625,16 @@ class Plan:
                 if not u.outs[0].needs_grad:
                     continue
                 o0 = u.outs[0]
-                slot = nconv % len(self.dy_ring)
-                nconv += 1
-                if slot in slot_user:              # the weight gradient that last read this ring slot must be done
-                    recs.append(('@join', side, slot_user.pop(slot)))
-                dy = self.dy_ring[slot][:o0.n * o0.h * o0.w * u.K].view(o0.n, o0.h, o0.w, u.K)
+                fused = self._fusable_1x1(u)
                 pair = len(u.mods) == 2 and not u.frozen
+                dy = None
+                if not fused:
+                    slot = nconv % len(self.dy_ring)
+                    nconv += 1
+                    if slot in slot_user:              # the weight gradient that last read this ring slot must be done
+                        recs.append(('@join', side, slot_user.pop(slot)))
+                    dy = self.dy_ring[slot][:o0.n * o0.h * o0.w * u.K].view(o0.n, o0.h, o0.w, u.K)
+                # BatchNorm / SiLU backward: statistics (reduce + finalize) and, unless the fused kernel applies them, dy
                 if pair:
                     ma, mb = u.mods
                     recs.append(ops.rec_bn_act_bwd_pair(u.outs[0].gread(), u.outs[1].gread(), u.yraw, u.scale, u.shift, u.mean, u.invstd, dy,
@@ -630,24 +645,23 @@ class Plan:
                     if pair:
                         break
                     K = m.conv.out_channels
+                    dyk = None if dy is None else dy[..., k0:k0 + K]
                     if u.frozen:
                         recs.append(ops.rec_bn_act_bwd(o.gread(), u.yraw[..., k0:k0 + K], u.scale[k0:k0 + K], u.shift[k0:k0 + K], None, None,
-                                                       dy[..., k0:k0 + K], None, None, self.bn_ws, act=u.act))
+                                                       dyk, None, None, self.bn_ws, act=u.act))
                     else:
                         recs.append(ops.rec_bn_act_bwd(o.gread(), u.yraw[..., k0:k0 + K], u.scale[k0:k0 + K], u.shift[k0:k0 + K],
-                                                       u.mean[k0:k0 + K], u.invstd[k0:k0 + K], dy[..., k0:k0 + K],
+                                                       u.mean[k0:k0 + K], u.invstd[k0:k0 + K], dyk,
                                                        self._grad_views(m.bn.weight), self._grad_views(m.bn.bias), self.bn_ws, act=u.act))
                     k0 += K
                 x = self.prep if u.stem else u.x.t()
                 stem_hw = (self.H, self.W) if u.stem else None
-                ga = self._grad_views(u.mods[0].conv.weight)
-                gb = self._grad_views(u.mods[1].conv.weight) if len(u.mods) > 1 else None
-                if any(m.conv.weight.requires_grad for m in u.mods):
-                    wgrad(ops.rec_conv_wgrad(x, dy, ga, gb, u.k, u.k, u.s, u.p, self.wg_ws, stem_hw=stem_hw), reads_dy_slot=slot)
-                if not u.stem and u.x is not self.input and up(u.x):
+                want_w = any(m.conv.weight.requires_grad for m in u.mods)
+                want_x = not u.stem and u.x is not self.input and up(u.x)
+                acc, xv = False, u.x
+                if want_x:
                     wb = u.mods[1].conv.weight if len(u.mods) > 1 else None
                     self.packs.add(u.mods[0].conv.weight, wb, u.s, u.p, ops.PACK_DGRAD, u.wpd)
-                    xv = u.x
                     if xv.parts is not None:
                         # writing the whole concat gradient: no part may already hold a partial contribution
                         if any(pv.ginit for pv, _ in xv.parts) and not xv.ginit:
@@ -656,6 +670,21 @@ class Plan:
                         xv.ginit = True
                     else:
                         acc = self._contrib(xv)
+                if fused:
+                    if want_w or want_x:
+                        M = o0.n * o0.h * o0.w
+                        c1, c2 = ops.bn_bwd_coeffs(self.bn_ws, M, u.K)
+                        ga = self._grad_views(u.mods[0].conv.weight) if want_w else None
+                        gb = self._grad_views(u.mods[1].conv.weight) if want_w and len(u.mods) > 1 else None
+                        recs.append(ops.rec_conv1x1_bwd_fused(u.outs[0].gread(), u.outs[1].gread() if len(u.mods) > 1 else None, u.yraw, u.scale,
+                                                              u.shift, u.mean, u.invstd, c1, c2, x, u.wpd if want_x else None,
+                                                              xv.g() if want_x else None, ga, gb, self.f1_ws, accumulate_dx=acc))
+                    continue
+                ga = self._grad_views(u.mods[0].conv.weight)
+                gb = self._grad_views(u.mods[1].conv.weight) if len(u.mods) > 1 else None
+                if want_w:
+                    wgrad(ops.rec_conv_wgrad(x, dy, ga, gb, u.k, u.k, u.s, u.p, self.wg_ws, stem_hw=stem_hw), reads_dy_slot=slot)
+                if want_x:
                     recs.append(ops.rec_conv_dgrad(dy, u.wpd, xv.g(), u.k, u.k, u.s, u.p, accumulate=acc))
         self._mark_buckets(recs, side)
         if side is not None and nfork[0]:

@@ -93,6 +93,19 @@ int hdy_conv_wgrad(const void* x, int ldx, const void* dy, int lddy, int N, int 
                    float* grad_a, int K_a, float* grad_b, int K_b, int accumulate, void* workspace, size_t ws_bytes, int dtype, int stem,
                    void* stream);
 
+/* Fused backward of a 1x1 Conv + BatchNorm(train) + SiLU unit (metayolo/models/layers.py:31-38 under autograd, train.py:472): from
+ * the output gradient dz ([0,Ka) from dz_a, [Ka,K) from dz_b), the raw conv output y, the BatchNorm coefficients and c1 / c2 of
+ * hdy_bn_act_bwd(dy = NULL), computes dy = scale*(dz*silu'(u) - c1 - xhat*c2) on the fly and from it BOTH dx (+)= dy * W (NULL: skipped)
+ * and the weight gradient grad_a / grad_b (+)= dy^T * x (NULL: skipped) in one pass: dy never goes to HBM.  bf16, C == K in {32, 64, 128}
+ * (hdy_conv1x1_bwd_fused_ok); w_packed_dgrad = hdy_conv_pack(kind = HDY_PACK_DGRAD). */
+int hdy_conv1x1_bwd_fused_ok(int C, int K, int dtype);
+int hdy_conv1x1_bwd_fused_grid(long long M, int K);
+size_t hdy_conv1x1_bwd_fused_workspace_bytes(long long M, int C, int K);
+int hdy_conv1x1_bwd_fused(const void* dz_a, int lddz_a, const void* dz_b, int lddz_b, int Ka, const void* y, int ldy, const float* scale,
+                          const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2, const void* x, int ldx,
+                          const void* w_packed_dgrad, void* dx, int lddx, int accumulate_dx, float* grad_a, int K_a, float* grad_b, int K_b,
+                          int accumulate_w, long long M, int C, int K, void* workspace, size_t ws_bytes, int dtype, void* stream);
+
 /* ---- BatchNorm + SiLU (+ residual) ---------------------------------------------------------------------------
  * Replaces nn.BatchNorm2d (eps 1e-3, momentum 0.03: metayolo/models/utils_torch.py:47-49) and nn.SiLU in
  * Conv.forward (metayolo/models/layers.py:37-38), the shortcut add of Bottleneck.forward (:97), their backward,
@@ -127,6 +140,8 @@ int hdy_bn_bwd_blocks(long long M);
 int hdy_bn_act_bwd(const void* dz, int lddz, const void* y, int ldy, const float* scale, const float* shift, const float* mean,
                    const float* invstd, void* dy, int lddy, float* dgamma, float* dbeta, int accumulate, long long M, int K, int act,
                    int dtype, float* workspace, void* stream);
+/* dy == NULL: statistics only (reduce + finalize: dgamma, dbeta, and c1 = dbeta/M, c2 = dgamma/M left in
+ * workspace[hdy_bn_bwd_blocks(M)*2*K .. +2K)) for a consumer that applies them itself (hdy_conv1x1_bwd_fused). */
 /* The same three passes for the PAIR of BatchNorms behind a C3's cv1 | cv2 (metayolo/models/layers.py:126-131: both read the same
  * input, so their convolutions run as one K = Ka + Kb wide launch): BatchNorm is per channel, so the pair is one K-wide layer; only
  * what the two modules own separately splits at Ka — parameters, running statistics and parameter gradients (finalize), the two

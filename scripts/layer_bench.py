@@ -48,12 +48,19 @@ def describe(rec):
         return f'bnfw K={K} M={M}', 0.0, 2.0 * M * K * (3 if a[4] else 2)
     if name == 'hdy_bn_act_bwd':
         M, K = a[13], a[14]
+        if a[8] is None:
+            return f'bnst K={K} M={M}', 0.0, 2.0 * M * K * 2
         return f'bnbw K={K} M={M}', 0.0, 2.0 * M * K * 5
+    if name == 'hdy_conv1x1_bwd_fused':
+        M, C, K = a[24], a[25], a[26]
+        return f'f1x1 {C:4d}<>{K:4d} M={M}' + (' acc' if a[18] else ''), 4.0 * M * K * C, 2.0 * M * (2 * K + (3 if a[18] else 2) * C)
     if name == 'hdy_bn_act_fwd_pair':
         M, K = a[9], a[10]
         return f'bnfw K={K} M={M} (pair)', 0.0, 2.0 * M * K * 2
     if name == 'hdy_bn_act_bwd_pair':
         M, K = a[18], a[19]
+        if a[11] is None:
+            return f'bnst K={K} M={M} (pair)', 0.0, 2.0 * M * K * 2
         return f'bnbw K={K} M={M} (pair)', 0.0, 2.0 * M * K * 5
     return name[4:], 0.0, 0.0
 

@@ -20,7 +20,8 @@ def _free_port():
 
 
 def _worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), YOLOv5_VERBOSE='false')
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), YOLOv5_VERBOSE='false',
+                      HDY_GRAD_BUCKET_MB='1')              # yolov5n has 7 MB of gradients: several overlapped buckets per backward
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from hd_yolo_amd import synth
@@ -35,12 +36,14 @@ def _worker(rank, world, port, q):
         model.load_state_dict(sd, strict=False)
         model = model.to(dev).train()
         net = DataParallel(model, nbuckets=3)
+        net.reducer.MIN_BYTES = 1 << 20
         start = torch.cat([p.detach().flatten() for p in model.parameters()]).cpu()
         x = synth.synth_images(2, 64, seed=20 + rank).to(dev)
         tg = synth.synth_targets(2, 64, 2, nmin=3, nmax=8, seed=30 + rank)
         # local gradient without the hook, for the sum check
         eng = model._eng()
         hooks, eng.grad_hooks = eng.grad_hooks, []
+        bhooks, eng.bucket_hooks = eng.bucket_hooks, []
         losses, _ = net(x, tg)
         losses['det']['det_loss'].backward()
         local = torch.cat([p.grad.flatten() for p in model.parameters()]).cpu().clone()
@@ -49,11 +52,15 @@ def _worker(rank, world, port, q):
         for m in model.modules():                     # undo the BN statistics update of the probe step
             if isinstance(m, torch.nn.BatchNorm2d):
                 m.load_state_dict({k: v for k, v in sd_bn(m).items()})
-        eng.grad_hooks = hooks
+        eng.grad_hooks, eng.bucket_hooks = hooks, bhooks
         opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.9)
         losses, _ = net(x, synth.synth_targets(2, 64, 2, nmin=3, nmax=8, seed=30 + rank))
         losses['det']['det_loss'].backward()
         reduced = torch.cat([p.grad.flatten() for p in model.parameters()]).cpu().clone()
+        plan = next(iter(eng.plans.values()))
+        assert len(plan.grad_marks) >= 4 and net.reducer.calls >= 4, (len(plan.grad_marks), net.reducer.calls)     # issued during backward
+        covered = sorted((a, b) for _, a, b in plan.grad_marks)
+        assert covered[0][0] == 0 and covered[-1][1] == eng.store.numel and all(x[1] == y[0] for x, y in zip(covered, covered[1:]))
         opt.step()
         opt.zero_grad(set_to_none=True)
         losses, _ = net(x, synth.synth_targets(2, 64, 2, nmin=3, nmax=8, seed=30 + rank))

@@ -23,7 +23,7 @@ def test_train_py_trains_validates_checkpoints_and_resumes(tmp_path):
     out = run(base + ['--epochs', '2'])
     assert 'epochs completed' in out and 'mAP@.5' in out
     ck = torch.load(tmp_path / 'run' / 'weights' / 'last.pt', map_location='cpu')
-    assert ck['epoch'] == 1 and 'backbone.0.conv.weight' in ck['model'] and 'headers.det.m.2.bias' in ck['ema']
+    assert ck['epoch'] == 2 and 'backbone.0.conv.weight' in ck['model'] and 'headers.det.m.2.bias' in ck['ema']
     assert all(torch.isfinite(v).all() for v in ck['model'].values() if v.dtype.is_floating_point)
     out = run(base + ['--epochs', '3', '--resume', '--weights', str(tmp_path / 'run' / 'weights' / 'last.pt')])
     assert 'epoch 2/2' in out and 'epoch 0/2' not in out
@@ -38,3 +38,64 @@ def test_train_py_two_ranks_gloo(tmp_path):
            '--steps-per-epoch', '3', '--val-batches', '1', '--project', str(tmp_path), '--name', 'dp', '--exist-ok']
     out = run(cmd, env={'HDY_DIST_BACKEND': 'gloo'})
     assert 'epochs completed' in out
+
+
+def test_bench_py_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with no rendezvous in the environment (how the driver calls it) starts two rank processes itself;
+    on a one-GPU box they share the card over gloo."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    p = subprocess.run([sys.executable, 'bench.py', '--gpus', '2', '--steps', '3', '--warmup', '1', '--batch', '4', '--variant', 'n', '--size', '128',
+                        '--no-roofline', '--no-cpu-baseline'], cwd=ROOT, env=dict(env, YOLOv5_VERBOSE='false'), capture_output=True, text=True, timeout=500)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['config']['world_size'] == 2 and line['config']['global_batch'] == 8
+    assert line['config']['backend'] in ('gloo', 'nccl') and line['value'] > 0
+
+
+def test_train_py_cfg_hyp_freeze_masks_save_period(tmp_path):
+    import yaml
+    sys.path.insert(0, ROOT)
+    from hd_yolo_amd import synth
+    cfg = synth.make_cfg('n', 3)
+    cfg['headers'][0][3][3] = 1                      # mask branch, one shared mask class (yolov5l6-mask.yaml:64)
+    with open(tmp_path / 'model.yaml', 'w') as f:
+        yaml.safe_dump(cfg, f)
+    with open(tmp_path / 'hyp.yaml', 'w') as f:
+        yaml.safe_dump({'lr0': 0.005, 'det': {'box': 0.04}}, f)
+    out = run([sys.executable, 'train.py', '--cfg', str(tmp_path / 'model.yaml'), '--hyp', str(tmp_path / 'hyp.yaml'), '--freeze', 'backbone',
+               '--masks', '--label-smoothing', '0.1', '--save-period', '1', '--batch-size', '4', '--imgsz', '128', '--epochs', '2',
+               '--steps-per-epoch', '3', '--val-batches', '1', '--project', str(tmp_path), '--name', 'run', '--exist-ok', '--log-every', '1'])
+    assert 'epochs completed' in out and 'det/mask' in out
+    w = tmp_path / 'run' / 'weights'
+    assert (w / 'epoch1.pt').exists() and (w / 'epoch2.pt').exists()
+    a, b = torch.load(w / 'epoch1.pt', map_location='cpu'), torch.load(w / 'epoch2.pt', map_location='cpu')
+    assert a['epoch'] == 1 and b['epoch'] == 2
+    assert torch.equal(a['model']['backbone.3.conv.weight'], b['model']['backbone.3.conv.weight'])            # frozen
+    assert torch.equal(a['model']['backbone.3.bn.running_mean'], b['model']['backbone.3.bn.running_mean'])    # FrozenBatchNorm2d
+    assert not torch.equal(a['model']['neck.0.conv.weight'], b['model']['neck.0.conv.weight'])
+    assert not torch.equal(a['model']['headers.det.seg_h.maskrcnn_preds.mask_fcn_logits.weight'],
+                           b['model']['headers.det.seg_h.maskrcnn_preds.mask_fcn_logits.weight'])              # the mask head trained
+    hyp = yaml.safe_load(open(tmp_path / 'run' / 'hyp.yaml'))
+    assert hyp['lr0'] == 0.005 and hyp['det']['box'] == 0.04 and hyp['det']['label_smoothing'] == 0.1 and hyp['det']['cls'] == 0.5
+
+
+def test_train_py_reads_reference_style_checkpoint(tmp_path):
+    """The reference saves pickled half-precision modules under 'model' / 'ema' and 'epoch' = finished epochs (train.py:530-540)."""
+    sys.path.insert(0, ROOT)
+    from hd_yolo_amd import synth
+    from metayolo.models.yolo import Model
+    m = Model(synth.make_cfg('n', 2), synth.make_hyp())
+    m.load_state_dict(synth.synth_state_dict(synth.shapes_of(m), seed=3), strict=False)
+    ema = Model(synth.make_cfg('n', 2), synth.make_hyp())
+    ema.load_state_dict(synth.synth_state_dict(synth.shapes_of(ema), seed=4), strict=False)
+    torch.save({'epoch': 1, 'best_fitness': 0.0, 'model': torch.nn.Module.half(m), 'ema': torch.nn.Module.half(ema), 'updates': 7, 'optimizer': None},
+               tmp_path / 'ref.pt')
+    out = run([sys.executable, 'train.py', '--variant', 'n', '--nc', '2', '--weights', str(tmp_path / 'ref.pt'), '--batch-size', '4', '--imgsz', '64',
+               '--epochs', '1', '--steps-per-epoch', '2', '--val-batches', '1', '--project', str(tmp_path), '--name', 'r', '--exist-ok', '--noval'])
+    assert 'Transferred' in out and 'epochs completed' in out
+    n = len(m.state_dict()) - sum('anchor' in k for k in m.state_dict())
+    assert f'Transferred {n}/' in out
+    out = run([sys.executable, 'val_nuclei.py', '--variant', 'n', '--nc', '2', '--imgsz', '64', '--batch-size', '2', '--batches', '1',
+               '--weights', str(tmp_path / 'ref.pt')])
+    assert 'fitness' in out

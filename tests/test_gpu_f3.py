@@ -122,3 +122,98 @@ def test_non_max_suppression_every_option_matches_reference():
         res = non_max_suppression(preds.clone(), conf_thres=0.2, iou_thres=0.5, **kw)
         for b, d in enumerate(res):
             np.testing.assert_array_equal(d.cpu().numpy(), g[f'{tag}_{b}'], err_msg=f'{tag} image {b}')
+
+
+# ---------------------------------------------------------------------------------------------- round 2 additions
+def test_nms_boxes_negative_scores_and_more_than_one_launch_of_survivors():
+    """torchvision.ops.nms takes scores of any sign and returns EVERY survivor: the wrapper continues the greedy pass when one
+    launch's 4096-entry kept list fills up (whole-slide merges), and ranks negative scores below positive ones."""
+    g = torch.Generator().manual_seed(5)
+    n = 14000
+    c = torch.rand((n, 2), generator=g) * 4000                    # sparse: most boxes survive
+    wh = torch.rand((n, 2), generator=g) * 30 + 6
+    boxes = torch.cat([c - wh / 2, c + wh / 2], 1)
+    scores = torch.rand(n, generator=g) * 2 - 1                   # half of them negative
+    scores[::11] = scores[3]
+    scores[5] = 0.0
+    scores[6] = -0.0
+    want = nms_ref.nms_numpy(boxes.numpy(), scores.numpy(), 0.4)
+    assert len(want) > 2 * 4096
+    got = ops.nms(boxes.to(DEV), scores.to(DEV), 0.4).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+    got = ops.nms(boxes.to(DEV), scores.to(DEV), 0.4, max_det=5000).cpu().numpy()
+    np.testing.assert_array_equal(got, want[:5000])
+
+
+@pytest.mark.parametrize('tag,ml', [('single', False), ('multi', True)])
+def test_compute_outputs_matches_reference_golden(tag, ml):
+    """Detect.compute_outputs on the HIP path (decode kernel -> NMS kernel -> score / label logic) against the reference's own
+    outputs for the same logits, incl. multi_label=True (reference: yolo_head.py:301-355; tests/golden/outputs.npz)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'outputs.npz'))
+    model = Model(synth.make_cfg('n', 3), synth.make_hyp(conf_thres=0.15, multi_label=ml)).to(DEV).eval()
+    head = model.headers['det']
+    dets = [torch.from_numpy(g[f'{tag}_det_{i}']).to(DEV) for i in range(3)]
+    for preds in (head.compute_proposals(dets), head.decode_all(dets)):          # per-level list and the fused (bs, N, no+1) form
+        res = head.compute_outputs(preds, [], compute_masks=False)
+        assert len(res) == 2
+        for b, o in enumerate(res):
+            np.testing.assert_allclose(o['boxes'].cpu().numpy(), g[f'{tag}_out_{b}_boxes'], rtol=1e-4, atol=1e-3)
+            np.testing.assert_allclose(o['scores'].cpu().numpy(), g[f'{tag}_out_{b}_scores'], rtol=1e-5, atol=1e-6)
+            assert np.array_equal(o['labels'].cpu().numpy(), g[f'{tag}_out_{b}_labels'])
+            if ml:
+                assert o['labels'].dim() == 2 and o['labels'].shape[1] == 1 + head.nc
+
+
+def test_evaluation_caller_end_to_end(tmp_path):
+    """evaluation.py: checkpoint -> build_model -> Deploy -> timed loop with resize and scale_coords back to the tile frame; the same
+    tiles run directly through the model at the network size give the same detections up to the rescale + round."""
+    import evaluation
+    from metayolo.datasets import SyntheticTiles
+    from metayolo.models.utils_general import scale_coords
+    ref = Model(synth.make_cfg('n', 3), synth.make_hyp(conf_thres=0.05))
+    ref.load_state_dict(synth.synth_state_dict(synth.shapes_of(ref), seed=2), strict=False)
+    torch.save({'model': ref.state_dict(), 'ema': None, 'epoch': 3}, tmp_path / 'w.pt')
+    model, deployed = evaluation.build_model(str(tmp_path / 'w.pt'), ref_model=ref, half=False,
+                                             extra_configs={'headers': {'det': {'nms_params': {'conf_thres': 0.05, 'iou_thres': 0.5, 'max_det': 50}}}})
+    assert model.headers['det'].nms_params['max_det'] == 50.0 and not model.training
+    loader = SyntheticTiles(3, 96, 3, 2, seed=77)                      # 96 px tiles, network input 128
+    results, spi = evaluation.inference_on_loader_yolov5(deployed, loader, DEV, input_size=128)
+    assert len(results) == 6 and spi > 0
+    k = 0
+    for images, _ in SyntheticTiles(3, 96, 3, 2, seed=77):
+        x = torch.nn.functional.interpolate(torch.stack(list(images)).to(DEV), size=(128, 128), mode='bilinear', align_corners=False)
+        _, outs = model(x)
+        for o in outs:
+            want = scale_coords((128, 128), o['det']['boxes'].clone(), (96, 96)).round().cpu()
+            got = results[k]['det']
+            assert got['boxes'].device.type == 'cpu' and torch.equal(got['boxes'], want) and torch.equal(got['labels'], o['det']['labels'].cpu())
+            k += 1
+    assert sum(len(r['det']['boxes']) for r in results) > 0
+    ens, ens_dep = evaluation.attempt_load_model([str(tmp_path / 'w.pt')] * 2, ref_model=ref, half=False)
+    assert isinstance(ens_dep, Ensemble) and len(ens_dep) == 2
+
+
+def test_inference_on_slide_merges_rois():
+    """Whole-slide protocol (Detect.merge_outputs / rescale_outputs, yolo_head.py:450-471): without overlap the merged result is exactly
+    the per-tile detections shifted by their roi; rescale_outputs scales the boxes; with overlap duplicates are removed by one NMS."""
+    import evaluation
+    m = Model(synth.make_cfg('n', 3), synth.make_hyp(conf_thres=0.05)).to(DEV).eval()
+    m.load_state_dict(synth.synth_state_dict(synth.shapes_of(m), seed=2), strict=False)
+    dep = Deploy(m)
+    slide = synth.synth_images(1, 256, seed=9)[0].to(DEV)
+    assert evaluation.slide_rois(256, 256, 128, 0) == [(0, 0), (128, 0), (0, 128), (128, 128)]
+    assert evaluation.slide_rois(300, 128, 128, 32) == [(0, 0), (0, 96), (0, 172)]
+    out = evaluation.inference_on_slide(dep, slide, tile=128, overlap=0, batch_size=3, scale=0.5)['det']
+    want_b, want_s = [], []
+    for (x0, y0) in evaluation.slide_rois(256, 256, 128, 0):
+        _, o = dep(slide[None, :, y0:y0 + 128, x0:x0 + 128].contiguous())
+        want_b.append(o[0]['det']['boxes'] + torch.tensor([x0, y0, x0, y0], device=DEV, dtype=torch.float32))
+        want_s.append(o[0]['det']['scores'])
+    assert len(out['boxes']) > 0
+    torch.testing.assert_close(out['boxes'], torch.cat(want_b).clamp(0, 256) * 0.5)
+    assert torch.equal(out['scores'], torch.cat(want_s))
+    dup = evaluation.inference_on_slide(dep, slide, tile=128, overlap=64, batch_size=4)['det']
+    s = dup['scores']
+    assert (s[:-1] >= s[1:]).all()                                 # NMS order
+    again = ops.nms(dup['boxes'], dup['scores'], m.headers['det'].nms_params['iou_thres'])
+    assert len(again) == len(dup['boxes'])                         # idempotent: nothing left to suppress

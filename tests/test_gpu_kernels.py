@@ -433,3 +433,81 @@ def test_errors_are_loud():
     wp = torch.zeros(4096, dtype=torch.bfloat16, device=DEV)
     with pytest.raises(_lib.HdyError):
         ops.run([ops.rec_conv_fwd(x, wp, y, 8, 1, 1, 1, 0)])
+
+
+# ---------------------------------------------------------------------------------------------- fused 1x1 backward (conv1x1_bwd.hip)
+@pytest.mark.parametrize('K,M,pair,acc', [(32, 128 * 3 + 37, False, False), (64, 128 * 5 + 1, True, True), (64, 90, False, True),
+                                          (128, 128 * 4 + 77, True, False), (128, 128 * 150 + 5, False, True), (64, 128 * 180, True, False)])
+def test_fused_1x1_backward_matches_reference_and_the_three_launch_path(K, M, pair, acc):
+    """hdy_conv1x1_bwd_fused (BatchNorm/SiLU backward apply + wgrad + dgrad in one pass) against (a) plain torch fp32 on the bf16-rounded
+    operands and (b) the three-launch path (hdy_bn_act_bwd -> dy, hdy_conv_wgrad, hdy_conv_dgrad) it replaces: same dy bits, so dx / dW
+    differ by accumulation order only.  Operands are channel slices of wider buffers; the pair case splits dz over two tensors."""
+    dt = torch.bfloat16
+    C = K
+    dz = rnd((1, K, 1, M), 1)
+    y = rnd((1, K, 1, M), 2, 2.0) + rnd((1, K, 1, 1), 3)                  # per-channel offsets: non-trivial mean / invstd
+    x = rnd((1, C, 1, M), 4)
+    w = rnd((K, C, 1, 1), 5, 0.3)
+    dx0 = rnd((1, C, 1, M), 6, 0.5)
+    gamma, beta = rnd((K,), 7) + 1.5, rnd((K,), 8, 0.3)
+    Ka = K // 2 if pair else K
+    dz_a = to_dev_nhwc(dz[:, :Ka], dt, ld=Ka + 16, off=8)
+    dz_b = to_dev_nhwc(dz[:, Ka:], dt, ld=K + 8, off=0) if pair else None
+    yd = to_dev_nhwc(y, dt)
+    xd = to_dev_nhwc(x, dt, ld=C + 24, off=16)
+    dzq, yq, xq, wq = q(dz, dt)[0, :, 0].T, q(y, dt)[0, :, 0].T, q(x, dt)[0, :, 0].T, q(w, dt)[:, :, 0, 0]          # (M, K) (M, K) (M, C) (K, C)
+    # BatchNorm coefficients as the forward pass would have left them (batch statistics of y)
+    mean, var = yq.mean(0), yq.var(0, unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-3)
+    scale, shift = gamma * invstd, beta - mean * gamma * invstd
+    u = yq * scale + shift
+    sg = torch.sigmoid(u)
+    du = dzq * (sg * (1 + u * (1 - sg)))
+    xh = (yq - mean) * invstd
+    c1, c2 = du.mean(0), (du * xh).mean(0)
+    dy = q(scale * (du - c1 - xh * c2), dt)
+    ref_dx = dy @ wq + (q(dx0, dt)[0, :, 0].T if acc else 0.0)
+    ref_dw = dy.T @ xq
+    dev = lambda t: t.float().contiguous().to(DEV)
+    sc_d, sh_d, mu_d, is_d = dev(scale), dev(shift), dev(mean), dev(invstd)
+    ws = torch.empty(ops.bn_bwd_ws_floats(M, K), dtype=torch.float32, device=DEV)
+    dgam, dbet = torch.zeros(K, device=DEV), torch.zeros(K, device=DEV)
+    wpd = ops.pack_alloc(K, C, 1, 1, 1, 0, ops.PACK_DGRAD, dt, DEV)
+    ops.run([ops.rec_pack(w.to(DEV), None, 1, 0, ops.PACK_DGRAD, wpd)])
+
+    def stats_rec(dy_out):
+        if pair:
+            return ops.rec_bn_act_bwd_pair(dz_a, dz_b, yd, sc_d, sh_d, mu_d, is_d, dy_out, dgam[:Ka], dbet[:Ka], dgam[Ka:], dbet[Ka:], ws)
+        return ops.rec_bn_act_bwd(dz_a, yd, sc_d, sh_d, mu_d, is_d, dy_out, dgam, dbet, ws)
+
+    # (b) three launches
+    dy_d = torch.empty((1, 1, M, K), dtype=dt, device=DEV)
+    dx_b = to_dev_nhwc(dx0, dt, ld=C + 8, off=8)
+    gw_b = torch.zeros((K, C, 1, 1), device=DEV)
+    wgws = torch.empty(ops.wgrad_ws_bytes(1, 1, M, C, K, 1, 1, 1, 0, dt) // 4 + 16, dtype=torch.float32, device=DEV)
+    ops.run([stats_rec(dy_d), ops.rec_conv_wgrad(xd, dy_d, gw_b[:Ka], gw_b[Ka:] if pair else None, 1, 1, 1, 0, wgws),
+             ops.rec_conv_dgrad(dy_d, wpd, dx_b, 1, 1, 1, 0, accumulate=acc)])
+    # (a) fused
+    dx_f = to_dev_nhwc(dx0, dt, ld=C + 8, off=8)
+    gw_f = torch.zeros((K, C, 1, 1), device=DEV)
+    f1ws = torch.empty(ops.fused_1x1_ws_bytes(M, C, K) // 4 + 16, dtype=torch.float32, device=DEV)
+    c1_d, c2_d = ops.bn_bwd_coeffs(ws, M, K)
+    ops.run([stats_rec(None),
+             ops.rec_conv1x1_bwd_fused(dz_a, dz_b, yd, sc_d, sh_d, mu_d, is_d, c1_d, c2_d, xd, wpd, dx_f, gw_f[:Ka], gw_f[Ka:] if pair else None, f1ws,
+                                       accumulate_dx=acc)])
+    torch.cuda.synchronize()
+    assert_close(c1_d.cpu(), c1, 2e-3, 'c1')
+    got_dx, got_dw = dx_f.float().cpu()[0, 0], gw_f.cpu()[:, :, 0, 0]
+    assert_close(got_dx, ref_dx, 1.5e-2, 'dx vs torch')
+    assert_close(got_dw, ref_dw, 1.5e-2, 'dW vs torch')
+    assert_close(got_dx, dx_b.float().cpu()[0, 0], 8e-3, 'dx vs three launches')         # one bf16 rounding of the output apart at most
+    assert_close(got_dw, gw_b.cpu()[:, :, 0, 0], 2e-4, 'dW vs three launches')           # fp32 sums in a different order
+    # dgrad only / wgrad only
+    dx_o = to_dev_nhwc(dx0, dt, ld=C + 8, off=8)
+    gw_o = torch.zeros((K, C, 1, 1), device=DEV)
+    ops.run([ops.rec_conv1x1_bwd_fused(dz_a, dz_b, yd, sc_d, sh_d, mu_d, is_d, c1_d, c2_d, xd, wpd, dx_o, None, None, f1ws, accumulate_dx=acc),
+             ops.rec_conv1x1_bwd_fused(dz_a, dz_b, yd, sc_d, sh_d, mu_d, is_d, c1_d, c2_d, xd, None, None, gw_o[:Ka], gw_o[Ka:] if pair else None, f1ws)])
+    torch.cuda.synchronize()
+    assert torch.equal(dx_o, dx_f) and torch.equal(gw_o, gw_f)
+    assert xd._base[..., :16].float().eq(7.0).all()         # poison outside the slices untouched
+    assert dx_f._base[..., :8].float().eq(7.0).all()
