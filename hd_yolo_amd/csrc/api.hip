@@ -3,6 +3,7 @@
 // on the caller's stream.  No allocation, no synchronisation, no global state besides the thread-local error text.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "common.h"
 #include "hdyolo_internal.h"
@@ -204,6 +205,34 @@ int hdy_conv_dgrad(const void* dy, int lddy, const void* w_packed_dgrad, void* d
     }
     const int rows_total = round_up(C, hdy_conv_bn_tile(C));
     size_t off = 0;
+    // One launch walking the four parity classes per spatial tile (conv_igemm.hip, `walk`): every class has the same Ho x Wo when H and W
+    // are even.  As four launches each class wrote every other pixel of every other row (half cache lines, each line written by two
+    // launches) and read dy from HBM again: 32<-64 @320x320 B=64 took 353 us against a 100 us bound.
+    static const bool no_walk = getenv("HDY_NO_CLASS_WALK") != nullptr;
+    if (H % 2 == 0 && W % 2 == 0 && !no_walk) {
+        ConvArgs c = a;
+        c.ncls = 4;
+        c.Ho = H / 2; c.Wo = W / 2;
+        c.oh_mul = c.ow_mul = 2; c.dense_out = 0;
+        bool ok = true;
+        for (int ca = 0; ca < 2 && ok; ++ca)
+            for (int cb = 0; cb < 2; ++cb) {
+                const Axis ah = class_axis(R, pad, ca), aw = class_axis(S, pad, cb);
+                if (!ah.taps || !aw.taps) { ok = false; break; }
+                const int i = ca * 2 + cb;
+                const int Kdp = round_up(ah.taps * aw.taps * K, bke(dtype));
+                c.c_dh[i] = ah.d0; c.c_dw[i] = aw.d0; c.c_TH[i] = ah.taps; c.c_TW[i] = aw.taps;
+                c.c_nkb[i] = Kdp / bke(dtype); c.c_oh[i] = ca; c.c_ow[i] = cb; c.c_w[i] = (long long)off;
+                off += (size_t)rows_total * Kdp;
+            }
+        if (ok) {
+            c.w = w_packed_dgrad;
+            c.dh0 = c.c_dh[0]; c.dw0 = c.c_dw[0]; c.TH = c.c_TH[0]; c.TW = c.c_TW[0]; c.oh_off = c.ow_off = 0;
+            c.Kdp = c.c_nkb[0] * bke(dtype);
+            return hdy_conv_igemm_launch(c, dtype, 0, (hipStream_t)stream);
+        }
+        off = 0;
+    }
     for (int ca = 0; ca < 2; ++ca)
         for (int cb = 0; cb < 2; ++cb) {
             const Axis ah = class_axis(R, pad, ca), aw = class_axis(S, pad, cb);

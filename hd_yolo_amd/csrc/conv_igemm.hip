@@ -93,7 +93,10 @@ __global__ __launch_bounds__(2 * BM, (BM == 256 || BN == 128) ? 2 : (BN == 64 ? 
     const int fr = lane & 15, fq = lane >> 4;
     const int ntiles = p.ntiles;
     const int mtiles = (p.M + BM - 1) / BM;
-    const int tiles_total = mtiles * ntiles;
+    // class walk (stride-2 dgrad in one launch): tile index = (m-tile, n-tile, parity class), class innermost, so that the four
+    // half-line writes of a 2x2 output block leave one CU back to back (they merge in L2) and dy tiles are re-read from L2
+    const bool walk = p.ncls > 1;
+    const int tiles_total = mtiles * ntiles * (walk ? 4 : 1);
     const int tpb = (tiles_total + (int)gridDim.x - 1) / (int)gridDim.x;
     const int tile_begin = xcd_remap(blockIdx.x, gridDim.x) * tpb;
     const int tile_end = min(tile_begin + tpb, tiles_total);
@@ -123,10 +126,24 @@ __global__ __launch_bounds__(2 * BM, (BM == 256 || BN == 128) ? 2 : (BN == 64 ? 
     int ld_tile = tile_begin, ld_kb = 0, ld_mtile = -1;
     int cc = 0, th = 0, tw = 0;
     const T* wrow0 = w;
-    const size_t wstep = (size_t)RSTEP * p.Kdp;          // distance between a thread's staged filter rows
+    size_t wstep = (size_t)RSTEP * p.Kdp;                // distance between a thread's staged filter rows
     const int HoWo = p.Ho * p.Wo;
+    // tap window of the loader's current tile: taps run th in [l_th0, l_TH), tw in [l_tw0, l_TW) relative to class 0's origin
+    int l_th0 = 0, l_tw0 = 0, l_TH = p.TH, l_TW = p.TW, l_nkb = nkb;
 
     auto loader_set_tile = [&](int t) {
+        const T* wbase = w;
+        int Kdp = p.Kdp;
+        if (walk) {
+            const int cls = t & 3;
+            t >>= 2;
+            l_th0 = p.c_dh[cls] - p.dh0; l_tw0 = p.c_dw[cls] - p.dw0;
+            l_TH = l_th0 + p.c_TH[cls]; l_TW = l_tw0 + p.c_TW[cls];
+            l_nkb = p.c_nkb[cls];
+            Kdp = l_nkb * BKE;
+            wbase = w + p.c_w[cls];
+            wstep = (size_t)RSTEP * Kdp;
+        }
         const int mt = t / ntiles, nt = t - mt * ntiles;
         if (mt != ld_mtile) {
 #pragma unroll
@@ -146,11 +163,11 @@ __global__ __launch_bounds__(2 * BM, (BM == 256 || BN == 128) ? 2 : (BN == 64 ? 
             }
             ld_mtile = mt;
         }
-        wrow0 = w + (size_t)(nt * BN + r0) * p.Kdp + lc * VE;
-        cc = lc * VE; th = 0; tw = 0;
+        wrow0 = wbase + (size_t)(nt * BN + r0) * Kdp + lc * VE;
+        cc = lc * VE; th = l_th0; tw = l_tw0;
         while (cc >= p.C) {
             cc -= p.C;
-            if (++tw == p.TW) { tw = 0; ++th; }
+            if (++tw == l_TW) { tw = l_tw0; ++th; }
         }
     };
 
@@ -158,7 +175,7 @@ __global__ __launch_bounds__(2 * BM, (BM == 256 || BN == 128) ? 2 : (BN == 64 ? 
         unsigned char* sa = smem + buf * STAGE;
         unsigned char* sb = sa + ASZ;
         const long long koff = (long long)(((th * p.Win + tw) * p.ldx + cc) * (int)sizeof(T));      // this chunk's tap and channel
-        const bool tap_ok = th < p.TH;                   // false only in the zero padding of the last k-block
+        const bool tap_ok = th < l_TH;                   // false only in the zero padding of the last k-block
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             const int hi = (int)(hw0[i] >> 16) - 4096 + th, wi = (int)(hw0[i] & 0xFFFFu) - 4096 + tw;
@@ -168,14 +185,14 @@ __global__ __launch_bounds__(2 * BM, (BM == 256 || BN == 128) ? 2 : (BN == 64 ? 
 #pragma unroll
         for (int i = 0; i < BR; ++i) glds16(wrow0 + i * wstep + (size_t)ld_kb * BKE, sb + (wave * 64 + NTHR * i) * 16);
         // advance to the next k-block, possibly of the next tile
-        if (++ld_kb == nkb) {
+        if (++ld_kb == l_nkb) {
             ld_kb = 0;
             if (++ld_tile < tile_end) loader_set_tile(ld_tile);
         } else {
             cc += BKE;
             while (cc >= p.C) {
                 cc -= p.C;
-                if (++tw == p.TW) { tw = 0; ++th; }
+                if (++tw == l_TW) { tw = l_tw0; ++th; }
             }
         }
     };
@@ -238,6 +255,11 @@ __global__ __launch_bounds__(2 * BM, (BM == 256 || BN == 128) ? 2 : (BN == 64 ? 
 
     // returns true when the coalesced path issued its fixed number of row stores per wave (full tile)
     auto epilogue = [&](int t, unsigned char* scratch) -> bool {
+        int oh_off = p.oh_off, ow_off = p.ow_off;
+        if (walk) {
+            oh_off = p.c_oh[t & 3]; ow_off = p.c_ow[t & 3];
+            t >>= 2;
+        }
         const int mtile = t / ntiles, ntile = t - mtile * ntiles;
         const int m0 = mtile * BM, n0 = ntile * BN;
         if (p.stats) {
@@ -355,7 +377,7 @@ __global__ __launch_bounds__(2 * BM, (BM == 256 || BN == 128) ? 2 : (BN == 64 ? 
                         } else {
                             const int n = m / HoWo, rem = m - n * HoWo;
                             const int oi = rem / p.Wo, oj = rem - oi * p.Wo;
-                            opix = ((size_t)n * p.Hout + (p.oh_off + oi * p.oh_mul)) * p.Wout + (p.ow_off + oj * p.ow_mul);
+                            opix = ((size_t)n * p.Hout + (oh_off + oi * p.oh_mul)) * p.Wout + (ow_off + oj * p.ow_mul);
                         }
                         const int chunk = ch ^ ((row & SWM) >> 1);
                         V16 v;
@@ -397,7 +419,7 @@ __global__ __launch_bounds__(2 * BM, (BM == 256 || BN == 128) ? 2 : (BN == 64 ? 
             } else {
                 const int n = m / HoWo, rem = m - n * HoWo;
                 const int oi = rem / p.Wo, oj = rem - oi * p.Wo;
-                opix = ((size_t)n * p.Hout + (p.oh_off + oi * p.oh_mul)) * p.Wout + (p.ow_off + oj * p.ow_mul);
+                opix = ((size_t)n * p.Hout + (oh_off + oi * p.oh_mul)) * p.Wout + (ow_off + oj * p.ow_mul);
             }
             OT* yrow = y + opix * p.ldy;
             const OT* rrow = p.res ? (const OT*)p.res + opix * p.ldr : nullptr;
@@ -423,7 +445,13 @@ __global__ __launch_bounds__(2 * BM, (BM == 256 || BN == 128) ? 2 : (BN == 64 ? 
     // stage s lives in ring slot s % NS.  Iteration `it`: wait until stage it has landed (counted vmcnt: only the stages issued
     // after it may still be in flight; vmcnt retires in issue order), barrier (also: everyone is done with stage it-1), issue
     // stage it+NS-1 into the slot stage it-1 just vacated, then the MFMAs of stage it.
-    const int total = (tile_end - tile_begin) * nkb;
+    int total = (tile_end - tile_begin) * nkb;
+    int c_nkb = nkb;
+    if (walk) {
+        total = 0;
+        for (int t = tile_begin; t < tile_end; ++t) total += p.c_nkb[t & 3];
+        c_nkb = p.c_nkb[tile_begin & 3];
+    }
     int issued = 0;
     loader_set_tile(tile_begin);
     for (; issued < NS - 1 && issued < total; ++issued) loader_issue(issued % NS);
@@ -480,12 +508,13 @@ __global__ __launch_bounds__(2 * BM, (BM == 256 || BN == 128) ? 2 : (BN == 64 ? 
                     for (int b = 0; b < NT; ++b) acc[a][b] = mma16<T>(bf[b], af[a], acc[a][b]);
             }
         }
-        if (++c_kb == nkb) {
+        if (++c_kb == c_nkb) {
             __syncthreads();                       // every wave is done reading stage `it`: its slot is scratch until the next barrier
             stores_pending = epilogue(c_tile, smem + (it % NS) * STAGE);
             zero_acc();
             c_kb = 0;
             ++c_tile;
+            if (walk) c_nkb = p.c_nkb[c_tile & 3];
         }
     }
     if (wg_stats) {
@@ -534,7 +563,7 @@ int launch(const ConvArgs& a, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, OT, BM, BN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
     }
-    const int grid = igemm_grid(a.M, a.ntiles, BM, BN, NS);
+    const int grid = igemm_grid(a.M, a.ntiles * (a.ncls > 1 ? 4 : 1), BM, BN, NS);
     hipLaunchKernelGGL((conv_igemm_kernel<T, OT, BM, BN, NS>), dim3(grid), dim3(2 * BM), smem, st, a);
     HDY_LAUNCH_CHECK("conv_igemm");
     return HDY_OK;
@@ -542,7 +571,7 @@ int launch(const ConvArgs& a, hipStream_t st) {
 
 template <typename T, typename OT>
 int launch_bn(const ConvArgs& a, hipStream_t st) {
-    const bool big = igemm_big(a.M, a.bn, a.ntiles, a.TH * a.TW);
+    const bool big = a.ncls <= 1 && igemm_big(a.M, a.bn, a.ntiles, a.TH * a.TW);
     switch (a.bn) {
         case 32: return launch<T, OT, 128, 32, 2>(a, st);
         case 64: return launch<T, OT, 128, 64, 2>(a, st);
@@ -589,14 +618,20 @@ int hdy_conv_igemm_launch(ConvArgs a, int dtype, int out_f32, hipStream_t st) {
     if (a.dense_out) HDY_ARG(a.oh_mul == 1 && a.ow_mul == 1 && a.oh_off == 0 && a.ow_off == 0 && a.Hout == a.Ho && a.Wout == a.Wo, "conv: dense_out geometry mismatch");
     // 1x1 / stride 1 / no padding: input pixel == output pixel, no coordinate arithmetic in the loader
     a.pointwise = (a.TH == 1 && a.TW == 1 && a.ih_mul == 1 && a.iw_mul == 1 && a.dh0 == 0 && a.dw0 == 0 && a.Hin == a.Ho && a.Win == a.Wo &&
-                   !a.span_pixels) ? 1 : 0;
+                   !a.span_pixels && a.ncls <= 1) ? 1 : 0;
+    if (a.ncls > 1) {
+        HDY_ARG(a.ncls == 4 && !a.dense_out && !a.stats, "conv: class walk is the four-class stride-2 dgrad");
+        for (int c = 0; c < 4; ++c) HDY_ARG(a.c_nkb[c] == round_up(a.c_TH[c] * a.c_TW[c] * a.C, BKE) / BKE, "conv: class %d k-blocks", c);
+    }
     // coalesced 16-byte epilogue needs bf16 output, whole vectors and aligned rows
     const bool bf16_out = dtype == HDY_BF16 && !out_f32;
     a.vec_out = (bf16_out && a.K % 8 == 0 && a.ldy % 8 == 0 && ((uintptr_t)a.y & 15) == 0 &&
                  (!a.res || (a.ldr % 8 == 0 && ((uintptr_t)a.res & 15) == 0))) ? 1 : 0;
     int rc = 0;
-    if (hdy_conv_stem_try(a, dtype, out_f32, st, &rc)) return rc;         // patch-resident 6x6/s2 stem
-    if (hdy_conv3x3_c64_try(a, dtype, out_f32, st, &rc)) return rc;      // filter-resident 3x3 kernel when the shape qualifies
+    if (a.ncls <= 1) {
+        if (hdy_conv_stem_try(a, dtype, out_f32, st, &rc)) return rc;         // patch-resident 6x6/s2 stem
+        if (hdy_conv3x3_c64_try(a, dtype, out_f32, st, &rc)) return rc;      // filter-resident 3x3 kernel when the shape qualifies
+    }
     if (dtype == HDY_BF16) return out_f32 ? launch_bn<bf16_t, float>(a, st) : launch_bn<bf16_t, bf16_t>(a, st);
     return launch_bn<float, float>(a, st);
 }

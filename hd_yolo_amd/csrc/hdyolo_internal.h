@@ -21,6 +21,12 @@ struct ConvArgs {
     int span_pixels;      // 1: the C-wide read deliberately spans several ldx-pitched pixels (stem)
     int pointwise;        // derived: 1x1 stride-1 unpadded (input pixel == output pixel)
     int vec_out;          // derived: bf16 output rows can be written with 16-byte stores
+    // Stride-2 dgrad as ONE launch: ncls = 4 parity classes of output pixels walked back to back per spatial tile (class = tile & 3).
+    // Per class: tap window (c_TH x c_TW taps starting at dy offset c_dh / c_dw), k-blocks, output offsets, packed-weight offset (elements).
+    // The scalar fields above (dh0, dw0, TH, TW, Kdp, oh_off, ow_off, w) hold class 0.  ncls <= 1: an ordinary launch.
+    int ncls;
+    int c_dh[4], c_dw[4], c_TH[4], c_TW[4], c_nkb[4], c_oh[4], c_ow[4];
+    long long c_w[4];
 };
 
 struct WgradArgs {

@@ -61,6 +61,9 @@ CONV_CASES = [
     (1, 10, 10, 48, 24, 3, 1, 1),
     (2, 20, 20, 32, 64, 3, 2, 1),
     (1, 18, 14, 64, 128, 3, 2, 1),
+    (1, 17, 15, 32, 64, 3, 2, 1),        # odd sides: the four parity classes differ in size -> four launches instead of the class walk
+    (3, 64, 96, 64, 128, 3, 2, 1),       # class walk over many tiles: workgroup ranges start mid-group
+    (2, 48, 48, 128, 256, 3, 2, 1),      # two column tiles per class
     (3, 40, 40, 256, 512, 1, 1, 0),
     (2, 16, 32, 64, 64, 3, 1, 1),        # qualifies for the filter-resident 3x3 kernel (bf16): C=64, H%8==0, W%16==0
     (3, 32, 48, 64, 32, 3, 1, 1),
