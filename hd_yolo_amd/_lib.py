@@ -38,6 +38,14 @@ SIGNATURES = {
     'hdy_conv1x1_bwd_fused_grid': (_I, [_L, _I]),
     'hdy_conv1x1_bwd_fused_workspace_bytes': (_Z, [_L, _I, _I]),
     'hdy_conv1x1_bwd_fused': (_I, [_P, _I, _P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P, _I, _P, _I, _I, _L, _I, _I, _P, _Z, _I, _P]),
+    'hdy_groupnorm_workspace_floats': (_Z, [_I, _I]),
+    'hdy_groupnorm_fwd': (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _F, _I, _I, _P, _P]),
+    'hdy_groupnorm_bwd': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    'hdy_bilinear_fwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'hdy_bilinear_bwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'hdy_softdice_workspace_floats': (_Z, [_I, _I]),
+    'hdy_softdice': (_I, [_P, _I, _P, _P, _I, _I, _I, _P, _P, _P, _I, _P, _P]),
+    'hdy_softmax2d': (_I, [_P, _I, _P, _I, _L, _I, _P]),
     'hdy_bn_finalize_workspace_bytes': (_Z, [_I, _I]),
     'hdy_bn_finalize': (_I, [_P, _I, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P]),
     'hdy_bn_eval_coeffs': (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),

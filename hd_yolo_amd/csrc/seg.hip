@@ -1,0 +1,626 @@
+// Semantic-segmentation branch primitives for gfx950 (hnet's PanopticSeg over the detector's pyramid):
+//   * GroupNorm(G) + ReLU forward / backward on NHWC tensors            (hnet/segmentation/utils_seg.py:21-36: Conv3x3 -> GroupNorm(32) -> ReLU)
+//   * bilinear resize with align_corners=True, any size, forward (optionally accumulating into the output: the branch sum
+//     `sum(res)`, utils_seg.py:58) and backward in gather form (no atomics)   (utils_seg.py:27,35; panoptic_seg.py:18,38)
+//   * Softmax2d + soft-dice loss forward / backward on fp32 logits        (panoptic_seg.py:15,22,40)
+// All are HBM-bound streaming kernels: one 16-byte vector (8 bf16 / 4 f32 channels) per lane per access, fp32 math; per-image
+// GroupNorm statistics go through [image][slice] fp32 partial slabs reduced in a fixed order (deterministic, no atomics).
+#include "common.h"
+#include "hdyolo.h"
+
+namespace {
+
+template <typename T> struct VT;
+template <> struct VT<float> { static constexpr int VE = 4; };
+template <> struct VT<bf16_t> { static constexpr int VE = 8; };
+
+template <typename T> __device__ __forceinline__ void unpack(const i32x4& v, float* f);
+template <> __device__ __forceinline__ void unpack<float>(const i32x4& v, float* f) {
+    V16 u; u.i = v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = u.f[i];
+}
+template <> __device__ __forceinline__ void unpack<bf16_t>(const i32x4& v, float* f) {
+    V16 u; u.i = v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (float)u.h[i];
+}
+template <typename T> __device__ __forceinline__ i32x4 pack(const float* f);
+template <> __device__ __forceinline__ i32x4 pack<float>(const float* f) {
+    V16 u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) u.f[i] = f[i];
+    return u.i;
+}
+template <> __device__ __forceinline__ i32x4 pack<bf16_t>(const float* f) {
+    V16 u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) u.h[i] = (bf16_t)f[i];
+    return u.i;
+}
+
+constexpr int GN_SLICES = 32;       // pixel slices per image in the statistics passes (grid = N x GN_SLICES)
+
+// ---------------------------------------------------------------- GroupNorm statistics
+// partial[n][s][2][C]: per-channel (sum, sum of squares) of x — or, BWD, (sum dy, sum dy*xhat) with dy = dout * relu'(x*a+b) —
+// over slice s of image n.  A thread owns one channel vector; 256/VC row lanes walk the slice's pixels.
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void gn_reduce_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dout, int lddo,
+                                                        const float* __restrict__ ab, const float* __restrict__ stat, int HW, int C, int G,
+                                                        int relu, float* __restrict__ partial) {
+    constexpr int VE = VT<T>::VE;
+    __shared__ float red[2][256 * VE];
+    const int n = blockIdx.x, s = blockIdx.y;
+    const int VCt = C / VE;
+    const int per = (HW + GN_SLICES - 1) / GN_SLICES;
+    const int p0 = s * per, p1 = min(p0 + per, HW);
+    for (int chunk = 0; chunk * 256 < VCt; ++chunk) {
+        const int VC = min(256, VCt - chunk * 256), RL = 256 / VC;
+        const int vc = chunk * 256 + (int)(threadIdx.x % (unsigned)VC), rl = (int)(threadIdx.x / (unsigned)VC);
+        const bool live = rl < RL;
+        const int c = vc * VE;
+        float a1[VE], a2[VE], ca[VE], cb[VE], mu[VE], rs[VE];
+#pragma unroll
+        for (int i = 0; i < VE; ++i) {
+            a1[i] = 0.f;
+            a2[i] = 0.f;
+            ca[i] = 0.f;
+            cb[i] = 0.f;
+            mu[i] = 0.f;
+            rs[i] = 0.f;
+        }
+        if constexpr (BWD) {
+            if (live) {
+#pragma unroll
+                for (int i = 0; i < VE; ++i) {
+                    const int g = (c + i) / (C / G);
+                    ca[i] = ab[((size_t)n * 2 + 0) * C + c + i];
+                    cb[i] = ab[((size_t)n * 2 + 1) * C + c + i];
+                    mu[i] = stat[((size_t)n * G + g) * 2 + 0];
+                    rs[i] = stat[((size_t)n * G + g) * 2 + 1];
+                }
+            }
+        }
+        if (live) {
+            for (int p = p0 + rl; p < p1; p += RL) {
+                const size_t m = (size_t)n * HW + p;
+                float v[VE], d[VE];
+                unpack<T>(*(const i32x4*)(x + m * ldx + c), v);
+                if (BWD) unpack<T>(*(const i32x4*)(dout + m * lddo + c), d);
+#pragma unroll
+                for (int i = 0; i < VE; ++i) {
+                    if (BWD) {
+                        const float u = v[i] * ca[i] + cb[i];
+                        const float dy = (relu != 0 && u <= 0.f) ? 0.f : d[i];
+                        a1[i] += dy;
+                        a2[i] += dy * ((v[i] - mu[i]) * rs[i]);
+                    } else {
+                        a1[i] += v[i];
+                        a2[i] = __builtin_fmaf(v[i], v[i], a2[i]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < VE; ++i) {
+                red[0][(rl * VC + (vc - chunk * 256)) * VE + i] = a1[i];
+                red[1][(rl * VC + (vc - chunk * 256)) * VE + i] = a2[i];
+            }
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < VC * VE; j += 256) {
+            float s1 = 0.f, s2 = 0.f;
+            for (int r = 0; r < RL; ++r) {
+                s1 += red[0][r * VC * VE + j];
+                s2 += red[1][r * VC * VE + j];
+            }
+            const size_t o = ((size_t)n * GN_SLICES + s) * 2 * C + chunk * 256 * VE + j;
+            partial[o] = s1;
+            partial[o + C] = s2;
+        }
+        __syncthreads();
+    }
+}
+
+// forward finalize: one block per image.  stat[n][g] = (mean, rstd); ab[n][0][c] = gamma*rstd, ab[n][1][c] = beta - mean*gamma*rstd
+__global__ __launch_bounds__(256) void gn_fwd_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, int HW, int C, int G, float eps,
+                                                              float* __restrict__ stat, float* __restrict__ ab) {
+    extern __shared__ double sh[];          // [2][C]
+    const int n = blockIdx.x, cpg = C / G;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int s = 0; s < GN_SLICES; ++s) {
+            const size_t o = ((size_t)n * GN_SLICES + s) * 2 * C + c;
+            s1 += (double)partial[o];
+            s2 += (double)partial[o + C];
+        }
+        sh[c] = s1;
+        sh[C + c] = s2;
+    }
+    __syncthreads();
+    for (int g = threadIdx.x; g < G; g += 256) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int i = 0; i < cpg; ++i) { s1 += sh[g * cpg + i]; s2 += sh[C + g * cpg + i]; }
+        const double cnt = (double)HW * cpg;
+        const double mean = s1 / cnt;
+        double var = s2 / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stat[((size_t)n * G + g) * 2 + 0] = (float)mean;
+        stat[((size_t)n * G + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const int g = c / cpg;
+        const float mean = stat[((size_t)n * G + g) * 2 + 0], rstd = stat[((size_t)n * G + g) * 2 + 1];
+        const float a = gamma[c] * rstd;
+        ab[((size_t)n * 2 + 0) * C + c] = a;
+        ab[((size_t)n * 2 + 1) * C + c] = beta[c] - mean * a;
+    }
+}
+
+// backward finalize, one block per image: coef[n][0][c] = rstd*gamma, coef[n][1][c] = rstd*s1/m, coef[n][2][c] = rstd*s2/m with the
+// group sums s1 = SUM_c gamma*A, s2 = SUM_c gamma*B; pc[n][2][C] = (A, B) per channel for the parameter gradients
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ gamma,
+                                                              const float* __restrict__ stat, int HW, int C, int G,
+                                                              float* __restrict__ coef, float* __restrict__ pc) {
+    extern __shared__ double sh[];          // [2][C]
+    const int n = blockIdx.x, cpg = C / G;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int s = 0; s < GN_SLICES; ++s) {
+            const size_t o = ((size_t)n * GN_SLICES + s) * 2 * C + c;
+            s1 += (double)partial[o];
+            s2 += (double)partial[o + C];
+        }
+        sh[c] = s1;
+        sh[C + c] = s2;
+        pc[((size_t)n * 2 + 0) * C + c] = (float)s1;
+        pc[((size_t)n * 2 + 1) * C + c] = (float)s2;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const int g = c / cpg;
+        double s1 = 0.0, s2 = 0.0;
+        for (int i = 0; i < cpg; ++i) {
+            s1 += (double)gamma[g * cpg + i] * sh[g * cpg + i];
+            s2 += (double)gamma[g * cpg + i] * sh[C + g * cpg + i];
+        }
+        const double m = (double)HW * cpg;
+        const float rstd = stat[((size_t)n * G + g) * 2 + 1];
+        coef[((size_t)n * 3 + 0) * C + c] = rstd * gamma[c];
+        coef[((size_t)n * 3 + 1) * C + c] = (float)((double)rstd * s1 / m);
+        coef[((size_t)n * 3 + 2) * C + c] = (float)((double)rstd * s2 / m);
+    }
+}
+
+// dgamma[c] (+)= SUM_n B[n][c], dbeta[c] (+)= SUM_n A[n][c]
+__global__ void gn_param_grad_kernel(const float* __restrict__ pc, int N, int C, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                     int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0, b = 0.0;
+    for (int n = 0; n < N; ++n) {
+        a += (double)pc[((size_t)n * 2 + 0) * C + c];
+        b += (double)pc[((size_t)n * 2 + 1) * C + c];
+    }
+    dbeta[c] = accumulate ? dbeta[c] + (float)a : (float)a;
+    dgamma[c] = accumulate ? dgamma[c] + (float)b : (float)b;
+}
+
+// forward: y = relu(x*a + b);  backward: dx = k0*dy - k1 - xhat*k2 with dy = dout * relu'(x*a+b)
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dout, int lddo,
+                                                       const float* __restrict__ ab, const float* __restrict__ stat,
+                                                       const float* __restrict__ coef, T* __restrict__ y, int ldy, int HW, int C, int G, int relu) {
+    constexpr int VE = VT<T>::VE;
+    const int n = blockIdx.y;
+    const int VCt = C / VE;
+    for (int chunk = 0; chunk * 256 < VCt; ++chunk) {
+        const int VC = min(256, VCt - chunk * 256), RL = 256 / VC;
+        const int vc = chunk * 256 + (int)(threadIdx.x % (unsigned)VC), rl = (int)(threadIdx.x / (unsigned)VC);
+        if (rl >= RL) continue;
+        const int c = vc * VE;
+        float ca[VE], cb[VE], mu[VE], rs[VE], k0[VE], k1[VE], k2[VE];
+#pragma unroll
+        for (int i = 0; i < VE; ++i) {
+            ca[i] = ab[((size_t)n * 2 + 0) * C + c + i];
+            cb[i] = ab[((size_t)n * 2 + 1) * C + c + i];
+            mu[i] = 0.f;
+            rs[i] = 0.f;
+            k0[i] = 0.f;
+            k1[i] = 0.f;
+            k2[i] = 0.f;
+        }
+        if constexpr (BWD) {
+#pragma unroll
+            for (int i = 0; i < VE; ++i) {
+                const int g = (c + i) / (C / G);
+                mu[i] = stat[((size_t)n * G + g) * 2 + 0];
+                rs[i] = stat[((size_t)n * G + g) * 2 + 1];
+                k0[i] = coef[((size_t)n * 3 + 0) * C + c + i];
+                k1[i] = coef[((size_t)n * 3 + 1) * C + c + i];
+                k2[i] = coef[((size_t)n * 3 + 2) * C + c + i];
+            }
+        }
+        for (int p = blockIdx.x * RL + rl; p < HW; p += gridDim.x * RL) {
+            const size_t m = (size_t)n * HW + p;
+            float v[VE], d[VE];
+            unpack<T>(*(const i32x4*)(x + m * ldx + c), v);
+            if (BWD) unpack<T>(*(const i32x4*)(dout + m * lddo + c), d);
+#pragma unroll
+            for (int i = 0; i < VE; ++i) {
+                const float u = v[i] * ca[i] + cb[i];
+                if (BWD) {
+                    const float dy = (relu && u <= 0.f) ? 0.f : d[i];
+                    v[i] = k0[i] * dy - k1[i] - ((v[i] - mu[i]) * rs[i]) * k2[i];
+                } else {
+                    v[i] = relu ? fmaxf(u, 0.f) : u;
+                }
+            }
+            *(i32x4*)(y + m * ldy + c) = pack<T>(v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- bilinear resize, align_corners = True
+// aten upsample_bilinear2d: scale = (in-1)/(out-1) (0 when out == 1); src = scale*dst; i0 = (int)src; i1 = i0 + (i0 < in-1); l1 = src - i0
+__device__ __forceinline__ void src_index(int dst, float scale, int in, int* i0, int* i1, float* l0, float* l1) {
+    const float s = scale * (float)dst;
+    int a = (int)s;
+    if (a > in - 1) a = in - 1;
+    *i0 = a;
+    *i1 = a + (a < in - 1 ? 1 : 0);
+    *l1 = s - (float)a;
+    *l0 = 1.0f - *l1;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int N, int Hi, int Wi,
+                                                           int Ho, int Wo, int C, float sh, float sw, int accumulate) {
+    constexpr int VE = VT<T>::VE;
+    const int VC = C / VE;
+    const long long total = (long long)N * Ho * Wo * VC;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int vc = (int)(idx % VC);
+        long long pix = idx / VC;
+        const int ox = (int)(pix % Wo);
+        pix /= Wo;
+        const int oy = (int)(pix % Ho), n = (int)(pix / Ho);
+        int y0, y1, x0, x1;
+        float ly0, ly1, lx0, lx1;
+        src_index(oy, sh, Hi, &y0, &y1, &ly0, &ly1);
+        src_index(ox, sw, Wi, &x0, &x1, &lx0, &lx1);
+        const T* base = x + (size_t)n * Hi * Wi * ldx + vc * VE;
+        float a[VE], b[VE], c[VE], d[VE], o[VE];
+        unpack<T>(*(const i32x4*)(base + ((size_t)y0 * Wi + x0) * ldx), a);
+        unpack<T>(*(const i32x4*)(base + ((size_t)y0 * Wi + x1) * ldx), b);
+        unpack<T>(*(const i32x4*)(base + ((size_t)y1 * Wi + x0) * ldx), c);
+        unpack<T>(*(const i32x4*)(base + ((size_t)y1 * Wi + x1) * ldx), d);
+        T* dst = y + (((size_t)n * Ho + oy) * Wo + ox) * ldy + vc * VE;
+        if (accumulate) unpack<T>(*(const i32x4*)dst, o);
+#pragma unroll
+        for (int i = 0; i < VE; ++i) {
+            const float v = ly0 * (lx0 * a[i] + lx1 * b[i]) + ly1 * (lx0 * c[i] + lx1 * d[i]);
+            o[i] = accumulate ? o[i] + v : v;
+        }
+        *(i32x4*)dst = pack<T>(o);
+    }
+}
+
+// gather form: input pixel (iy, ix) collects from every output whose i0 or i1 is it.  Candidates: src in (i-1, i+1).
+__device__ __forceinline__ void dst_range(int i, float scale, int out, int* lo, int* hi) {
+    if (scale <= 0.f) { *lo = 0; *hi = out - 1; return; }
+    int a = (int)floorf(((float)i - 1.0f) / scale) - 1, b = (int)ceilf(((float)i + 1.0f) / scale) + 1;
+    *lo = a < 0 ? 0 : a;
+    *hi = b > out - 1 ? out - 1 : b;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const T* __restrict__ dy, int lddy, T* __restrict__ dx, int lddx, int N, int Hi, int Wi,
+                                                           int Ho, int Wo, int C, float sh, float sw, int accumulate) {
+    constexpr int VE = VT<T>::VE;
+    const int VC = C / VE;
+    const long long total = (long long)N * Hi * Wi * VC;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int vc = (int)(idx % VC);
+        long long pix = idx / VC;
+        const int ix = (int)(pix % Wi);
+        pix /= Wi;
+        const int iy = (int)(pix % Hi), n = (int)(pix / Hi);
+        int ylo, yhi, xlo, xhi;
+        dst_range(iy, sh, Ho, &ylo, &yhi);
+        dst_range(ix, sw, Wo, &xlo, &xhi);
+        float acc[VE];
+#pragma unroll
+        for (int i = 0; i < VE; ++i) acc[i] = 0.f;
+        const T* base = dy + (size_t)n * Ho * Wo * lddy + vc * VE;
+        for (int oy = ylo; oy <= yhi; ++oy) {
+            int y0, y1;
+            float ly0, ly1;
+            src_index(oy, sh, Hi, &y0, &y1, &ly0, &ly1);
+            const float wy = (y0 == iy ? ly0 : 0.f) + (y1 == iy ? ly1 : 0.f);
+            if (wy == 0.f) continue;
+            for (int ox = xlo; ox <= xhi; ++ox) {
+                int x0, x1;
+                float lx0, lx1;
+                src_index(ox, sw, Wi, &x0, &x1, &lx0, &lx1);
+                const float wx = (x0 == ix ? lx0 : 0.f) + (x1 == ix ? lx1 : 0.f);
+                if (wx == 0.f) continue;
+                float g[VE];
+                unpack<T>(*(const i32x4*)(base + ((size_t)oy * Wo + ox) * lddy), g);
+#pragma unroll
+                for (int i = 0; i < VE; ++i) acc[i] += wy * wx * g[i];
+            }
+        }
+        T* dst = dx + (((size_t)n * Hi + iy) * Wi + ix) * lddx + vc * VE;
+        if (accumulate) {
+            float o[VE];
+            unpack<T>(*(const i32x4*)dst, o);
+#pragma unroll
+            for (int i = 0; i < VE; ++i) acc[i] += o[i];
+        }
+        *(i32x4*)dst = pack<T>(acc);
+    }
+}
+
+// ---------------------------------------------------------------- Softmax2d + soft dice
+// logits fp32 [N][H][W][ldl] (nc classes), targets fp32 [N][nc][H][W] (the reference stacks per-roi masks: panoptic_seg.py:36).
+// pass 1: per (n, slice): prod[c] = SUM t*p, plus[c] = SUM (t + p)  -> partial[n][s][2][nc]
+constexpr int DICE_SLICES = 64, DICE_MAXC = 32;
+__global__ __launch_bounds__(256) void dice_reduce_kernel(const float* __restrict__ logits, int ldl, const float* __restrict__ tgt, int HW, int nc,
+                                                          float* __restrict__ partial) {
+    __shared__ float red[2][DICE_MAXC][256 / 64];
+    const int n = blockIdx.x, s = blockIdx.y;
+    const int per = (HW + DICE_SLICES - 1) / DICE_SLICES;
+    const int p0 = s * per, p1 = min(p0 + per, HW);
+    float prod[DICE_MAXC], plus[DICE_MAXC];
+#pragma unroll
+    for (int c = 0; c < DICE_MAXC; ++c) prod[c] = plus[c] = 0.f;
+    for (int p = p0 + threadIdx.x; p < p1; p += 256) {
+        const float* l = logits + ((size_t)n * HW + p) * ldl;
+        float mx = l[0];
+        for (int c = 1; c < nc; ++c) mx = fmaxf(mx, l[c]);
+        float e[DICE_MAXC], sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < DICE_MAXC; ++c) {
+            e[c] = c < nc ? expf(l[c] - mx) : 0.f;
+            sum += e[c];
+        }
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int c = 0; c < DICE_MAXC; ++c) {
+            if (c < nc) {
+                const float pr = e[c] * inv, t = tgt[((size_t)n * nc + c) * HW + p];
+                prod[c] += t * pr;
+                plus[c] += t + pr;
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < DICE_MAXC; ++c) {
+        if (c < nc) {
+            float a = prod[c], b = plus[c];
+            for (int m = 32; m >= 1; m >>= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
+            if (lane == 0) { red[0][c][wave] = a; red[1][c][wave] = b; }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < nc) {
+        float a = 0.f, b = 0.f;
+        for (int w = 0; w < 4; ++w) { a += red[0][threadIdx.x][w]; b += red[1][threadIdx.x][w]; }
+        const size_t o = ((size_t)n * DICE_SLICES + s) * 2 * nc + threadIdx.x;
+        partial[o] = a;
+        partial[o + nc] = b;
+    }
+}
+
+// one block: dice[n][c] = 2*prod/plus; loss = 1 - SUM_c w_c * mean_n dice[n][c] / SUM_c w_c.  Also leaves, for the backward,
+// coefA[n][c] = -w_c/(N*W) * 2/plus and coefB[n][c] = -w_c/(N*W) * (-2*prod/plus^2)   (d loss / d p = coefA*t + coefB per pixel of class c)
+__global__ __launch_bounds__(256) void dice_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ cw, int N, int nc,
+                                                            float* __restrict__ loss, float* __restrict__ coef) {
+    __shared__ double acc[256];
+    double wsum = 0.0;
+    for (int c = 0; c < nc; ++c) wsum += cw ? (double)cw[c] : 1.0;
+    double local = 0.0;
+    for (int i = threadIdx.x; i < N * nc; i += 256) {
+        const int n = i / nc, c = i - n * nc;
+        double prod = 0.0, plus = 0.0;
+        for (int s = 0; s < DICE_SLICES; ++s) {
+            const size_t o = ((size_t)n * DICE_SLICES + s) * 2 * nc + c;
+            prod += (double)partial[o];
+            plus += (double)partial[o + nc];
+        }
+        const double w = (cw ? (double)cw[c] : 1.0) / (wsum * N);
+        local += w * 2.0 * prod / plus;
+        coef[((size_t)n * 2 + 0) * nc + c] = (float)(-w * 2.0 / plus);
+        coef[((size_t)n * 2 + 1) * nc + c] = (float)(w * 2.0 * prod / (plus * plus));
+    }
+    acc[threadIdx.x] = local;
+    __syncthreads();
+    for (int m = 128; m >= 1; m >>= 1) {
+        if (threadIdx.x < m) acc[threadIdx.x] += acc[threadIdx.x + m];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = (float)(1.0 - acc[0]);
+}
+
+// dlogits[n][p][c] = upstream * p_c * (q_c - SUM_j q_j p_j),  q_c = coefA[n][c]*t_c + coefB[n][c]
+__global__ __launch_bounds__(256) void dice_bwd_kernel(const float* __restrict__ logits, int ldl, const float* __restrict__ tgt,
+                                                       const float* __restrict__ coef, const float* __restrict__ upstream, int N, int HW, int nc,
+                                                       float* __restrict__ dlogits, int lddl) {
+    const float up = upstream ? upstream[0] : 1.0f;
+    const long long total = (long long)N * HW;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int n = (int)(idx / HW), p = (int)(idx - (long long)n * HW);
+        const float* l = logits + (size_t)idx * ldl;
+        float mx = l[0];
+        for (int c = 1; c < nc; ++c) mx = fmaxf(mx, l[c]);
+        float e[DICE_MAXC], q[DICE_MAXC], sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < DICE_MAXC; ++c) {
+            e[c] = c < nc ? expf(l[c] - mx) : 0.f;
+            sum += e[c];
+        }
+        const float inv = 1.0f / sum;
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < DICE_MAXC; ++c) {
+            if (c < nc) {
+                e[c] *= inv;
+                q[c] = coef[((size_t)n * 2 + 0) * nc + c] * tgt[((size_t)n * nc + c) * HW + p] + coef[((size_t)n * 2 + 1) * nc + c];
+                dot += q[c] * e[c];
+            }
+        }
+        float* d = dlogits + (size_t)idx * lddl;
+#pragma unroll
+        for (int c = 0; c < DICE_MAXC; ++c)
+            if (c < nc) d[c] = up * e[c] * (q[c] - dot);
+    }
+}
+
+// probabilities for inference: p = softmax over the nc channels, fp32 [N][HW][ldp]
+__global__ __launch_bounds__(256) void softmax2d_kernel(const float* __restrict__ logits, int ldl, float* __restrict__ probs, int ldp, long long M, int nc) {
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < M; idx += (long long)gridDim.x * 256) {
+        const float* l = logits + (size_t)idx * ldl;
+        float mx = l[0];
+        for (int c = 1; c < nc; ++c) mx = fmaxf(mx, l[c]);
+        float sum = 0.f;
+        for (int c = 0; c < nc; ++c) sum += expf(l[c] - mx);
+        const float inv = 1.0f / sum;
+        for (int c = 0; c < nc; ++c) probs[(size_t)idx * ldp + c] = expf(l[c] - mx) * inv;
+    }
+}
+
+inline int grid_for(long long items) {
+    long long g = (items + 255) / 256;
+    if (g > 256 * 16) g = 256 * 16;
+    return (int)(g < 1 ? 1 : g);
+}
+
+}  // namespace
+
+#define VEC_OK(ptr, ld, VE) ((((uintptr_t)(ptr)) & 15) == 0 && (ld) % (VE) == 0)
+
+extern "C" {
+
+// floats: partial [N][GN_SLICES][2][C] + pc [N][2][C] (backward)
+size_t hdy_groupnorm_workspace_floats(int N, int C) { return (size_t)N * GN_SLICES * 2 * C + (size_t)N * 2 * C; }
+
+// y = relu?(GroupNorm_G(x) * gamma + beta) per image; saves stat [N][G][2] = (mean, rstd) and ab [N][2][C] for the backward.
+int hdy_groupnorm_fwd(const void* x, int ldx, const float* gamma, const float* beta, void* y, int ldy, float* stat, float* ab, int N, int HW,
+                      int C, int G, float eps, int relu, int dtype, float* workspace, void* stream) {
+    const int VE = dtype == HDY_BF16 ? 8 : 4;
+    HDY_ARG(x && gamma && beta && y && stat && ab && workspace && N > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0, "groupnorm_fwd: bad args");
+    HDY_ARG(C % VE == 0 && VEC_OK(x, ldx, VE) && VEC_OK(y, ldy, VE) && C <= 4096, "groupnorm_fwd: C/pitch/alignment must be multiples of one 16-byte vector");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 rg(N, GN_SLICES);
+    if (dtype == HDY_BF16)
+        hipLaunchKernelGGL((gn_reduce_kernel<bf16_t, false>), rg, dim3(256), 0, st, (const bf16_t*)x, ldx, (const bf16_t*)nullptr, 0, (const float*)nullptr, (const float*)nullptr, HW, C, G, relu, workspace);
+    else
+        hipLaunchKernelGGL((gn_reduce_kernel<float, false>), rg, dim3(256), 0, st, (const float*)x, ldx, (const float*)nullptr, 0, (const float*)nullptr, (const float*)nullptr, HW, C, G, relu, workspace);
+    HDY_LAUNCH_CHECK("gn_reduce");
+    hipLaunchKernelGGL(gn_fwd_finalize_kernel, dim3(N), dim3(256), 2 * C * sizeof(double), st, workspace, gamma, beta, HW, C, G, eps, stat, ab);
+    HDY_LAUNCH_CHECK("gn_fwd_finalize");
+    const int rl = 256 / ((C / VE) < 256 ? (C / VE) : 256);
+    int gx = (HW + rl - 1) / rl;
+    if (gx > 2048 / (N < 2048 ? N : 2048) + 1) gx = 2048 / (N < 2048 ? N : 2048) + 1;
+    dim3 ag(gx, N);
+    if (dtype == HDY_BF16)
+        hipLaunchKernelGGL((gn_apply_kernel<bf16_t, false>), ag, dim3(256), 0, st, (const bf16_t*)x, ldx, (const bf16_t*)nullptr, 0, ab, stat, (const float*)nullptr, (bf16_t*)y, ldy, HW, C, G, relu);
+    else
+        hipLaunchKernelGGL((gn_apply_kernel<float, false>), ag, dim3(256), 0, st, (const float*)x, ldx, (const float*)nullptr, 0, ab, stat, (const float*)nullptr, (float*)y, ldy, HW, C, G, relu);
+    HDY_LAUNCH_CHECK("gn_apply");
+    return HDY_OK;
+}
+
+// dx, dgamma / dbeta (+)= from dout (gradient of the ReLU output), the raw input x and the saved stat / ab of the forward call.
+// coef: [N][3][C] floats of scratch.
+int hdy_groupnorm_bwd(const void* dout, int lddo, const void* x, int ldx, const float* gamma, const float* stat, const float* ab, void* dx, int lddx,
+                      float* dgamma, float* dbeta, int accumulate, float* coef, int N, int HW, int C, int G, int relu, int dtype, float* workspace,
+                      void* stream) {
+    const int VE = dtype == HDY_BF16 ? 8 : 4;
+    HDY_ARG(dout && x && gamma && stat && ab && dx && dgamma && dbeta && coef && workspace && N > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0, "groupnorm_bwd: bad args");
+    HDY_ARG(C % VE == 0 && VEC_OK(x, ldx, VE) && VEC_OK(dout, lddo, VE) && VEC_OK(dx, lddx, VE) && C <= 4096, "groupnorm_bwd: C/pitch/alignment must be multiples of one 16-byte vector");
+    hipStream_t st = (hipStream_t)stream;
+    float* pc = workspace + (size_t)N * GN_SLICES * 2 * C;
+    dim3 rg(N, GN_SLICES);
+    if (dtype == HDY_BF16)
+        hipLaunchKernelGGL((gn_reduce_kernel<bf16_t, true>), rg, dim3(256), 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dout, lddo, ab, stat, HW, C, G, relu, workspace);
+    else
+        hipLaunchKernelGGL((gn_reduce_kernel<float, true>), rg, dim3(256), 0, st, (const float*)x, ldx, (const float*)dout, lddo, ab, stat, HW, C, G, relu, workspace);
+    HDY_LAUNCH_CHECK("gn_bwd_reduce");
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(N), dim3(256), 2 * C * sizeof(double), st, workspace, gamma, stat, HW, C, G, coef, pc);
+    HDY_LAUNCH_CHECK("gn_bwd_finalize");
+    hipLaunchKernelGGL(gn_param_grad_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, pc, N, C, dgamma, dbeta, accumulate);
+    HDY_LAUNCH_CHECK("gn_param_grad");
+    const int rl = 256 / ((C / VE) < 256 ? (C / VE) : 256);
+    int gx = (HW + rl - 1) / rl;
+    if (gx > 2048 / (N < 2048 ? N : 2048) + 1) gx = 2048 / (N < 2048 ? N : 2048) + 1;
+    dim3 ag(gx, N);
+    if (dtype == HDY_BF16)
+        hipLaunchKernelGGL((gn_apply_kernel<bf16_t, true>), ag, dim3(256), 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dout, lddo, ab, stat, coef, (bf16_t*)dx, lddx, HW, C, G, relu);
+    else
+        hipLaunchKernelGGL((gn_apply_kernel<float, true>), ag, dim3(256), 0, st, (const float*)x, ldx, (const float*)dout, lddo, ab, stat, coef, (float*)dx, lddx, HW, C, G, relu);
+    HDY_LAUNCH_CHECK("gn_bwd_apply");
+    return HDY_OK;
+}
+
+static inline float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.0f; }
+
+// y[N][Ho][Wo][C] (+)= bilinear(x[N][Hi][Wi][C]), align_corners = True
+int hdy_bilinear_fwd(const void* x, int ldx, void* y, int ldy, int N, int Hi, int Wi, int Ho, int Wo, int C, int accumulate, int dtype, void* stream) {
+    const int VE = dtype == HDY_BF16 ? 8 : 4;
+    HDY_ARG(x && y && N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0 && C % VE == 0 && VEC_OK(x, ldx, VE) && VEC_OK(y, ldy, VE), "bilinear_fwd: bad args");
+    const long long items = (long long)N * Ho * Wo * (C / VE);
+    if (dtype == HDY_BF16)
+        hipLaunchKernelGGL(bilinear_fwd_kernel<bf16_t>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, N, Hi, Wi, Ho, Wo, C, ac_scale(Hi, Ho), ac_scale(Wi, Wo), accumulate);
+    else
+        hipLaunchKernelGGL(bilinear_fwd_kernel<float>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, (float*)y, ldy, N, Hi, Wi, Ho, Wo, C, ac_scale(Hi, Ho), ac_scale(Wi, Wo), accumulate);
+    HDY_LAUNCH_CHECK("bilinear_fwd");
+    return HDY_OK;
+}
+
+// dx[N][Hi][Wi][C] (+)= bilinear^T(dy[N][Ho][Wo][C])
+int hdy_bilinear_bwd(const void* dy, int lddy, void* dx, int lddx, int N, int Hi, int Wi, int Ho, int Wo, int C, int accumulate, int dtype, void* stream) {
+    const int VE = dtype == HDY_BF16 ? 8 : 4;
+    HDY_ARG(dy && dx && N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0 && C % VE == 0 && VEC_OK(dy, lddy, VE) && VEC_OK(dx, lddx, VE), "bilinear_bwd: bad args");
+    const long long items = (long long)N * Hi * Wi * (C / VE);
+    if (dtype == HDY_BF16)
+        hipLaunchKernelGGL(bilinear_bwd_kernel<bf16_t>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, N, Hi, Wi, Ho, Wo, C, ac_scale(Hi, Ho), ac_scale(Wi, Wo), accumulate);
+    else
+        hipLaunchKernelGGL(bilinear_bwd_kernel<float>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, (const float*)dy, lddy, (float*)dx, lddx, N, Hi, Wi, Ho, Wo, C, ac_scale(Hi, Ho), ac_scale(Wi, Wo), accumulate);
+    HDY_LAUNCH_CHECK("bilinear_bwd");
+    return HDY_OK;
+}
+
+// floats: partial [N][DICE_SLICES][2][nc] + coef [N][2][nc]
+size_t hdy_softdice_workspace_floats(int N, int nc) { return (size_t)N * DICE_SLICES * 2 * nc + (size_t)N * 2 * nc; }
+
+// loss[0] = 1 - SUM_c w_c * mean_n dice(softmax(logits)[n][c], targets[n][c]) / SUM_c w_c, dice = 2*SUM(t*p) / SUM(t + p);
+// when dlogits != NULL also the gradient of loss * upstream[0] (upstream == NULL: 1).
+int hdy_softdice(const float* logits, int ldl, const float* targets, const float* class_weight, int N, int HW, int nc, float* loss,
+                 const float* upstream, float* dlogits, int lddl, float* workspace, void* stream) {
+    HDY_ARG(logits && targets && loss && workspace && N > 0 && HW > 0 && nc > 0 && nc <= DICE_MAXC && ldl >= nc && N * nc <= 65536, "softdice: bad args (nc <= %d)", DICE_MAXC);
+    hipStream_t st = (hipStream_t)stream;
+    float* coef = workspace + (size_t)N * DICE_SLICES * 2 * nc;
+    hipLaunchKernelGGL(dice_reduce_kernel, dim3(N, DICE_SLICES), dim3(256), 0, st, logits, ldl, targets, HW, nc, workspace);
+    HDY_LAUNCH_CHECK("dice_reduce");
+    hipLaunchKernelGGL(dice_finalize_kernel, dim3(1), dim3(256), 0, st, workspace, class_weight, N, nc, loss, coef);
+    HDY_LAUNCH_CHECK("dice_finalize");
+    if (dlogits) {
+        HDY_ARG(lddl >= nc, "softdice: dlogits pitch");
+        hipLaunchKernelGGL(dice_bwd_kernel, dim3(grid_for((long long)N * HW)), dim3(256), 0, st, logits, ldl, targets, coef, upstream, N, HW, nc, dlogits, lddl);
+        HDY_LAUNCH_CHECK("dice_bwd");
+    }
+    return HDY_OK;
+}
+
+int hdy_softmax2d(const float* logits, int ldl, float* probs, int ldp, long long M, int nc, void* stream) {
+    HDY_ARG(logits && probs && M > 0 && nc > 0 && ldl >= nc && ldp >= nc, "softmax2d: bad args");
+    hipLaunchKernelGGL(softmax2d_kernel, dim3(grid_for(M)), dim3(256), 0, (hipStream_t)stream, logits, ldl, probs, ldp, M, nc);
+    HDY_LAUNCH_CHECK("softmax2d");
+    return HDY_OK;
+}
+
+}  // extern "C"

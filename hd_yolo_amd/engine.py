@@ -136,6 +136,39 @@ class MaskBranchFn(torch.autograd.Function):
         return torch.zeros(1, device=dlogits.device), None, None, None, None, None, None
 
 
+class _PlanTapFn(torch.autograd.Function):
+    """_PlanFn for a plan with tapped layers: also returns the tapped feature maps, so that outside modules (hnet's segmentation
+    header) hang off them in autograd and their gradients come back here before the backward launch list runs."""
+
+    @staticmethod
+    def forward(ctx, engine, plan, hook, images):
+        ctx.engine, ctx.plan = engine, plan
+        dets = tuple(plan.run_forward(images))
+        ctx.ndet = len(dets)
+        return dets + tuple(plan.tap_features())
+
+    @staticmethod
+    def backward(ctx, *grads):
+        ctx.plan.run_backward(grads[:ctx.ndet], gtaps=grads[ctx.ndet:])
+        ctx.engine.after_backward()
+        return None, None, None, None
+
+
+class _FusedLossTapFn(torch.autograd.Function):
+    """_FusedLossFn for a plan with tapped layers (see _PlanTapFn)."""
+
+    @staticmethod
+    def forward(ctx, engine, plan, hook, loss_view):
+        ctx.engine, ctx.plan = engine, plan
+        return (loss_view.clone(),) + tuple(plan.tap_features())
+
+    @staticmethod
+    def backward(ctx, g, *gtaps):
+        ctx.plan.run_backward(None, scale=g if g is not None else torch.zeros(1, device=gtaps[0].device), gtaps=gtaps)
+        ctx.engine.after_backward()
+        return None, None, None, None
+
+
 class _FusedLossFn(torch.autograd.Function):
     """loss = hdy_det_loss(plan logits, targets); its backward replays the plan's backward launch list."""
 
@@ -154,8 +187,10 @@ class _FusedLossFn(torch.autograd.Function):
 class Engine:
     """Owns the plans of one (backbone, neck, head) triple."""
 
-    def __init__(self, backbone, neck=None, head=None, max_plans=3):
+    def __init__(self, backbone, neck=None, head=None, max_plans=3, extra=None, taps=()):
         self.parts = (backbone, neck, head)
+        self.extra = extra            # module(s) outside the plans whose parameters share the flat gradient store (hnet's seg header)
+        self.taps = tuple(taps)       # layer indices whose outputs those modules read
         self.plans = {}
         self.max_plans = max_plans
         self.store = None
@@ -179,7 +214,7 @@ class Engine:
         call on yolov5s, more than the whole inference launch list."""
         params, seen, fused, bufs = [], set(), [], []
         stack = []
-        for part in self.parts:
+        for part in self.parts + (self.extra,):
             if part is None:
                 continue
             stack.extend(reversed(list(part) if not isinstance(part, nn.Module) else [part]))
@@ -231,9 +266,13 @@ class Engine:
             if len(self.plans) >= self.max_plans:
                 self.plans.pop(next(iter(self.plans)))
             b, n, h = self.parts
-            plan = Plan(b, n, h, tuple(x.shape), dtype, training, x.device, grad_store=self.store)
+            tap_params = []
+            if self.extra is not None and training:
+                tap_params = [q for m in (self.extra if not isinstance(self.extra, nn.Module) else [self.extra]) for q in m.parameters()]
+            plan = Plan(b, n, h, tuple(x.shape), dtype, training, x.device, grad_store=self.store, taps=self.taps, tap_params=tap_params)
             plan.bucket_hook = self._bucket_ready
             self.plans[key] = plan
+        self.last_plan = plan
         return plan
 
     def _bucket_ready(self, a, b, side_stream):
@@ -258,13 +297,19 @@ class Engine:
         """Returns (plan, det logits list).  With grad enabled in training mode the logits are attached to autograd."""
         plan = self.plan_for(x, training, dtype)
         self.mask_token = None
+        self.tap_outputs = None
         if training and torch.is_grad_enabled():
-            if plan.mask_vals:
+            if plan.tap_keys:
+                outs = _PlanTapFn.apply(self, plan, self.hook, x)
+                dets, self.tap_outputs = outs[:len(outs) - len(plan.tap_keys)], list(outs[len(outs) - len(plan.tap_keys):])
+            elif plan.mask_vals:
                 *dets, self.mask_token = _PlanMaskFn.apply(self, plan, self.hook, x)
             else:
                 dets = _PlanFn.apply(self, plan, self.hook, x)
         else:
             dets = plan.run_forward(x)
+            if plan.tap_keys:
+                self.tap_outputs = plan.tap_features()
         return plan, list(dets)
 
     def forward_fused_loss(self, x, dtype, head, gts, tcls):
@@ -273,11 +318,21 @@ class Engine:
         plan.run_forward(x)
         plan.fused_loss(head)(gts, tcls)
         self.mask_token = None
-        if plan.mask_vals:
+        self.tap_outputs = None
+        if plan.tap_keys:
+            loss, *self.tap_outputs = _FusedLossTapFn.apply(self, plan, self.hook, plan.loss_out[0:1])
+        elif plan.mask_vals:
             loss, self.mask_token = _FusedLossMaskFn.apply(self, plan, self.hook, plan.loss_out[0:1])
         else:
             loss = _FusedLossFn.apply(self, plan, self.hook, plan.loss_out[0:1])
         return plan, loss, plan.loss_out[1:4].clone()
+
+    def tap_grad_sink(self, plan):
+        """`grad_of(param)` for an outside module's backward: the flat store's view; the first call marks the gradients as written"""
+        def grad_of(p):
+            plan.tap_grads_ready = True
+            return self.store.view_of(p)
+        return grad_of
 
     def after_backward(self):
         for fn in self.grad_hooks:

@@ -599,3 +599,77 @@ def scale_inplace(t, scale):
     """t *= scale (a 1-element fp32 device tensor), no host sync"""
     assert t.is_contiguous() and scale.dtype == torch.float32 and scale.is_cuda
     _lib.call('hdy_scale_inplace', t.data_ptr(), t.numel(), scale.data_ptr(), dcode(t.dtype), stream_ptr())
+
+
+# ------------------------------------------------------------------------------------------ segmentation branch primitives (row f4)
+def groupnorm_relu_fwd(x, gamma, beta, G, eps=1e-5, relu=True):
+    """x NHWC (N, H, W, C) -> (y, saved) with y = relu(GroupNorm_G(x)); saved = (stat [N][G][2], ab [N][2][C]) for the backward."""
+    xp, N, H, W, C, ldx = nhwc(x)
+    y = torch.empty((N, H, W, C), dtype=x.dtype, device=x.device)
+    stat = torch.empty((N, G, 2), dtype=torch.float32, device=x.device)
+    ab = torch.empty((N, 2, C), dtype=torch.float32, device=x.device)
+    ws = torch.empty(_lib.query('hdy_groupnorm_workspace_floats', N, C), dtype=torch.float32, device=x.device)
+    _lib.call('hdy_groupnorm_fwd', xp, ldx, ptr(gamma), ptr(beta), y.data_ptr(), C, stat.data_ptr(), ab.data_ptr(), N, H * W, C, G, float(eps),
+              int(relu), dcode(x.dtype), ws.data_ptr(), stream_ptr())
+    return y, (stat, ab)
+
+
+def groupnorm_relu_bwd(dout, x, gamma, saved, G, dgamma, dbeta, relu=True, accumulate=False):
+    """Gradient of groupnorm_relu_fwd: returns dx (NHWC, x's type); dgamma / dbeta (fp32 views) are written (or accumulated)."""
+    dop, N, H, W, C, lddo = nhwc(dout)
+    xp, _, _, _, _, ldx = nhwc(x)
+    stat, ab = saved
+    dx = torch.empty((N, H, W, C), dtype=x.dtype, device=x.device)
+    coef = torch.empty((N, 3, C), dtype=torch.float32, device=x.device)
+    ws = torch.empty(_lib.query('hdy_groupnorm_workspace_floats', N, C), dtype=torch.float32, device=x.device)
+    assert dout.dtype == x.dtype and dgamma.dtype == dbeta.dtype == torch.float32 and dgamma.is_contiguous() and dbeta.is_contiguous()
+    _lib.call('hdy_groupnorm_bwd', dop, lddo, xp, ldx, ptr(gamma), stat.data_ptr(), ab.data_ptr(), dx.data_ptr(), C, dgamma.data_ptr(),
+              dbeta.data_ptr(), int(accumulate), coef.data_ptr(), N, H * W, C, G, int(relu), dcode(x.dtype), ws.data_ptr(), stream_ptr())
+    return dx
+
+
+def bilinear_fwd(x, size, out=None, accumulate=False):
+    """F.interpolate(x, size, mode='bilinear', align_corners=True) on NHWC; `out` (+)= when given."""
+    xp, N, Hi, Wi, C, ldx = nhwc(x)
+    Ho, Wo = size
+    if out is None:
+        out = torch.empty((N, Ho, Wo, C), dtype=x.dtype, device=x.device)
+        accumulate = False
+    op, _, _, _, Co, ldo = nhwc(out)
+    assert Co == C and tuple(out.shape[:3]) == (N, Ho, Wo) and out.dtype == x.dtype
+    _lib.call('hdy_bilinear_fwd', xp, ldx, op, ldo, N, Hi, Wi, Ho, Wo, C, int(accumulate), dcode(x.dtype), stream_ptr())
+    return out
+
+
+def bilinear_bwd(dy, in_size, out=None, accumulate=False):
+    dyp, N, Ho, Wo, C, lddy = nhwc(dy)
+    Hi, Wi = in_size
+    if out is None:
+        out = torch.empty((N, Hi, Wi, C), dtype=dy.dtype, device=dy.device)
+        accumulate = False
+    op, _, _, _, _, ldo = nhwc(out)
+    _lib.call('hdy_bilinear_bwd', dyp, lddy, op, ldo, N, Hi, Wi, Ho, Wo, C, int(accumulate), dcode(dy.dtype), stream_ptr())
+    return out
+
+
+def softdice(logits, targets, class_weight=None, upstream=None, want_grad=False):
+    """logits fp32 NHWC (N, H, W, ld) with nc = targets.shape[1] classes; targets fp32 (N, nc, H, W) -> (loss[1], dlogits or None)."""
+    require_gpu(logits)
+    N, H, W, ld = logits.shape
+    nc = targets.shape[1]
+    assert logits.dtype == torch.float32 and logits.is_contiguous() and targets.dtype == torch.float32 and targets.is_contiguous()
+    assert tuple(targets.shape) == (N, nc, H, W) and ld >= nc
+    loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+    ws = torch.empty(_lib.query('hdy_softdice_workspace_floats', N, nc), dtype=torch.float32, device=logits.device)
+    dl = torch.zeros_like(logits) if want_grad else None
+    _lib.call('hdy_softdice', logits.data_ptr(), ld, targets.data_ptr(), ptr(class_weight), N, H * W, nc, loss.data_ptr(), ptr(upstream),
+              ptr(dl), ld, ws.data_ptr(), stream_ptr())
+    return loss, dl
+
+
+def softmax2d(logits, nc):
+    require_gpu(logits)
+    assert logits.dtype == torch.float32 and logits.is_contiguous()
+    probs = torch.empty(tuple(logits.shape[:-1]) + (nc,), dtype=torch.float32, device=logits.device)
+    _lib.call('hdy_softmax2d', logits.data_ptr(), logits.shape[-1], probs.data_ptr(), nc, probs.numel() // nc, nc, stream_ptr())
+    return probs

@@ -102,7 +102,7 @@ def _is(m, name):
 
 
 class Plan:
-    def __init__(self, backbone, neck, head, shape, dtype, training, device, grad_store=None):
+    def __init__(self, backbone, neck, head, shape, dtype, training, device, grad_store=None, taps=(), tap_params=()):
         """backbone / neck: the metayolo CSPDarkNet / FPN containers (neck, head may be None);
         head: Detect module or None; shape = (B, 3, H, W).
         Feature-input plans (FPN.forward / Detect.forward called on bare feature maps): backbone is None and shape is
@@ -119,6 +119,11 @@ class Plan:
         self.ext = {}
         self.vals, self.units = [], []
         self.grad_store = grad_store
+        # taps: layer indices whose outputs also feed modules outside the plan (hnet's segmentation header on the pyramid): their
+        # gradient buffers are pre-filled from outside before the backward list runs; tap_params: those modules' parameters (their
+        # gradients are written into the flat store by the outside backward, or zeroed when it did not run)
+        self.tap_keys, self.tap_params = list(taps), list(tap_params)
+        self.tap_grads_ready = False
         self._grad_log = None
         self.bucket_hook = None         # engine: called as hook(a, b, side_stream) when gradient elements [a, b) of the flat buffer are final
         self._order = 0
@@ -581,6 +586,11 @@ class Plan:
             self.input.needs_grad = False
         for v in self.ext.values():
             v.needs_grad = False
+        for k in self.tap_keys:
+            v = self.outs[k]
+            if v.cat is not None or v.parts is not None or v.galias is not None:
+                raise _lib.HdyError(f'layer {k} cannot be tapped: its gradient storage is shared (concat member / shortcut)')
+            v.ginit = True                  # holds the outside consumer's gradient when the list starts: everything else accumulates
 
         def up(v):                                   # needs_grad of a (possibly concatenated) input value
             if v is None:
@@ -736,9 +746,23 @@ class Plan:
                                              head.det_loss.balance, cw, head.det_loss.hyp, self.loss_out, self.device)
         return self.loss_call
 
-    def run_backward(self, gdets=None, scale=None):
+    def tap_features(self):
+        return [self.feature(k) for k in self.tap_keys]
+
+    def run_backward(self, gdets=None, scale=None, gtaps=None):
         """gdets: autograd's logits gradients (unfused loss), or None when the fused loss kernel already filled the plan's
-        gradient buffers; then `scale` is the upstream gradient of the loss (1-element device tensor)."""
+        gradient buffers; then `scale` is the upstream gradient of the loss (1-element device tensor).  gtaps: gradients of the
+        tapped feature maps (NCHW-shaped, or None = no outside consumer contributed in this step)."""
+        for i, k in enumerate(self.tap_keys):
+            g = None if gtaps is None else gtaps[i]
+            if g is None:
+                self.outs[k].g().zero_()
+            else:
+                self.outs[k].g().copy_(g.permute(0, 2, 3, 1))
+        if self.tap_params and not self.tap_grads_ready:
+            for q in self.tap_params:
+                self.grad_store.view_of(q).zero_()
+        self.tap_grads_ready = False
         if gdets is None:
             if scale is not None:
                 ops.scale_inplace(self.gdet_flat, scale.reshape(-1)[:1].float().contiguous())

@@ -230,6 +230,25 @@ int hdy_det_loss(const float* const* logits, int ldl, void* const* gdet, int ldg
                  float* out, void* workspace, size_t ws_bytes, void* stream);
 int hdy_scale_inplace(void* p, long long n, const float* scale_dev, int dtype, void* stream);
 
+/* ---- Semantic-segmentation branch (hnet's PanopticSeg) ---------------------------------------------
+ * Replaces, under autograd, torch.nn.GroupNorm(32, C) + ReLU and nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True)
+ * of PanopticFeatureConnector (hnet/segmentation/utils_seg.py:21-36), the branch sum (:58), nn.Upsample / F.interpolate(...,
+ * align_corners=True) and torch.nn.Softmax2d of PanopticSeg (hnet/segmentation/panoptic_seg.py:13-19,38-39) and its soft-dice
+ * criterion (:22,40; `SoftDiceLoss` is not defined anywhere upstream: restated from the repository's own dice, mask_iou(factor=0),
+ * metayolo/models/utils_general.py:268-280).  NHWC, pixel pitches, caller-owned workspaces as everywhere else. */
+size_t hdy_groupnorm_workspace_floats(int N, int C);
+int hdy_groupnorm_fwd(const void* x, int ldx, const float* gamma, const float* beta, void* y, int ldy, float* stat, float* ab, int N, int HW,
+                      int C, int G, float eps, int relu, int dtype, float* workspace, void* stream);
+int hdy_groupnorm_bwd(const void* dout, int lddo, const void* x, int ldx, const float* gamma, const float* stat, const float* ab, void* dx, int lddx,
+                      float* dgamma, float* dbeta, int accumulate, float* coef, int N, int HW, int C, int G, int relu, int dtype, float* workspace,
+                      void* stream);
+int hdy_bilinear_fwd(const void* x, int ldx, void* y, int ldy, int N, int Hi, int Wi, int Ho, int Wo, int C, int accumulate, int dtype, void* stream);
+int hdy_bilinear_bwd(const void* dy, int lddy, void* dx, int lddx, int N, int Hi, int Wi, int Ho, int Wo, int C, int accumulate, int dtype, void* stream);
+size_t hdy_softdice_workspace_floats(int N, int nc);
+int hdy_softdice(const float* logits, int ldl, const float* targets, const float* class_weight, int N, int HW, int nc, float* loss,
+                 const float* upstream, float* dlogits, int lddl, float* workspace, void* stream);
+int hdy_softmax2d(const float* logits, int ldl, float* probs, int ldp, long long M, int nc, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -263,6 +263,106 @@ def gen_outputs():
     print('wrote outputs.npz')
 
 
+def gen_seg():
+    """hnet's semantic-segmentation header from the reference's OWN classes: PanopticFeatureConnector
+    (hnet/segmentation/utils_seg.py) unmodified, and PanopticSeg (hnet/segmentation/panoptic_seg.py) with the two names it cannot
+    resolve supplied: `SoftDiceLoss` (defined nowhere upstream: oracle/seg_ref.py's restatement from the repository's dice) and
+    torchvision's roi_align on its identity case (a whole-map roi at the map's own resolution with aligned=True samples every bin
+    once, at the pixel centre).  `hnet/__init__.py` imports timm / mmcv-style modules, so the package object is pre-seeded."""
+    import contextlib
+    import io
+    from collections import OrderedDict
+    from oracle import seg_ref
+    pkg = types.ModuleType('hnet')
+    pkg.__path__ = [os.path.join(REF, 'hnet')]
+    sys.modules['hnet'] = pkg
+    segpkg = types.ModuleType('hnet.segmentation')
+    segpkg.__path__ = [os.path.join(REF, 'hnet', 'segmentation')]
+    sys.modules['hnet.segmentation'] = segpkg
+    tv_ops = sys.modules['torchvision.ops']
+
+    def roi_align_identity(f, rois, o_size, aligned=False, **k):
+        assert aligned and tuple(o_size) == tuple(f.shape[2:])
+        for r in rois:
+            assert r.shape == (1, 4) and [float(v) for v in r[0]] == [0.0, 0.0, float(f.shape[3]), float(f.shape[2])], r
+        return f
+    saved = tv_ops.roi_align
+    tv_ops.roi_align = roi_align_identity
+    boxes_mod = types.ModuleType('torchvision.ops.boxes')     # sliding_window_scanner clips its windows to the image (hnet/utils.py:60)
+
+    def clip_boxes_to_image(boxes, size):
+        h, w = size
+        return torch.stack([boxes[:, 0].clamp(0, w), boxes[:, 1].clamp(0, h), boxes[:, 2].clamp(0, w), boxes[:, 3].clamp(0, h)], 1)
+    boxes_mod.clip_boxes_to_image = clip_boxes_to_image
+    tv_ops.boxes = boxes_mod
+    useg = importlib.import_module('hnet.segmentation.utils_seg')
+    pseg = importlib.import_module('hnet.segmentation.panoptic_seg')
+
+    class SoftDiceLoss(nn.Module):
+        def __init__(self, class_weight=None):
+            super().__init__()
+            self.class_weight = class_weight
+
+        def forward(self, probs, masks):
+            return seg_ref.soft_dice_criterion(probs, masks, self.class_weight)
+    pseg.SoftDiceLoss = SoftDiceLoss
+    out = {}
+    g = torch.Generator().manual_seed(77)
+    # ---- connector alone: 4 levels (the reference's pyramid depth), widths as a yolov5n6-like pyramid, 32-channel ladders (one channel per group)
+    chans, sizes = [32, 64, 96, 128], [(24, 16), (12, 8), (6, 4), (3, 2)]
+    names = OrderedDict((str(k), str(k)) for k in (23, 26, 29, 32))
+    con = useg.PanopticFeatureConnector(chans, 32, names)
+    for k, v in con.state_dict().items():
+        v.copy_(torch.randn(v.shape, generator=g) * (0.08 if v.dim() == 4 else 0.5) + (1.0 if k.endswith('1.weight') or '.weight' in k and v.dim() == 1 else 0.0))
+    feats = OrderedDict((n, torch.randn((2, c, h, w), generator=g, requires_grad=True)) for n, c, (h, w) in zip(names, chans, sizes))
+    y = con(feats)['0']
+    wsum = torch.randn(y.shape, generator=g)
+    (y * wsum).sum().backward()
+    out['con_out'], out['con_wsum'] = npf(y), npf(wsum)
+    for n, f in feats.items():
+        out[f'con_in_{n}'], out[f'con_din_{n}'] = npf(f), npf(f.grad)
+    for k, v in con.state_dict().items():
+        out[f'con_p_{k}'] = npf(v)
+    for k, v in con.named_parameters():
+        out[f'con_g_{k}'] = npf(v.grad)
+    # ---- PanopticSeg: 3 levels at 1/8, 1/16, 1/32 of a 64 x 96 tile, 3 classes, scale_factor 8, class weights
+    cfg = {'in_channels': 64, 'num_classes': 3, 'feature_maps': OrderedDict((str(k), str(k)) for k in (17, 20, 23)), 'scale_factor': 8,
+           'resize_mode': 'bilinear', 'class_weight': [1.0, 2.0, 0.5], 'roi_size': None}
+    head = pseg.PanopticSeg(cfg).train()
+    for k, v in head.state_dict().items():
+        v.copy_(torch.randn(v.shape, generator=g) * (0.08 if v.dim() == 4 else 0.5) + (1.0 if v.dim() == 1 and k.endswith('weight') else 0.0))
+    H, W = 64, 96
+    feats = OrderedDict((n, torch.randn((2, 64, H // s, W // s), generator=g, requires_grad=True)) for n, s in zip(cfg['feature_maps'], (8, 16, 32)))
+    lab = torch.randint(0, 3, (2, H, W), generator=g)
+    masks = F_one_hot(lab, 3)
+    targets = [[{'roi': torch.tensor([0.0, 0.0, W, H]), 'masks': masks[i]}] for i in range(2)]
+    with contextlib.redirect_stdout(io.StringIO()):                      # the reference prints a debug line per level (hnet/utils.py:152)
+        res, losses = head(feats, (H, W), None, targets)
+    losses['soft_iou_loss'].backward()
+    out['seg_loss'] = npf(losses['soft_iou_loss'].reshape(1))
+    out['seg_probs'] = npf(torch.cat(list(res)))
+    out['seg_masks'] = npf(masks)
+    for n, f in feats.items():
+        out[f'seg_in_{n}'], out[f'seg_din_{n}'] = npf(f), npf(f.grad)
+    for k, v in head.state_dict().items():
+        out[f'seg_p_{k}'] = npf(v)
+    for k, v in head.named_parameters():
+        out[f'seg_g_{k}'] = npf(v.grad)
+    head.eval()
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+        res, _ = head(OrderedDict((n, f.detach()) for n, f in feats.items()), (H, W), None, None)
+    out['seg_eval_probs'] = npf(torch.cat(list(res)))
+    tv_ops.roi_align = saved
+    for m in ('hnet', 'hnet.segmentation', 'hnet.segmentation.utils_seg', 'hnet.segmentation.panoptic_seg', 'hnet.utils'):
+        sys.modules.pop(m, None)
+    np.savez_compressed(os.path.join(HERE, 'seg.npz'), **out)
+    print('wrote seg.npz')
+
+
+def F_one_hot(lab, nc):
+    return torch.nn.functional.one_hot(lab, nc).permute(0, 3, 1, 2).float().contiguous()
+
+
 def gen_keys():
     """state_dict key list + shapes for the four variants (drop-in surface)."""
     out = {}
@@ -526,6 +626,9 @@ def main():
     if sys.argv[1:] == ['scale_img']:
         gen_scale_img()
         return
+    if sys.argv[1:] == ['seg']:
+        gen_seg()
+        return
     if sys.argv[1:] == ['p6']:                 # only the P6 fixtures (the others are unchanged by construction)
         gen_stages('n6_128', 'n6', 3, 2, 128, full=False)
         gen_train('n6_128', 'n6', 3, 2, 128, 4, 12)
@@ -546,6 +649,7 @@ def main():
     gen_scale_img()
     gen_confusion()
     gen_train('n_64_ragged', 'n', 2, 2, 64, 3, 8, empty_first=True)
+    gen_seg()
 
 
 if __name__ == '__main__':
