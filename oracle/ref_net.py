@@ -320,7 +320,14 @@ class RefNet:
                 pwh = (ps[:, 2:4].sigmoid() * 2) ** 2 * anc
                 iou = self.ciou(torch.cat((pxy, pwh), 1), tbox).squeeze()
                 lbox = lbox + (1.0 - iou).mean()
-                tobj[b, a, gj, gi] = iou.detach().clamp(0).type(tobj.dtype)
+                # loss.py:217 `tobj[b, a, gj, gi] = iou`: with several matches in one (anchor, cell) the reference keeps whichever
+                # write its (parallel) index_put_ made last — run-to-run different with more than one thread.  The oracle pins the
+                # one-thread behaviour: the last match in target order wins.
+                lin = ((b * tobj.shape[1] + a) * tobj.shape[2] + gj) * tobj.shape[3] + gi
+                order = torch.arange(lin.numel())
+                last = torch.full((tobj.numel(),), -1, dtype=torch.long).scatter_reduce_(0, lin, order, reduce='amax', include_self=True)
+                win = last[lin] == order
+                tobj.view(-1)[lin[win]] = iou.detach().clamp(0).type(tobj.dtype)[win]
                 if nc > 1:
                     tc = onehot[tid]
                     has = tc[:, 1:].sum(-1) > 0

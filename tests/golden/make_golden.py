@@ -169,6 +169,32 @@ def gen_stages(tag, variant, nc, batch, size, full=True):
     print('wrote', f'stages_{tag}.npz', {k: v.shape for k, v in list(out.items())[:4]})
 
 
+def gen_eval_compact(tag, variant, nc, batch, size, conf=0.05):
+    """Full-size eval fixtures kept small: final detections per image, and per detection level the (sum, abs-sum, l2) of the logits plus
+    a thin strip of them (first image, first anchor, four grid rows) to localise a mismatch."""
+    hyp = synth.make_hyp(conf_thres=conf)
+    model = ref_model(variant, nc, hyp).eval()
+    x = synth.synth_images(batch, size, seed=7)
+    out = {'meta': np.array([batch, size, nc]), 'conf_thres': np.array(conf)}
+    with torch.no_grad():
+        neck = model.neck(dict(model.backbone(x)))
+        head = model.headers['det']
+        for i, conv in enumerate(head.m):
+            f = conv(neck[head.f[i]])
+            bs, _, ny, nx = f.shape
+            d = f.view(bs, head.na, head.no, ny, nx).permute(0, 1, 3, 4, 2).contiguous()
+            d64 = d.double()
+            out[f'det_{i}_sums'] = np.array([d64.sum().item(), d64.abs().sum().item(), d64.pow(2).sum().sqrt().item()])
+            out[f'det_{i}_strip'] = npf(d[:1, :1, :4])
+        _, outputs = model(x)
+        for b, o in enumerate(outputs):
+            out[f'out_{b}_boxes'] = npf(o['det']['boxes'])
+            out[f'out_{b}_scores'] = npf(o['det']['scores'])
+            out[f'out_{b}_labels'] = npf(o['det']['labels'])
+    np.savez_compressed(os.path.join(HERE, f'eval_{tag}.npz'), **out)
+    print('wrote', f'eval_{tag}.npz', [len(out[f'out_{b}_boxes']) for b in range(batch)])
+
+
 GRAD_KEYS = ['backbone.0.conv.weight', 'backbone.1.conv.weight', 'backbone.2.m.0.cv2.conv.weight',
              'backbone.2.cv3.conv.weight', 'backbone.2.cv1.bn.weight', 'backbone.2.cv1.bn.bias',
              'backbone.9.cv2.conv.weight', 'neck.3.cv3.conv.weight', 'neck.8.conv.weight',
@@ -189,9 +215,16 @@ def gen_train(tag, variant, nc, batch, size, nmin, nmax, empty_first=False):
     if empty_first:                           # a tile without nuclei: empty boxes / labels (datasets.py:462-519)
         a = targets[0]['anns']['det'][0]
         a['boxes'], a['labels'] = a['boxes'][:0], a['labels'][:0]
+    # Dense targets (50-400 per 640x640 tile) put several matches into the same (anchor, cell); `tobj[b, a, gj, gi] = iou` (loss.py:217)
+    # then keeps whichever write its parallel index_put_ made last: with 8 threads the obj term moved by 1e-4 and the stem gradient by
+    # 2e-3 between runs.  One thread makes it the last match in target order — the semantics the oracle and csrc/loss.hip implement.
+    threads = torch.get_num_threads()
+    if size >= 640:
+        torch.set_num_threads(1)
     losses, _ = model(x, targets, compute_masks=True)
     loss = losses['det']['det_loss'] + losses['det']['mask_loss']
     loss.backward()
+    torch.set_num_threads(threads)
     out = {'meta': np.array([batch, size, nc, nmin, nmax]),
            'loss': npf(losses['det']['det_loss'])}
     for k, v in losses['det']['loss_items'].items():
@@ -626,6 +659,11 @@ def main():
     if sys.argv[1:] == ['scale_img']:
         gen_scale_img()
         return
+    if sys.argv[1:] == ['fullsize']:            # BASELINE config C1 exactly (yolov5n, 2 classes, batch 4, 640x640) and yolov5s at 640x640
+        gen_train('c1_640', 'n', 2, 4, 640, 50, 400)
+        gen_eval_compact('c1_640', 'n', 2, 4, 640)
+        gen_eval_compact('s_640', 's', 8, 2, 640)
+        return
     if sys.argv[1:] == ['seg']:
         gen_seg()
         return
@@ -650,6 +688,9 @@ def main():
     gen_confusion()
     gen_train('n_64_ragged', 'n', 2, 2, 64, 3, 8, empty_first=True)
     gen_seg()
+    gen_train('c1_640', 'n', 2, 4, 640, 50, 400)
+    gen_eval_compact('c1_640', 'n', 2, 4, 640)
+    gen_eval_compact('s_640', 's', 8, 2, 640)
 
 
 if __name__ == '__main__':

@@ -121,7 +121,7 @@ def ragged(targets, tag):
     return targets
 
 
-@pytest.mark.parametrize('tag,v', [('n_64', 'n'), ('s_128', 's'), ('n6_128', 'n6'), ('n_64_ragged', 'n')])
+@pytest.mark.parametrize('tag,v', [('n_64', 'n'), ('s_128', 's'), ('n6_128', 'n6'), ('n_64_ragged', 'n'), ('c1_640', 'n')])
 def test_train_loss_and_grads(golden_dir, tag, v):
     g = load(golden_dir, f'train_{tag}.npz')
     batch, size, nc, nmin, nmax = (int(t) for t in g['meta'])
@@ -134,9 +134,11 @@ def test_train_loss_and_grads(golden_dir, tag, v):
     targets = ragged(synth.synth_targets(batch, size, nc, nmin=nmin, nmax=nmax, seed=5), tag)
     loss, items, _ = net.train_forward(sd, x, targets)
     loss.backward()
-    close(loss, g['loss'], rtol=1e-5)
+    # (the full-size golden was made with ONE torch thread: colliding matches are then resolved in target order, see make_golden.gen_train)
+    rtol = 1e-5 if size < 640 else 1e-4          # full size: fp32 reduction order over ~10^6 elements differs with the thread count (2e-5)
+    close(loss, g['loss'], rtol=rtol)
     for k in ('box', 'obj', 'cls'):
-        close(items[k], g[f'loss_{k}'], rtol=1e-5)
+        close(items[k], g[f'loss_{k}'], rtol=rtol)
     for k in g.files:
         if k.startswith('stat:'):
             close(sd[k[5:]], g[k], rtol=1e-4, atol=1e-6)
