@@ -10,8 +10,13 @@ backward, wgrad, dgrad), the RCCL gradient all-reduce when N > 1, and the SGD(Ne
 configs[1]: yolov5s, 8 classes, batch 64 per GPU, 640x640 (weak scaling: per-GPU batch fixed).  One JSON line on rank 0.
 
 Extra objects on the line:
-  roofline      the dominant kernel (conv_igemm, bf16) on the layer the north star names — the fused 3x3 conv 64->64 at
-                80x80, batch 64 — timed live with HIP events on the launch stream; achieved = 2*N*K*C*9*Ho*Wo / t.
+  roofline      the kernel on the layer the north star names — the fused 3x3 conv 64->64 at 80x80, batch 64 (filter-resident
+                conv3x3_c64) — timed live with HIP events on the launch stream; achieved = 2*N*K*C*9*Ho*Wo / t.  Its `layers_3x3`
+                lists EVERY 3x3 convolution launch of the benchmarked model (forward and data gradient) timed alone, `min_frac` is the
+                worst of them: the named kernel is 2 % of the step, the others are where the time goes.
+  step          whole-step fractions: conv FLOPs of the step / time / 2.5 PFLOP/s and read-once/write-once bytes of its conv and
+                BatchNorm launches / time / 8 TB/s.
+  infer         BASELINE configs[3] (yolov5l, batch 128, 1024x1024 inference): tiles/s, decode and NMS microseconds per tile.
   cpu_baseline  the CPU oracle (oracle/ref_net.py, a torch-fp32 port of the reference path) doing the same training step on
                 a bounded sample (a few 640x640 tiles) on this host's cores.
 """
@@ -158,6 +163,7 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-infer', action='store_true', help='skip the C4 inference measurement (yolov5l, batch 128, 1024x1024)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -268,8 +274,23 @@ def main():
                        'world_size': dist.get_world_size() if world > 1 else 1, 'backend': backend},
             'final_loss': round(final_loss, 4),
         }
+        from hd_yolo_amd import bench_util
+        plan = next(iter(model._eng().plans.values()))
+        fl, by = bench_util.plan_work(plan)
+        ms = dt / args.steps * 1e3
+        line['step'] = {'conv_tflop_per_step': round(fl / 1e12, 3), 'mfma_frac': round(fl / ms / 1e9 / PEAK_BF16_TFLOPS, 4),
+                        'algorithmic_gb_per_step': round(by / 1e9, 2), 'hbm_frac': round(by / ms / 1e6 / PEAK_HBM_GBS, 4),
+                        'launches_per_step': len(bench_util.flat_records(plan.fwd)) + len(bench_util.flat_records(plan.bwd))}
         if not args.no_roofline:
             line['roofline'] = conv_roofline(device)
+            rows = bench_util.conv3x3_table(plan, PEAK_BF16_TFLOPS)
+            line['roofline']['layers_3x3'] = [{'layer': r[0], 'us': r[1], 'tflops': r[2], 'frac': r[3]} for r in rows]
+            line['roofline']['min_frac'] = min(r[3] for r in rows)
+        if world == 1 and not args.no_infer and args.variant == 's' and args.batch == 64:
+            try:
+                line['infer'] = bench_util.infer_benchmark('l', 128, 1024, 3, device)
+            except Exception as e:                                     # never lose the headline line to the side measurement
+                line['infer'] = {'error': repr(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.variant, args.nc, args.size)
         print(json.dumps(line), flush=True)

@@ -1,0 +1,132 @@
+"""Measurement helpers shared by bench.py and scripts/: algorithmic work of a plan's launch records, per-launch timing, and the
+C4 inference measurement (BASELINE.json configs[3])."""
+import torch
+
+from . import ops, synth
+
+
+def describe(rec):
+    """(label, FLOPs, read-once/write-once bytes) of a launch record (bf16 operands); (label, 0, 0) for records without a model."""
+    name, a = rec[0], rec[1]
+    if name == 'hdy_conv_fwd':
+        N, H, W, C, K, R, S_, st, pad = a[10:19]
+        Ho, Wo = ops.out_dim(H, R, st, pad), ops.out_dim(W, S_, st, pad)
+        return f'fwd  {C:4d}->{K:4d} k{R} s{st} @{H}x{W}', 2.0 * N * Ho * Wo * K * C * R * S_, 2.0 * (N * H * W * C + N * Ho * Wo * K)
+    if name == 'hdy_conv_dgrad':
+        N, H, W, C, K, R, S_, st, pad = a[5:14]
+        Ho, Wo = ops.out_dim(H, R, st, pad), ops.out_dim(W, S_, st, pad)
+        return f'dgrd {C:4d}<-{K:4d} k{R} s{st} @{H}x{W}', 2.0 * N * Ho * Wo * K * C * R * S_, 2.0 * (N * H * W * C + N * Ho * Wo * K)
+    if name == 'hdy_conv_wgrad':
+        N, H, W, C, K, R, S_, st, pad = a[4:13]
+        Ho, Wo = ops.out_dim(H, R, st, pad), ops.out_dim(W, S_, st, pad)
+        return f'wgrd {C:4d}x{K:4d} k{R} s{st} @{H}x{W}', 2.0 * N * Ho * Wo * K * C * R * S_, 2.0 * (N * H * W * C + N * Ho * Wo * K)
+    if name == 'hdy_bn_act_fwd':
+        M, K = a[8], a[9]
+        return f'bnfw K={K} M={M}', 0.0, 2.0 * M * K * (3 if a[4] else 2)
+    if name == 'hdy_bn_act_bwd':
+        M, K = a[13], a[14]
+        if a[8] is None:
+            return f'bnst K={K} M={M}', 0.0, 2.0 * M * K * 2
+        return f'bnbw K={K} M={M}', 0.0, 2.0 * M * K * 5
+    if name == 'hdy_conv1x1_bwd_fused':
+        M, C, K = a[24], a[25], a[26]
+        return f'f1x1 {C:4d}<>{K:4d} M={M}' + (' acc' if a[18] else ''), 4.0 * M * K * C, 2.0 * M * (2 * K + (3 if a[18] else 2) * C)
+    if name == 'hdy_bn_act_fwd_pair':
+        M, K = a[9], a[10]
+        return f'bnfw K={K} M={M} (pair)', 0.0, 2.0 * M * K * 2
+    if name == 'hdy_bn_act_bwd_pair':
+        M, K = a[18], a[19]
+        if a[11] is None:
+            return f'bnst K={K} M={M} (pair)', 0.0, 2.0 * M * K * 2
+        return f'bnbw K={K} M={M} (pair)', 0.0, 2.0 * M * K * 5
+    return name[4:], 0.0, 0.0
+
+
+def flat_records(recs):
+    out = []
+    for rec in recs or []:
+        if rec[0] == '@fork':
+            out.extend(rec[2])
+        elif rec[0][0] != '@':
+            out.append(rec)
+    return out
+
+
+def plan_work(plan):
+    """(FLOPs, bytes) of one forward + backward replay of a training plan: the sums of describe() over its conv / BatchNorm launches."""
+    fl = by = 0.0
+    for rec in flat_records(plan.fwd) + flat_records(plan.bwd):
+        _, f, b = describe(rec)
+        fl, by = fl + f, by + b
+    return fl, by
+
+
+def time_record(rec, reps=10):
+    """average microseconds of one launch record replayed back to back (HIP events on the launch stream)"""
+    for _ in range(2):
+        ops.run([rec])
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        ops.run([rec])
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
+def conv3x3_table(plan, peak_tflops=2500.0, reps=8):
+    """Every 3x3 convolution launch (forward, and data gradient) of a plan timed alone: [(label, us, TFLOP/s, fraction of peak)]"""
+    rows, seen = [], set()
+    for rec in flat_records(plan.fwd) + flat_records(plan.bwd):
+        if rec[0] not in ('hdy_conv_fwd', 'hdy_conv_dgrad'):
+            continue
+        label, fl, _ = describe(rec)
+        if ' k3 ' not in label or label in seen:
+            continue
+        seen.add(label)
+        us = time_record(rec, reps)
+        rows.append((label, round(us, 1), round(fl / us / 1e6, 1), round(fl / us / 1e6 / peak_tflops, 4)))
+    return rows
+
+
+def timed(fn, n):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def infer_benchmark(variant='l', B=128, S=1024, iters=3, device=None, nc=8):
+    """BASELINE.json configs[3] (C4): yolov5l, batch 128, 1024x1024, bf16 inference = eval launch list + decode + NMS + outputs."""
+    from metayolo.models.yolo import Model
+    dev = device or torch.device('cuda', 0)
+    m = Model(synth.make_cfg(variant, nc), synth.make_hyp())
+    m.load_state_dict(synth.synth_state_dict(synth.shapes_of(m), seed=0), strict=False)
+    m = m.to(dev).eval().half()
+    x = synth.synth_images(B, S, seed=0).to(dev)
+    with torch.no_grad():
+        ms_all = timed(lambda: m(x), iters)
+        plan = next(iter(m._eng().plans.values()))
+        ms_net = timed(lambda: plan.run_forward(x), iters)
+        head = m.headers['det']
+        dets = plan.det_views()
+        ms_dec = timed(lambda: head.decode_all(dets), iters)
+        preds = head.decode_all(dets)
+        ms_out = timed(lambda: head.compute_outputs(preds), iters)
+        p = head.nms_params
+        ms_nms = timed(lambda: ops.nms_batched(preds, head.nc, p['conf_thres'], p['iou_thres'], int(p['max_det'])), iters)
+    ncand = preds.shape[1]
+    dec_bytes = B * ncand * (head.no + head.no + 1) * 4        # logits read + rows written (108 B per candidate at nc = 8)
+    gf = {'n': 4.13, 's': 15.81, 'm': 47.94, 'l': 107.76}[variant[0]] * (S / 640) ** 2
+    out = {'workload': f'yolov5{variant} {nc}-class, batch {B}, {S}x{S}, bf16 inference: network + decode + NMS + outputs', 'tiles_per_s': round(B / ms_all * 1e3, 1),
+           'ms_per_batch': round(ms_all, 3), 'ms_network': round(ms_net, 3), 'network_tflops': round(gf * B / ms_net, 1),
+           'decode_us_per_tile': round(ms_dec / B * 1e3, 2), 'decode_hbm_frac': round(dec_bytes / ms_dec / 1e6 / 8000, 3),
+           'nms_kernel_us_per_tile': round(ms_nms / B * 1e3, 2), 'nms_plus_outputs_us_per_tile': round(ms_out / B * 1e3, 2), 'candidates_per_tile': ncand}
+    del m, x, preds, dets
+    torch.cuda.empty_cache()
+    return out

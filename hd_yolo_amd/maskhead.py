@@ -11,11 +11,17 @@ import torch
 from . import ops
 
 
+_CACHE = None
+
+
 def _pack(weight, stride, pad, kind, dtype):
-    K, C, R, S = weight.shape
-    wp = ops.pack_alloc(K, C, R, S, stride, pad, kind, dtype, weight.device)
-    ops.run([ops.rec_pack(weight.detach().float(), None, stride, pad, kind, wp)])
-    return wp
+    """Packed kernel operand of a head weight, re-packed only when the parameter changed (version counter / storage): evaluation
+    loops and the several uses of one weight inside a training step (forward, data gradient) share one packing."""
+    global _CACHE
+    if _CACHE is None:
+        from .segrun import PackCache
+        _CACHE = PackCache()
+    return _CACHE.get(weight, stride, pad, kind, dtype)
 
 
 class MaskHeadRun:

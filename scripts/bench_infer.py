@@ -38,8 +38,16 @@ with torch.no_grad():
     head = m.headers['det']
     dets = plan.det_views()
     ms_dec = timed(lambda: head.decode_all(dets), iters)
+    preds = head.decode_all(dets)
+    ms_out = timed(lambda: head.compute_outputs(preds), iters)
+    conf, iou, max_det = head.nms_params['conf_thres'], head.nms_params['iou_thres'], int(head.nms_params['max_det'])
+    ms_nms = timed(lambda: ops.nms_batched(preds, head.nc, conf, iou, max_det), iters)
+ncand = preds.shape[1]
+dec_bytes = B * ncand * (head.no + head.no + 1) * 4            # logits read + rows written (108 B per candidate at nc = 8)
 out.update(ms_per_batch=round(ms_all, 3), tiles_per_s=round(B / ms_all * 1e3, 1), ms_network=round(ms_net, 3), ms_decode=round(ms_dec, 3),
-           mem_GB=round(torch.cuda.max_memory_allocated() / 2**30, 1))
+           decode_us_per_tile=round(ms_dec / B * 1e3, 2), decode_GBs=round(dec_bytes / ms_dec / 1e6, 1), decode_hbm_frac=round(dec_bytes / ms_dec / 1e6 / 8000, 3),
+           ms_nms_kernel=round(ms_nms, 3), nms_us_per_tile=round(ms_nms / B * 1e3, 2), ms_outputs_total=round(ms_out, 3),
+           candidates_per_tile=ncand, mem_GB=round(torch.cuda.max_memory_allocated() / 2**30, 1))
 gf = {'n': 4.13, 's': 15.81, 'm': 47.94, 'l': 107.76}[variant] * (S / 640) ** 2
 out['network_TFLOPs'] = round(gf * B / ms_net, 1)
 # NMS stress sets: M survivors per tile

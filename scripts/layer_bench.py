@@ -27,42 +27,7 @@ else:
     plan = next(iter(m._eng().plans.values()))
 torch.cuda.synchronize()
 
-def describe(rec):
-    name, a = rec[0], rec[1]
-    if name == 'hdy_conv_fwd':
-        N, H, W, C, K, R, S_, st, pad = a[10:19]
-        Ho, Wo = ops.out_dim(H, R, st, pad), ops.out_dim(W, S_, st, pad)
-        fl = 2.0 * N * Ho * Wo * K * C * R * S_
-        by = 2.0 * (N * H * W * C + N * Ho * Wo * K)
-        return f'fwd  {C:4d}->{K:4d} k{R} s{st} @{H}x{W}', fl, by
-    if name == 'hdy_conv_dgrad':
-        N, H, W, C, K, R, S_, st, pad = a[5:14]
-        Ho, Wo = ops.out_dim(H, R, st, pad), ops.out_dim(W, S_, st, pad)
-        return f'dgrd {C:4d}<-{K:4d} k{R} s{st} @{H}x{W}', 2.0 * N * Ho * Wo * K * C * R * S_, 2.0 * (N * H * W * C + N * Ho * Wo * K)
-    if name == 'hdy_conv_wgrad':
-        N, H, W, C, K, R, S_, st, pad = a[4:13]
-        Ho, Wo = ops.out_dim(H, R, st, pad), ops.out_dim(W, S_, st, pad)
-        return f'wgrd {C:4d}x{K:4d} k{R} s{st} @{H}x{W}', 2.0 * N * Ho * Wo * K * C * R * S_, 2.0 * (N * H * W * C + N * Ho * Wo * K)
-    if name == 'hdy_bn_act_fwd':
-        M, K = a[8], a[9]
-        return f'bnfw K={K} M={M}', 0.0, 2.0 * M * K * (3 if a[4] else 2)
-    if name == 'hdy_bn_act_bwd':
-        M, K = a[13], a[14]
-        if a[8] is None:
-            return f'bnst K={K} M={M}', 0.0, 2.0 * M * K * 2
-        return f'bnbw K={K} M={M}', 0.0, 2.0 * M * K * 5
-    if name == 'hdy_conv1x1_bwd_fused':
-        M, C, K = a[24], a[25], a[26]
-        return f'f1x1 {C:4d}<>{K:4d} M={M}' + (' acc' if a[18] else ''), 4.0 * M * K * C, 2.0 * M * (2 * K + (3 if a[18] else 2) * C)
-    if name == 'hdy_bn_act_fwd_pair':
-        M, K = a[9], a[10]
-        return f'bnfw K={K} M={M} (pair)', 0.0, 2.0 * M * K * 2
-    if name == 'hdy_bn_act_bwd_pair':
-        M, K = a[18], a[19]
-        if a[11] is None:
-            return f'bnst K={K} M={M} (pair)', 0.0, 2.0 * M * K * 2
-        return f'bnbw K={K} M={M} (pair)', 0.0, 2.0 * M * K * 5
-    return name[4:], 0.0, 0.0
+from hd_yolo_amd.bench_util import describe  # noqa: E402
 
 rows = []
 for phase, recs in (('F', plan.fwd), ('B', plan.bwd or [])):

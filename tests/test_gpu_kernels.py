@@ -370,6 +370,19 @@ def test_decode_against_reference_golden(golden_dir):
         out2 = torch.zeros((B, d.shape[1] * d.shape[2] * d.shape[3], no + 1), device=DEV)
         ops.decode_level(nhwc.permute(0, 3, 1, 2, 4), synth.ANCHORS_P5[0], 8.0, out2, 0, 0)
         assert torch.equal(out2, out[:, :out2.shape[1]])
+        # the plan's layout: pixel-major logits with the channel pitch padded to a multiple of 4 floats -> the tiled kernel; every level,
+        # written at its row offset, must give the very same bits as the per-candidate kernel
+        out3 = torch.zeros_like(out)
+        off = 0
+        for l, d in enumerate(dets):
+            Bn, na_, ny, nx, no_ = d.shape
+            ld = (na_ * no_ + 7) // 8 * 8
+            buf = torch.full((Bn, ny, nx, ld), 9.0, device=DEV)
+            buf[..., :na_ * no_] = d.permute(0, 2, 3, 1, 4).reshape(Bn, ny, nx, na_ * no_)
+            view = buf[..., :na_ * no_].view(Bn, ny, nx, na_, no_).permute(0, 3, 1, 2, 4)
+            ops.decode_level(view, synth.ANCHORS_P5[l], strides[l], out3, off, l)
+            off += na_ * ny * nx
+        assert torch.equal(out3, out)
 
 
 def _check_nms(preds, nc, conf, iou, max_det, class_aware=False):
