@@ -262,7 +262,12 @@ size_t hdy_conv_wgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, 
         const int g = hdy_wgrad_stem_grid(N, Ho, Wo, K, dtype);        // patch-resident stem kernel: one slab per workgroup
         if (g > splits) splits = g;
     }
-    return (size_t)splits * K * Q * sizeof(float);
+    size_t bytes = (size_t)splits * K * Q * sizeof(float);
+    if (!stem && R == 3 && S == 3 && pad == 1) {                       // patch-resident 3x3 kernel: its own split count
+        const size_t b3 = hdy_wgrad3x3_workspace_bytes(N, Ho, Wo, C, K, stride, dtype);
+        if (b3 > bytes) bytes = b3;
+    }
+    return bytes;
 }
 
 // grad_a [K_a][C][R][S] (and optionally grad_b [K_b][C][R][S], the lower rows of a stacked weight) (+)= dW.
@@ -289,7 +294,10 @@ int hdy_conv_wgrad(const void* x, int ldx, const void* dy, int lddy, int N, int 
     const int Q = a.TH * a.TW * a.C;
     const int stem_grid = stem ? hdy_wgrad_stem_grid(N, a.Ho, a.Wo, K, dtype) : 0;
     int rc;
-    if (stem_grid > 0) {
+    if (!stem && R == 3 && S == 3 && pad == 1 &&
+        hdy_wgrad3x3_try(x, ldx, dy, lddy, N, H, W, a.Ho, a.Wo, C, K, stride, a.partial, dtype, (hipStream_t)stream, &a.splits, &rc)) {
+        // patch-resident kernel launched (conv_wgrad3x3.hip)
+    } else if (stem_grid > 0) {
         a.splits = stem_grid;
         rc = hdy_wgrad_stem_launch(a, stem_grid, (hipStream_t)stream);
     } else {

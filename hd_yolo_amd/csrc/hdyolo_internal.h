@@ -53,3 +53,6 @@ int hdy_conv_stem_slabs(int N, int H, int W, int K, int dtype);
 int hdy_conv_igemm_launch(ConvArgs a, int dtype, int out_f32, hipStream_t st);
 int hdy_wgrad_launch(WgradArgs a, int dtype, hipStream_t st);
 int hdy_wgrad_plan(int K, int Q, long long P, int dtype, int* splits, int* pix_per_split);
+size_t hdy_wgrad3x3_workspace_bytes(int N, int Ho, int Wo, int C, int K, int stride, int dtype);
+int hdy_wgrad3x3_try(const void* x, int ldx, const void* dy, int lddy, int N, int Hin, int Win, int Ho, int Wo, int C, int K, int stride, float* partial,
+                     int dtype, hipStream_t st, int* splits, int* rc);
