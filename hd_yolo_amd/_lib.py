@@ -34,6 +34,12 @@ SIGNATURES = {
     'hdy_conv_dgrad': (_I, [_P, _I, _P, _P, _I] + [_I] * 11 + [_P]),
     'hdy_conv_wgrad_workspace_bytes': (_Z, [_I] * 11),
     'hdy_conv_wgrad': (_I, [_P, _I, _P, _I] + [_I] * 9 + [_P, _I, _P, _I, _I, _P, _Z, _I, _I, _P]),
+    'hdy_conv_dgrad_stat_slabs': (_I, [_I] * 10),
+    'hdy_conv_dgrad_stats': (_I, [_P, _I, _P, _P, _I] + [_I] * 11 + [_P, _I, _P]),
+    'hdy_conv1x1_bwd_fused_stats': (_I, [_P, _I, _P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P, _I, _P, _I, _I, _L, _I, _I, _P, _Z, _I, _P, _I, _P]),
+    'hdy_bn_bwd_finalize_slabs': (_I, [_P, _I, _I, _L, _P, _P, _P, _P, _I, _P, _P, _P]),
+    'hdy_conv1x1_bwd_fused_stat_slabs': (_I, [_L, _I, _I, _I]),
+    'hdy_bn_act_bwd_apply': (_I, [_P, _I, _P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P]),
     'hdy_conv1x1_bwd_fused_ok': (_I, [_I, _I, _I]),
     'hdy_conv1x1_bwd_fused_grid': (_I, [_L, _I]),
     'hdy_conv1x1_bwd_fused_workspace_bytes': (_Z, [_L, _I, _I]),
@@ -90,6 +96,12 @@ class PackDesc(ctypes.Structure):
 class BnEvalDesc(ctypes.Structure):
     """mirror of hdy_bn_eval_desc (include/hdyolo.h)"""
     _fields_ = [(n, c_void_p) for n in ('gamma', 'beta', 'running_mean', 'running_var', 'scale', 'shift')] + [('K', c_int), ('eps', c_float)]
+
+
+class StatReq(ctypes.Structure):
+    """mirror of hdy_stat_req (include/hdyolo.h)"""
+    _fields_ = [('y', c_void_p), ('ldy', c_int)] + [(n, c_void_p) for n in ('scale', 'shift', 'slabs')] + \
+               [('c0', c_int), ('c1', c_int), ('act', c_int)]
 
 
 _lib = None

@@ -12,7 +12,7 @@ def describe(rec):
         N, H, W, C, K, R, S_, st, pad = a[10:19]
         Ho, Wo = ops.out_dim(H, R, st, pad), ops.out_dim(W, S_, st, pad)
         return f'fwd  {C:4d}->{K:4d} k{R} s{st} @{H}x{W}', 2.0 * N * Ho * Wo * K * C * R * S_, 2.0 * (N * H * W * C + N * Ho * Wo * K)
-    if name == 'hdy_conv_dgrad':
+    if name in ('hdy_conv_dgrad', 'hdy_conv_dgrad_stats'):
         N, H, W, C, K, R, S_, st, pad = a[5:14]
         Ho, Wo = ops.out_dim(H, R, st, pad), ops.out_dim(W, S_, st, pad)
         return f'dgrd {C:4d}<-{K:4d} k{R} s{st} @{H}x{W}', 2.0 * N * Ho * Wo * K * C * R * S_, 2.0 * (N * H * W * C + N * Ho * Wo * K)
@@ -28,9 +28,12 @@ def describe(rec):
         if a[8] is None:
             return f'bnst K={K} M={M}', 0.0, 2.0 * M * K * 2
         return f'bnbw K={K} M={M}', 0.0, 2.0 * M * K * 5
-    if name == 'hdy_conv1x1_bwd_fused':
+    if name in ('hdy_conv1x1_bwd_fused', 'hdy_conv1x1_bwd_fused_stats'):
         M, C, K = a[24], a[25], a[26]
         return f'f1x1 {C:4d}<>{K:4d} M={M}' + (' acc' if a[18] else ''), 4.0 * M * K * C, 2.0 * M * (2 * K + (3 if a[18] else 2) * C)
+    if name == 'hdy_bn_act_bwd_apply':
+        M, K = a[15], a[16]
+        return f'bnap K={K} M={M}', 0.0, 2.0 * M * K * 3
     if name == 'hdy_bn_act_fwd_pair':
         M, K = a[9], a[10]
         return f'bnfw K={K} M={M} (pair)', 0.0, 2.0 * M * K * 2
@@ -78,7 +81,7 @@ def conv3x3_table(plan, peak_tflops=2500.0, reps=8):
     """Every 3x3 convolution launch (forward, and data gradient) of a plan timed alone: [(label, us, TFLOP/s, fraction of peak)]"""
     rows, seen = [], set()
     for rec in flat_records(plan.fwd) + flat_records(plan.bwd):
-        if rec[0] not in ('hdy_conv_fwd', 'hdy_conv_dgrad'):
+        if rec[0] not in ('hdy_conv_fwd', 'hdy_conv_dgrad', 'hdy_conv_dgrad_stats'):
             continue
         label, fl, _ = describe(rec)
         if ' k3 ' not in label or label in seen:

@@ -186,8 +186,33 @@ int hdy_conv_fwd(const void* x, int ldx, const void* w_packed, const float* scal
 }
 
 // dx (+)= conv_transpose(dy, w): dx is [N][H][W][lddx] (C channels), dy is [N][Ho][Wo][lddy] (K channels).
+static int dgrad_impl(const void* dy, int lddy, const void* w_packed_dgrad, void* dx, int lddx, int N, int H, int W, int C, int K, int R,
+                      int S, int stride, int pad, int accumulate, int dtype, const hdy_stat_req* stats, int nstat, void* stream);
+
 int hdy_conv_dgrad(const void* dy, int lddy, const void* w_packed_dgrad, void* dx, int lddx, int N, int H, int W, int C, int K, int R,
                    int S, int stride, int pad, int accumulate, int dtype, void* stream) {
+    return dgrad_impl(dy, lddy, w_packed_dgrad, dx, lddx, N, H, W, C, K, R, S, stride, pad, accumulate, dtype, nullptr, 0, stream);
+}
+
+int hdy_conv_dgrad_stats(const void* dy, int lddy, const void* w_packed_dgrad, void* dx, int lddx, int N, int H, int W, int C, int K, int R,
+                         int S, int stride, int pad, int accumulate, int dtype, const hdy_stat_req* stats, int nstat, void* stream) {
+    HDY_ARG(nstat >= 0 && nstat <= 2 && (nstat == 0 || stats), "conv_dgrad_stats: bad request count");
+    HDY_ARG(nstat == 0 || hdy_conv_dgrad_stat_slabs(N, H, W, C, K, R, S, stride, pad, dtype) > 0, "conv_dgrad_stats: this shape cannot serve statistics");
+    return dgrad_impl(dy, lddy, w_packed_dgrad, dx, lddx, N, H, W, C, K, R, S, stride, pad, accumulate, dtype, stats, nstat, stream);
+}
+
+// workgroups of the data-gradient launch that would serve statistics: stride 1, or stride 2 as ONE class-walking launch (even H, W)
+int hdy_conv_dgrad_stat_slabs(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dtype) {
+    if (dtype != HDY_BF16 || C % 8 || (stride != 1 && stride != 2)) return 0;
+    if (stride == 1) return hdy_conv_igemm_stat_grid((long long)N * H * W, C, R * S, 1);
+    if (H % 2 || W % 2 || getenv("HDY_NO_CLASS_WALK")) return 0;
+    for (int a = 0; a < 2; ++a)
+        if (!class_axis(R, pad, a).taps || !class_axis(S, pad, a).taps) return 0;
+    return hdy_conv_igemm_stat_grid((long long)N * (H / 2) * (W / 2), C, 1, 4);
+}
+
+static int dgrad_impl(const void* dy, int lddy, const void* w_packed_dgrad, void* dx, int lddx, int N, int H, int W, int C, int K, int R,
+                      int S, int stride, int pad, int accumulate, int dtype, const hdy_stat_req* stats, int nstat, void* stream) {
     HDY_ARG(stride == 1 || stride == 2, "conv_dgrad: stride %d unsupported", stride);
     HDY_ARG(dtype == HDY_BF16 || dtype == HDY_F32, "conv_dgrad: unknown dtype %d", dtype);
     const int Ho = hdy_conv_out_dim(H, R, stride, pad), Wo = hdy_conv_out_dim(W, S, stride, pad);
@@ -196,6 +221,9 @@ int hdy_conv_dgrad(const void* dy, int lddy, const void* w_packed_dgrad, void* d
     a.x = dy; a.y = dx; a.N = N; a.Hin = Ho; a.Win = Wo; a.C = K; a.ldx = lddy;
     a.K = C; a.ldy = lddx; a.Hout = H; a.Wout = W;
     a.ih_mul = a.iw_mul = 1; a.accumulate = accumulate;
+    a.nstat = nstat;
+    for (int r = 0; r < nstat; ++r)
+        a.stat[r] = StatReq{stats[r].y, stats[r].ldy, stats[r].scale, stats[r].shift, stats[r].slabs, stats[r].c0, stats[r].c1, stats[r].act};
     if (stride == 1) {
         a.w = w_packed_dgrad;
         a.Ho = H; a.Wo = W; a.oh_mul = a.ow_mul = 1; a.dense_out = 1;

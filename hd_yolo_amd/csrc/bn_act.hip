@@ -311,7 +311,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restr
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblocks, int K, double count,
                                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                float* __restrict__ dgamma_b, float* __restrict__ dbeta_b, int Ka, int accumulate,
-                                                               float* __restrict__ c1, float* __restrict__ c2) {
+                                                               float* __restrict__ c1, float* __restrict__ c2,
+                                                               const float* __restrict__ mean = nullptr, const float* __restrict__ invstd = nullptr) {
     __shared__ double red[2][32][33];
     const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
     const int k = blockIdx.x * 32 + cl;
@@ -342,6 +343,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
     if (tl == 0 && k < K) {
         s1 = 0.0; s2 = 0.0;
         for (int t = 0; t < 32; ++t) { s1 += red[0][t][cl]; s2 += red[1][t][cl]; }
+        if (mean) s2 = (double)invstd[k] * (s2 - (double)mean[k] * s1);      // slabs of (SUM du, SUM du*y) from a producer's epilogue
         float* const db = k < Ka ? dbeta : dbeta_b;      // parameter gradients of the pair's second module
         float* const dg = k < Ka ? dgamma : dgamma_b;
         const int kk = k < Ka ? k : k - Ka;
@@ -607,6 +609,30 @@ static int bn_act_bwd_impl(const Split& dz, const void* y, int ldy, const float*
     if (!dy) return HDY_OK;                               // statistics only: the consumer applies c1 / c2 itself (conv1x1_bwd.hip)
     if (dtype == HDY_BF16) bn_bwd_apply_launch<bf16_t, false>(g2, st, dz, y, ldy, scale, shift, mean, invstd, c1, c2, dy, lddy, (int)M, K, act);
     else bn_bwd_apply_launch<float, false>(g2, st, dz, y, ldy, scale, shift, mean, invstd, c1, c2, dy, lddy, (int)M, K, act);
+    HDY_LAUNCH_CHECK("bn_act_bwd_apply");
+    return HDY_OK;
+}
+
+int hdy_bn_bwd_finalize_slabs(const float* slabs, int nslabs, int K, long long count, const float* mean, const float* invstd, float* dgamma,
+                              float* dbeta, int accumulate, float* c1, float* c2, void* stream) {
+    HDY_ARG(slabs && nslabs > 0 && K > 0 && count > 0 && mean && invstd, "bn_bwd_finalize_slabs: bad args");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(K, 32)), dim3(1024), 0, (hipStream_t)stream, slabs, nslabs, K, (double)count, dgamma, dbeta,
+                       (float*)nullptr, (float*)nullptr, K, accumulate, c1, c2, mean, invstd);
+    HDY_LAUNCH_CHECK("bn_bwd_finalize_slabs");
+    return HDY_OK;
+}
+
+int hdy_bn_act_bwd_apply(const void* dz, int lddz, const void* dz_b, int lddz_b, int Ka, const void* y, int ldy, const float* scale,
+                         const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2, void* dy, int lddy,
+                         long long M, int K, int act, int dtype, void* stream) {
+    const int VE = dtype == HDY_BF16 ? 8 : 4;
+    HDY_ARG(dz && y && dy && scale && shift && mean && invstd && c1 && c2 && M_OK(M) && K > 0 && (act == 0 || act == 1), "bn_act_bwd_apply: bad args");
+    HDY_ARG(K % VE == 0 && VEC_OK(dz, lddz, VE) && VEC_OK(y, ldy, VE) && VEC_OK(dy, lddy, VE), "bn_act_bwd_apply: K/pitch/alignment must be multiples of one 16-byte vector");
+    HDY_ARG(Ka == K || (Ka > 0 && Ka < K && Ka % VE == 0 && dz_b && VEC_OK(dz_b, lddz_b, VE)), "bn_act_bwd_apply: bad gradient split");
+    const Split src = {dz, lddz, dz_b, lddz_b, Ka};
+    const int g2 = stream_grid(M, K / VE);
+    if (dtype == HDY_BF16) bn_bwd_apply_launch<bf16_t, false>(g2, (hipStream_t)stream, src, y, ldy, scale, shift, mean, invstd, c1, c2, dy, lddy, (int)M, K, act);
+    else bn_bwd_apply_launch<float, false>(g2, (hipStream_t)stream, src, y, ldy, scale, shift, mean, invstd, c1, c2, dy, lddy, (int)M, K, act);
     HDY_LAUNCH_CHECK("bn_act_bwd_apply");
     return HDY_OK;
 }

@@ -47,6 +47,8 @@ struct FusedArgs {
     float* partial;                   // [gridDim.x][K][C]
     int M, K, C;
     int do_dgrad, do_wgrad;
+    int nstat;                        // producer-side BatchNorm-backward statistics of the tensor(s) whose gradient dx completes
+    StatReq stat[2];
 };
 
 __device__ __forceinline__ int fsw3(int row) { return (row & 6) ^ (((row >> 3) & 1) * 5); }
@@ -144,6 +146,19 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_kernel(const FusedArgs p) 
                                                  (void __attribute__((address_space(3)))*)(dst + s * SUB + q * 1024), 16, 0, 0);
             }
     };
+
+    // statistics served by the dx store loop (instances up to 64 channels: the 128-wide one has no registers to spare): a thread owns
+    // one 16-byte channel chunk of dx for the whole launch
+    constexpr bool STATS_OK = CT <= 64;
+    float bs1[8], bs2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bs1[e] = bs2[e] = 0.f;
+    int st_req = -1;
+    {
+        const int kc0 = (tid % (CT * 2 / 16)) * 8;
+        for (int r = 0; r < p.nstat; ++r)
+            if (kc0 >= p.stat[r].c0 && kc0 < p.stat[r].c1) st_req = r;
+    }
 
     f32x4 accw[MTW][NTW];
 #pragma unroll
@@ -264,11 +279,36 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_kernel(const FusedArgs p) 
             __syncthreads();
             const int cc = tid % CPR, rr = tid / CPR;
             bf16_t* const dx = (bf16_t*)p.dx;
+            const bf16_t* st_y = nullptr;
+            int st_ldy = 0, st_act = 0;
+            float st_sc[8], st_sh[8];
+            if constexpr (STATS_OK) {
+                if (st_req >= 0) {
+                    const StatReq& q = p.stat[st_req];
+                    const int o = cc * 8 - q.c0;
+                    st_y = (const bf16_t*)q.y + o;
+                    st_ldy = q.ldy;
+                    st_act = q.act;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        *(f32x4*)(st_sc + 4 * h) = *(const f32x4*)(q.scale + o + 4 * h);
+                        *(f32x4*)(st_sh + 4 * h) = *(const f32x4*)(q.shift + o + 4 * h);
+                    }
+                }
+            }
+            i32x4 ynext = {0, 0, 0, 0};                             // statistics: the next row's raw output is requested one row ahead
+            if constexpr (STATS_OK) {
+                if (st_y && t * BM + rr < p.M) ynext = *(const i32x4*)(st_y + (size_t)(t * BM + rr) * st_ldy);
+            }
 #pragma unroll 4
             for (int row = rr; row < BM; row += RPI) {
                 const int m = t * BM + row;
                 if (m >= p.M) break;
-                V16 v;
+                V16 v, yv;
+                yv.i = ynext;
+                if constexpr (STATS_OK) {
+                    if (st_y && row + RPI < BM && m + RPI < p.M) ynext = *(const i32x4*)(st_y + (size_t)(m + RPI) * st_ldy);
+                }
                 v.i = *(const i32x4*)(sD + row * ROWB + ((cc ^ ((row & SWM) >> 1)) << 4));
                 bf16_t* dst = dx + (size_t)m * p.lddx + cc * 8;
                 if (p.accumulate) {
@@ -278,11 +318,42 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_kernel(const FusedArgs p) 
                     for (int e = 0; e < 8; ++e) v.h[e] = (bf16_t)((float)v.h[e] + (float)q.h[e]);
                 }
                 *(i32x4*)dst = v.i;
+                if constexpr (STATS_OK) {
+                    if (st_y) {                                     // v = the final gradient of this pixel, as the consumer will read it
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float yy = (float)yv.h[e];
+                            float du = (float)v.h[e];
+                            if (st_act == 1) du *= dsilu_f(yy * st_sc[e] + st_sh[e]);
+                            bs1[e] += du;
+                            bs2[e] += du * yy;
+                        }
+                    }
+                }
             }
             __syncthreads();                                        // staging is free: the next tile's dy may be written
         }
     }
 
+    if (STATS_OK && p.nstat > 0) {
+        constexpr int CPR = CT * 2 / 16, RPI = 256 / CPR;
+        float* red = (float*)sD;                                     // [256][16]; D / staging are free
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { red[tid * 16 + e] = bs1[e]; red[tid * 16 + 8 + e] = bs2[e]; }
+        __syncthreads();
+        for (int j = tid; j < CPR * 16; j += 256) {
+            const int ch = j / 16, e16 = j - ch * 16;
+            float v = 0.f;
+            for (int r = 0; r < RPI; ++r) v += red[(r * CPR + ch) * 16 + e16];
+            const int kc = ch * 8 + (e16 & 7);
+            for (int r = 0; r < p.nstat; ++r)
+                if (kc >= p.stat[r].c0 && kc < p.stat[r].c1) {
+                    const int w = p.stat[r].c1 - p.stat[r].c0;
+                    p.stat[r].slabs[((size_t)blockIdx.x * 2 + (e16 >> 3)) * w + kc - p.stat[r].c0] = v;
+                }
+        }
+    }
     if (p.do_wgrad) {
         float* out = p.partial + (size_t)blockIdx.x * p.K * p.C;
 #pragma unroll
@@ -337,14 +408,43 @@ int hdy_conv1x1_bwd_fused_grid(long long M, int K) {
     return (int)(tiles < cap ? tiles : cap);
 }
 
+// slabs (= workgroups) a statistics-serving fused launch writes; 0: this instance does not serve statistics
+int hdy_conv1x1_bwd_fused_stat_slabs(long long M, int C, int K, int dtype) {
+    return hdy_conv1x1_bwd_fused_ok(C, K, dtype) && C <= 64 ? hdy_conv1x1_bwd_fused_grid(M, K) : 0;
+}
+
 size_t hdy_conv1x1_bwd_fused_workspace_bytes(long long M, int C, int K) {
     return (size_t)hdy_conv1x1_bwd_fused_grid(M, K) * K * C * sizeof(float);
 }
+
+static int fused_impl(const void* dz_a, int lddz_a, const void* dz_b, int lddz_b, int Ka, const void* y, int ldy, const float* scale,
+                      const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2, const void* x, int ldx,
+                      const void* w_packed_dgrad, void* dx, int lddx, int accumulate_dx, float* grad_a, int K_a, float* grad_b, int K_b,
+                      int accumulate_w, long long M, int C, int K, void* workspace, size_t ws_bytes, int dtype, const hdy_stat_req* stats, int nstat,
+                      void* stream);
 
 int hdy_conv1x1_bwd_fused(const void* dz_a, int lddz_a, const void* dz_b, int lddz_b, int Ka, const void* y, int ldy, const float* scale,
                           const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2, const void* x, int ldx,
                           const void* w_packed_dgrad, void* dx, int lddx, int accumulate_dx, float* grad_a, int K_a, float* grad_b, int K_b,
                           int accumulate_w, long long M, int C, int K, void* workspace, size_t ws_bytes, int dtype, void* stream) {
+    return fused_impl(dz_a, lddz_a, dz_b, lddz_b, Ka, y, ldy, scale, shift, mean, invstd, c1, c2, x, ldx, w_packed_dgrad, dx, lddx, accumulate_dx, grad_a, K_a,
+                      grad_b, K_b, accumulate_w, M, C, K, workspace, ws_bytes, dtype, nullptr, 0, stream);
+}
+
+int hdy_conv1x1_bwd_fused_stats(const void* dz_a, int lddz_a, const void* dz_b, int lddz_b, int Ka, const void* y, int ldy, const float* scale,
+                                const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2, const void* x, int ldx,
+                                const void* w_packed_dgrad, void* dx, int lddx, int accumulate_dx, float* grad_a, int K_a, float* grad_b, int K_b,
+                                int accumulate_w, long long M, int C, int K, void* workspace, size_t ws_bytes, int dtype, const hdy_stat_req* stats,
+                                int nstat, void* stream) {
+    return fused_impl(dz_a, lddz_a, dz_b, lddz_b, Ka, y, ldy, scale, shift, mean, invstd, c1, c2, x, ldx, w_packed_dgrad, dx, lddx, accumulate_dx, grad_a, K_a,
+                      grad_b, K_b, accumulate_w, M, C, K, workspace, ws_bytes, dtype, stats, nstat, stream);
+}
+
+static int fused_impl(const void* dz_a, int lddz_a, const void* dz_b, int lddz_b, int Ka, const void* y, int ldy, const float* scale,
+                          const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2, const void* x, int ldx,
+                          const void* w_packed_dgrad, void* dx, int lddx, int accumulate_dx, float* grad_a, int K_a, float* grad_b, int K_b,
+                      int accumulate_w, long long M, int C, int K, void* workspace, size_t ws_bytes, int dtype, const hdy_stat_req* stats, int nstat,
+                      void* stream) {
     HDY_ARG(hdy_conv1x1_bwd_fused_ok(C, K, dtype), "conv1x1_bwd_fused: no kernel for C=%d K=%d dtype=%d", C, K, dtype);
     HDY_ARG(dz_a && y && scale && shift && mean && invstd && c1 && c2 && x && M > 0 && M < (1LL << 31), "conv1x1_bwd_fused: bad args");
     HDY_ARG(Ka == K || (Ka > 0 && Ka < K && Ka % 8 == 0 && dz_b), "conv1x1_bwd_fused: bad gradient split Ka=%d", Ka);
@@ -362,6 +462,15 @@ int hdy_conv1x1_bwd_fused(const void* dz_a, int lddz_a, const void* dz_b, int ld
     a.partial = (float*)workspace;
     a.M = (int)M; a.K = K; a.C = C;
     a.do_dgrad = dx != nullptr; a.do_wgrad = grad_a != nullptr;
+    HDY_ARG(nstat >= 0 && nstat <= 2 && (nstat == 0 || (stats && dx)), "conv1x1_bwd_fused: statistics requests need dx");
+    a.nstat = nstat;
+    for (int r = 0; r < nstat; ++r) {
+        const hdy_stat_req& q = stats[r];
+        HDY_ARG(q.y && q.scale && q.shift && q.slabs && q.c0 >= 0 && q.c0 < q.c1 && q.c1 <= C && q.c0 % 8 == 0 && q.c1 % 8 == 0 &&
+                q.ldy % 8 == 0 && (((uintptr_t)q.y | (uintptr_t)q.scale | (uintptr_t)q.shift) & 15) == 0 && C <= 64,
+                "conv1x1_bwd_fused: bad statistics request %d (served up to 64 channels)", r);
+        a.stat[r] = StatReq{q.y, q.ldy, q.scale, q.shift, q.slabs, q.c0, q.c1, q.act};
+    }
     const int grid = hdy_conv1x1_bwd_fused_grid(M, K);
     hipStream_t st = (hipStream_t)stream;
     int rc;

@@ -70,9 +70,11 @@ __device__ __forceinline__ void glds16(const void* g, unsigned char* lds_wave_ba
 //   <128, *, 2>  4 waves, 2 stages: many small workgroups per CU (K <= 64, small problems)
 //   <256, *, 3>  8 waves (2 per SIMD), 3 stages with counted vmcnt: half the filter re-fetch per output, two k-blocks of
 //                DMA in flight across the barrier, one workgroup per CU (the K >= 128 layers, which were L2-fetch bound)
-template <typename T, typename OT, int BM, int BN, int NS>
+// STAT: the epilogue also serves p.stat[] (BatchNorm-backward statistics of the tensor whose gradient this launch completes)
+template <typename T, typename OT, int BM, int BN, int NS, bool STAT = false>
 // second bound = waves per SIMD the LDS footprint allows (2 / 3 / 4 co-resident 4-wave workgroups, 1 x 8 waves): caps the VGPRs there
-__global__ __launch_bounds__(2 * BM, (BM == 256 || BN == 128) ? 2 : (BN == 64 ? 3 : 4)) void conv_igemm_kernel(const ConvArgs p) {
+// (STAT instances: 2 — the statistics operands of the store loop do not fit the 128 / 168 registers of 4 / 3 waves per SIMD)
+__global__ __launch_bounds__(2 * BM, (BM == 256 || BN == 128 || STAT) ? 2 : (BN == 64 ? 3 : 4)) void conv_igemm_kernel(const ConvArgs p) {
     constexpr int NTHR = 2 * BM;
     constexpr int VE = Traits<T>::VE;
     constexpr int BKE = 8 * VE;          // elements per 128-byte k-block
@@ -233,6 +235,18 @@ __global__ __launch_bounds__(2 * BM, (BM == 256 || BN == 128) ? 2 : (BN == 64 ? 
 #pragma unroll
         for (int r = 0; r < 4; ++r) s1[b][r] = s2[b][r] = 0.f;
 
+    // ---- producer-side BatchNorm-backward statistics (STAT): a thread of the coalesced store loop owns ONE 16-byte channel chunk for the
+    // whole launch (single column tile), so its 8 + 8 partial sums stay in registers across all of the workgroup's tiles
+    float bs1[8], bs2[8];
+    int st_req = -1;
+    if constexpr (STAT) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bs1[e] = bs2[e] = 0.f;
+        const int kc0 = (tid % (BN * 2 / 16)) * 8;
+        for (int r = 0; r < p.nstat; ++r)
+            if (kc0 >= p.stat[r].c0 && kc0 < p.stat[r].c1) st_req = r;
+    }
+
     // lane-local sums -> [BM/64 wave rows][BN][2] in `red` (16 pixel lanes by shuffles)
     auto stats_to_lds = [&](float* red, float (&u1)[NT][4], float (&u2)[NT][4]) {
 #pragma unroll
@@ -367,17 +381,44 @@ __global__ __launch_bounds__(2 * BM, (BM == 256 || BN == 128) ? 2 : (BN == 64 ? 
                 __syncthreads();
                 const int ch = tid % CPR, rr = tid / CPR;
                 const int kc = n0 + ch * 8;
+                // statistics operands of this thread's chunk: the unit's raw output row pointer and its 2 x 8 coefficients (L1-hot)
+                const bf16_t* st_y = nullptr;
+                int st_ldy = 0, st_act = 0;
+                float st_sc[8], st_sh[8];
+                if constexpr (STAT) {
+                    if (st_req >= 0) {
+                        const StatReq& q = p.stat[st_req];
+                        const int o = kc - q.c0;
+                        st_y = (const bf16_t*)q.y + o;
+                        st_ldy = q.ldy;
+                        st_act = q.act;
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            *(f32x4*)(st_sc + 4 * h) = *(const f32x4*)(q.scale + o + 4 * h);
+                            *(f32x4*)(st_sh + 4 * h) = *(const f32x4*)(q.shift + o + 4 * h);
+                        }
+                    }
+                }
                 if (kc < p.K) {
+                    auto pixel = [&](int m) -> size_t {
+                        if (p.dense_out) return (size_t)m;
+                        const int n = m / HoWo, rem = m - n * HoWo;
+                        const int oi = rem / p.Wo, oj = rem - oi * p.Wo;
+                        return ((size_t)n * p.Hout + (oh_off + oi * p.oh_mul)) * p.Wout + (ow_off + oj * p.ow_mul);
+                    };
+                    // statistics: the raw-output vector of the NEXT row is requested before this row is processed (one load in flight)
+                    i32x4 ynext = {0, 0, 0, 0};
+                    if constexpr (STAT) {
+                        if (st_y && m0 + pass * RPP + rr < p.M) ynext = *(const i32x4*)(st_y + pixel(m0 + pass * RPP + rr) * st_ldy);
+                    }
                     for (int row = rr; row < RPP; row += RPI) {
                         const int m = m0 + pass * RPP + row;
                         if (m >= p.M) break;
-                        size_t opix;
-                        if (p.dense_out) {
-                            opix = (size_t)m;
-                        } else {
-                            const int n = m / HoWo, rem = m - n * HoWo;
-                            const int oi = rem / p.Wo, oj = rem - oi * p.Wo;
-                            opix = ((size_t)n * p.Hout + (oh_off + oi * p.oh_mul)) * p.Wout + (ow_off + oj * p.ow_mul);
+                        const size_t opix = pixel(m);
+                        V16 yv;
+                        yv.i = ynext;
+                        if constexpr (STAT) {
+                            if (st_y && row + RPI < RPP && m + RPI < p.M) ynext = *(const i32x4*)(st_y + pixel(m + RPI) * st_ldy);
                         }
                         const int chunk = ch ^ ((row & SWM) >> 1);
                         V16 v;
@@ -402,6 +443,22 @@ __global__ __launch_bounds__(2 * BM, (BM == 256 || BN == 128) ? 2 : (BN == 64 ? 
                             for (int e = 0; e < 8; ++e) v.h[e] = (bf16_t)f[e];
                         }
                         *(i32x4*)((bf16_t*)p.y + opix * p.ldy + kc) = v.i;
+                        if constexpr (STAT) {
+                            if (st_y) {                    // v is the FINAL gradient of this pixel (bf16, as the apply pass will read it)
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) {
+                                    const float yy = (float)yv.h[e];
+                                    float du = (float)v.h[e];
+                                    if (st_act == 1) {
+                                        const float u = yy * st_sc[e] + st_sh[e];
+                                        const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-u));
+                                        du *= sg * (1.0f + u * (1.0f - sg));
+                                    }
+                                    bs1[e] += du;
+                                    bs2[e] += du * yy;
+                                }
+                            }
+                        }
                     }
                 }
                 __syncthreads();
@@ -517,6 +574,26 @@ __global__ __launch_bounds__(2 * BM, (BM == 256 || BN == 128) ? 2 : (BN == 64 ? 
             if (walk) c_nkb = p.c_nkb[c_tile & 3];
         }
     }
+    if constexpr (STAT) {
+        // one slab [2][c1 - c0] per workgroup and request: the RPI threads that share a channel chunk are summed through LDS
+        constexpr int CPR = BN * 2 / 16, RPI = NTHR / CPR;
+        float* red = (float*)smem;                 // [NTHR][16]: every stage has been consumed
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { red[tid * 16 + e] = bs1[e]; red[tid * 16 + 8 + e] = bs2[e]; }
+        __syncthreads();
+        for (int j = tid; j < CPR * 16; j += NTHR) {
+            const int ch = j / 16, e16 = j - ch * 16;
+            float v = 0.f;
+            for (int r = 0; r < RPI; ++r) v += red[(r * CPR + ch) * 16 + e16];
+            const int kc = ch * 8 + (e16 & 7);
+            for (int r = 0; r < p.nstat; ++r)
+                if (kc >= p.stat[r].c0 && kc < p.stat[r].c1) {
+                    const int w = p.stat[r].c1 - p.stat[r].c0;
+                    p.stat[r].slabs[((size_t)blockIdx.x * 2 + (e16 >> 3)) * w + kc - p.stat[r].c0] = v;
+                }
+        }
+    }
     if (wg_stats) {
         // one slab per workgroup (index = its position in the XCD-aware order): 16 pixel lanes -> wave rows -> global
         float* red = (float*)smem;                 // every stage has been consumed
@@ -555,16 +632,16 @@ inline bool igemm_big(long long M, int bn, int ntiles, int taps) {
     return bn == 128 && taps > 1 && (M + 255) / 256 * ntiles >= 4096 && !no_big;
 }
 
-template <typename T, typename OT, int BM, int BN, int NS>
+template <typename T, typename OT, int BM, int BN, int NS, bool STAT = false>
 int launch(const ConvArgs& a, hipStream_t st) {
     const size_t smem = (size_t)NS * (BM * 128 + BN * 128) + (BN > 32 ? 2 * BN * sizeof(float) : 0);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, OT, BM, BN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, OT, BM, BN, NS, STAT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
     }
     const int grid = igemm_grid(a.M, a.ntiles * (a.ncls > 1 ? 4 : 1), BM, BN, NS);
-    hipLaunchKernelGGL((conv_igemm_kernel<T, OT, BM, BN, NS>), dim3(grid), dim3(2 * BM), smem, st, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, OT, BM, BN, NS, STAT>), dim3(grid), dim3(2 * BM), smem, st, a);
     HDY_LAUNCH_CHECK("conv_igemm");
     return HDY_OK;
 }
@@ -572,6 +649,12 @@ int launch(const ConvArgs& a, hipStream_t st) {
 template <typename T, typename OT>
 int launch_bn(const ConvArgs& a, hipStream_t st) {
     const bool big = a.ncls <= 1 && igemm_big(a.M, a.bn, a.ntiles, a.TH * a.TW);
+    if constexpr (std::is_same<T, bf16_t>::value && std::is_same<OT, bf16_t>::value) {
+        if (a.nstat > 0) {                         // producer-side BatchNorm-backward statistics (dgrad launches, <= 64 output channels)
+            if (a.bn == 32) return launch<T, OT, 128, 32, 2, true>(a, st);
+            return launch<T, OT, 128, 64, 2, true>(a, st);
+        }
+    }
     switch (a.bn) {
         case 32: return launch<T, OT, 128, 32, 2>(a, st);
         case 64: return launch<T, OT, 128, 64, 2>(a, st);
@@ -594,6 +677,13 @@ int hdy_conv_igemm_slabs(long long M, int K, int taps) {
     const long long tiles = (M + BM - 1) / BM;
     const long long tpb = (tiles + grid - 1) / grid;
     return (int)((tiles + tpb - 1) / tpb);
+}
+
+// Workgroups (= statistics slabs) a dgrad launch with producer-side statistics uses; 0 when the shape cannot serve them.
+int hdy_conv_igemm_stat_grid(long long M, int K, int taps, int ncls) {
+    const int bn = hdy_conv_bn_tile(K);
+    if (bn > 64 || K % 8) return 0;               // the 128-wide instances have no registers to spare for the statistics operands
+    return igemm_grid(M, ncls > 1 ? 4 : 1, 128, bn, 2);
 }
 
 // Host-side validation + dispatch shared by the C-ABI entry points (api.hip).
@@ -627,8 +717,17 @@ int hdy_conv_igemm_launch(ConvArgs a, int dtype, int out_f32, hipStream_t st) {
     const bool bf16_out = dtype == HDY_BF16 && !out_f32;
     a.vec_out = (bf16_out && a.K % 8 == 0 && a.ldy % 8 == 0 && ((uintptr_t)a.y & 15) == 0 &&
                  (!a.res || (a.ldr % 8 == 0 && ((uintptr_t)a.res & 15) == 0))) ? 1 : 0;
+    if (a.nstat > 0) {
+        HDY_ARG(a.nstat <= 2 && a.vec_out && a.ntiles == 1 && a.bn <= 64 && !a.stats && !a.res, "conv: producer-side statistics need the bf16 vector epilogue and at most 64 output channels");
+        for (int r = 0; r < a.nstat; ++r) {
+            const StatReq& q = a.stat[r];
+            HDY_ARG(q.y && q.scale && q.shift && q.slabs && q.c0 >= 0 && q.c0 < q.c1 && q.c1 <= a.K && q.c0 % 8 == 0 && q.c1 % 8 == 0 &&
+                    q.ldy % 8 == 0 && (((uintptr_t)q.y | (uintptr_t)q.scale | (uintptr_t)q.shift) & 15) == 0,
+                    "conv: bad statistics request %d", r);
+        }
+    }
     int rc = 0;
-    if (a.ncls <= 1) {
+    if (a.ncls <= 1 && a.nstat == 0) {
         if (hdy_conv_stem_try(a, dtype, out_f32, st, &rc)) return rc;         // patch-resident 6x6/s2 stem
         if (hdy_conv3x3_c64_try(a, dtype, out_f32, st, &rc)) return rc;      // filter-resident 3x3 kernel when the shape qualifies
     }

@@ -2,6 +2,18 @@
 #pragma once
 #include "common.h"
 
+// BatchNorm-backward statistics requested from the kernel that produces a gradient tensor (its LAST contribution): for the output
+// channels [c0, c1) of the producer, which are the gradient dz of a Conv+BN+act unit's output, the epilogue also reads that unit's raw
+// conv output y (same pixels; channel c0 of the producer = channel 0 of y/scale/...) and accumulates SUM du and SUM du*xhat per channel
+// (du = dz * act'(y*scale + shift)) and SUM du*y into one fp32 slab [2][c1 - c0] per workgroup: slabs[wg][2][c1 - c0]; the finalize
+// launch turns SUM du*y into SUM du*xhat = invstd * (SUM du*y - mean * SUM du), so the epilogue needs two coefficient vectors, not four.
+struct StatReq {
+    const void* y; int ldy;
+    const float *scale, *shift;
+    float* slabs;
+    int c0, c1, act;
+};
+
 struct ConvArgs {
     const void* x;        // [N][Hin][Win][ldx]
     const void* w;        // packed [Kpad][Kdp]
@@ -24,6 +36,8 @@ struct ConvArgs {
     // Stride-2 dgrad as ONE launch: ncls = 4 parity classes of output pixels walked back to back per spatial tile (class = tile & 3).
     // Per class: tap window (c_TH x c_TW taps starting at dy offset c_dh / c_dw), k-blocks, output offsets, packed-weight offset (elements).
     // The scalar fields above (dh0, dw0, TH, TW, Kdp, oh_off, ow_off, w) hold class 0.  ncls <= 1: an ordinary launch.
+    int nstat;            // 0..2 statistics requests served by the epilogue (dgrad, bf16 vector epilogue, single column tile)
+    StatReq stat[2];
     int ncls;
     int c_dh[4], c_dw[4], c_TH[4], c_TW[4], c_nkb[4], c_oh[4], c_ow[4];
     long long c_w[4];
@@ -56,3 +70,4 @@ int hdy_wgrad_plan(int K, int Q, long long P, int dtype, int* splits, int* pix_p
 size_t hdy_wgrad3x3_workspace_bytes(int N, int Ho, int Wo, int C, int K, int stride, int dtype);
 int hdy_wgrad3x3_try(const void* x, int ldx, const void* dy, int lddy, int N, int Hin, int Win, int Ho, int Wo, int C, int K, int stride, float* partial,
                      int dtype, hipStream_t st, int* splits, int* rc);
+int hdy_conv_igemm_stat_grid(long long M, int K, int taps, int ncls);

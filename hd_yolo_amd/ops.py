@@ -146,11 +146,65 @@ def rec_conv_fwd(x, wp, y, K, R, S, stride, pad, scale=None, shift=None, stats=N
                              int(accumulate), dcode(x.dtype), out_f32, stem))
 
 
-def rec_conv_dgrad(dy, wp_d, dx, R, S, stride, pad, accumulate=False):
+class StatRequest:
+    """One producer-side BatchNorm-backward statistics request (hdy_stat_req): the producer's output channels [c0, c1) are the gradient
+    of a unit whose raw conv output is `y` (an NHWC view of exactly those c1 - c0 channels); slabs: fp32 [nslabs][2][c1 - c0]."""
+
+    def __init__(self, y, scale, shift, slabs, c0, act):
+        yp, _, _, _, K, ldy = nhwc(y)
+        for t in (scale, shift):
+            assert t.dtype == torch.float32 and t.numel() >= K and t.stride(0) == 1
+        assert slabs.dtype == torch.float32 and slabs.is_contiguous() and slabs.shape[1:] == (2, K)
+        self.c = _lib.StatReq(yp, ldy, ptr(scale), ptr(shift), ptr(slabs), c0, c0 + K, act)
+        self.keep = (y, scale, shift, slabs)
+
+
+def _stat_array(stats):
+    arr = (_lib.StatReq * len(stats))(*[q.c for q in stats])
+    return arr, ctypes.cast(arr, ctypes.c_void_p)
+
+
+def conv_dgrad_stat_slabs(N, H, W, C, K, R, S, stride, pad, dtype):
+    """workgroups (= statistics slabs) of the data-gradient launch of this shape; 0: it cannot serve statistics"""
+    return _lib.query('hdy_conv_dgrad_stat_slabs', N, H, W, C, K, R, S, stride, pad, dcode(dtype))
+
+
+def rec_conv_dgrad(dy, wp_d, dx, R, S, stride, pad, accumulate=False, stats=None):
     dyp, N, Ho, Wo, K, lddy = nhwc(dy)
     dxp, _, H, W, C, lddx = nhwc(dx)
     assert Ho == out_dim(H, R, stride, pad) and Wo == out_dim(W, S, stride, pad) and dy.dtype == dx.dtype
+    if stats:
+        arr, arrp = _stat_array(stats)
+        keep = [t for q in stats for t in q.keep]
+        return _rec(locals(), 'hdy_conv_dgrad_stats', (dyp, lddy, ptr(wp_d), dxp, lddx, N, H, W, C, K, R, S, stride, pad, int(accumulate), dcode(dy.dtype),
+                                                       arrp, len(stats))) + ((arr,),)
     return _rec(locals(), 'hdy_conv_dgrad', (dyp, lddy, ptr(wp_d), dxp, lddx, N, H, W, C, K, R, S, stride, pad, int(accumulate), dcode(dy.dtype)))
+
+
+def rec_bn_bwd_finalize_slabs(slabs, count, mean, invstd, dgamma, dbeta, c1, c2, accumulate=False):
+    """slabs [n][2][K] of (SUM du, SUM du*y) -> dbeta, dgamma = invstd*(SUM du*y - mean*SUM du) (+)=; c1 = dbeta / count, c2 = dgamma / count"""
+    n, _, K = slabs.shape
+    assert slabs.is_contiguous() and c1.numel() >= K and c2.numel() >= K and mean.numel() >= K and invstd.numel() >= K
+    return _rec(locals(), 'hdy_bn_bwd_finalize_slabs', (ptr(slabs), n, K, count, ptr(mean), ptr(invstd), ptr(dgamma), ptr(dbeta), int(accumulate),
+                                                        ptr(c1), ptr(c2)))
+
+
+def fused_1x1_stat_slabs(M, C, K, dtype):
+    return _lib.query('hdy_conv1x1_bwd_fused_stat_slabs', M, C, K, dcode(dtype))
+
+
+def rec_bn_act_bwd_apply(dz_a, dz_b, y, scale, shift, mean, invstd, c1, c2, dy, act=ACT_SILU):
+    dap, N, H, W, Ka, ldda = nhwc(dz_a)
+    dbp, lddb = None, 0
+    K = Ka
+    if dz_b is not None:
+        dbp, _, _, _, Kb, lddb = nhwc(dz_b)
+        K = Ka + Kb
+    yp, _, _, _, Ky, ldy = nhwc(y)
+    dyp, _, _, _, _, lddy = nhwc(dy)
+    assert Ky == K and y.shape == dy.shape and y.dtype == dy.dtype == dz_a.dtype
+    return _rec(locals(), 'hdy_bn_act_bwd_apply', (dap, ldda, dbp, lddb, Ka, yp, ldy, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(c1), ptr(c2),
+                                                  dyp, lddy, N * H * W, K, act, dcode(y.dtype)))
 
 
 def wgrad_ws_bytes(N, H, W, C, K, R, S, stride, pad, dtype, stem=False):
@@ -331,7 +385,7 @@ def fused_1x1_ws_bytes(M, C, K):
     return _lib.query('hdy_conv1x1_bwd_fused_workspace_bytes', M, C, K)
 
 
-def rec_conv1x1_bwd_fused(dz_a, dz_b, y, scale, shift, mean, invstd, c1, c2, x, wp_d, dx, grad_a, grad_b, ws, accumulate_dx=False):
+def rec_conv1x1_bwd_fused(dz_a, dz_b, y, scale, shift, mean, invstd, c1, c2, x, wp_d, dx, grad_a, grad_b, ws, accumulate_dx=False, stats=None):
     """One pass: dy from (dz, y, BatchNorm coefficients) -> dx (+)= dy*W and grad_a / grad_b = dy^T * x.  dx / grad_a may be None."""
     dap, N, H, W, Ka, ldda = nhwc(dz_a)
     dbp, lddb = None, 0
@@ -349,9 +403,13 @@ def rec_conv1x1_bwd_fused(dz_a, dz_b, y, scale, shift, mean, invstd, c1, c2, x, 
     K_a = 0 if grad_a is None else grad_a.shape[0]
     K_b = 0 if grad_b is None else grad_b.shape[0]
     assert grad_a is None or (grad_a.is_contiguous() and grad_a.dtype == torch.float32 and tuple(grad_a.shape[1:]) == (C, 1, 1))
-    return _rec(locals(), 'hdy_conv1x1_bwd_fused', (dap, ldda, dbp, lddb, Ka, yp, ldy, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(c1), ptr(c2),
-                                                    xp, ldx, ptr(wp_d), dxp, lddx, int(accumulate_dx), ptr(grad_a), K_a, ptr(grad_b), K_b, 0,
-                                                    N * H * W, C, K, ptr(ws), ws.numel() * ws.element_size(), dcode(x.dtype)))
+    args = (dap, ldda, dbp, lddb, Ka, yp, ldy, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(c1), ptr(c2), xp, ldx, ptr(wp_d), dxp, lddx,
+            int(accumulate_dx), ptr(grad_a), K_a, ptr(grad_b), K_b, 0, N * H * W, C, K, ptr(ws), ws.numel() * ws.element_size(), dcode(x.dtype))
+    if stats:
+        arr, arrp = _stat_array(stats)
+        keep = [t for q in stats for t in q.keep]
+        return _rec(locals(), 'hdy_conv1x1_bwd_fused_stats', args + (arrp, len(stats))) + ((arr,),)
+    return _rec(locals(), 'hdy_conv1x1_bwd_fused', args)
 
 
 def rec_colsum(dz, out, ws, accumulate=False):

@@ -28,6 +28,10 @@ from . import _lib, ops
 USE_GRAPHS = os.environ.get('HDY_GRAPH', '0') == '1'   # hipGraph replay of ~400-node graphs measured slower than eager on ROCm 7.2
 SIDE_WGRAD = os.environ.get('HDY_SIDE_WGRAD', '1') == '1' and not USE_GRAPHS      # weight gradients on a second stream
 DY_RING = int(os.environ.get('HDY_DY_RING', '4'))
+# BN-backward reduce pass served by the launch that completes dz ('1': fused 1x1 backward and dgrad launches, 'fused': the former only).
+# Built, parity-tested (tests/test_gpu_kernels.py, test_gpu_model.py) and NOT the default: the epilogues that would serve the statistics are
+# themselves VALU-bound (exp + rcp per element on top of the store loop) — yolov5s B=64 step 14.09 ms without, 14.31 ('fused'), 14.37 ('1').
+PRODUCER_STATS = os.environ.get('HDY_PRODUCER_STATS', '0')
 FUSED_1X1 = os.environ.get('HDY_FUSED_1X1', '1') == '1'     # BN-apply + wgrad + dgrad of eligible 1x1 units in one kernel (conv1x1_bwd.hip)
 GRAD_BUCKET_BYTES = int(os.environ.get('HDY_GRAD_BUCKET_MB', '6')) << 20      # granularity of the "these gradients are final" marks
 
@@ -379,6 +383,7 @@ class Plan:
         self.dy_ring = [self._new(max_dy) for _ in range(DY_RING if SIDE_WGRAD else 1)]
         self.dy = self.dy_ring[0]
         self.wg_ws = self._new(max_wg // 4 + 16, dtype=f32)
+        self.bn_c12 = self._new(2, kmax if False else max(u.K for u in self.units if isinstance(u, ConvUnit)), dtype=f32)     # c1 / c2 of the unit in flight
         self.f1_ws = self._new(max_f1 // 4 + 16, dtype=f32)      # weight-gradient slabs of the fused 1x1 backward (main stream: not shared with wg_ws)
         self.bn_ws = self._new(max_bnws, dtype=f32)
         kmax = max(u.K for u in self.units if isinstance(u, ConvUnit))
@@ -571,6 +576,17 @@ class Plan:
 
         slot_user = {}
         nconv = 0
+        # Producer-side statistics: `last[id(v)]` = the launch record that wrote the LAST contribution of v's gradient, when that is a
+        # data-gradient launch which can serve statistics (index into recs, channel offset of v inside the producer's output, how to
+        # rebuild the record with requests, slab count).  A unit whose outputs all have such a producer skips its reduce pass: the
+        # producers' epilogues leave (SUM du, SUM du*xhat) slabs and a finalize launch turns them into dgamma / dbeta / c1 / c2.
+        last, pending, remake = {}, {}, {}
+
+        def note_grad(xv, kind, idx=None, make=None, slabs=0):
+            for pv, off in ([(xv, 0)] if xv.parts is None else xv.parts):
+                last[id(pv)] = (kind, idx, off, slabs)
+            if idx is not None:
+                remake[idx] = make
 
         # Model.freeze: a tensor needs a gradient only if something trainable lies upstream of it; units without trainable
         # parameters below frozen inputs are skipped altogether, frozen filters skip their weight gradient
@@ -621,16 +637,21 @@ class Plan:
                 if not up(x):
                     continue
                 self.packs.add(u.conv.weight, None, 1, 0, ops.PACK_DGRAD, u.wpd, K=u.Kp)
-                recs.append(ops.rec_conv_dgrad(u.gdet, u.wpd, x.g(), 1, 1, 1, 0, accumulate=self._contrib(x)))
+                acc_x = self._contrib(x)
+                mk = (lambda st, u=u, x=x, acc_x=acc_x: ops.rec_conv_dgrad(u.gdet, u.wpd, x.g(), 1, 1, 1, 0, accumulate=acc_x, stats=st))
+                recs.append(mk(None))
+                note_grad(x, 'dgrad', len(recs) - 1, mk, ops.conv_dgrad_stat_slabs(x.n, x.h, x.w, x.c, u.Kp, 1, 1, 1, 0, self.dtype) if self.dtype == torch.bfloat16 else 0)
             elif isinstance(u, UpUnit):
                 if up(u.x):
                     recs.append(ops.rec_upsample_bwd(u.out.gread(), u.x.g(), accumulate=self._contrib(u.x)))
+                    note_grad(u.x, 'other')
             elif isinstance(u, PoolUnit):
                 a = u.x
                 if not up(a):
                     continue
                 gs = [a.g()] + [o.g() for o in u.outs]
                 recs.append(ops.rec_sppf_pool_bwd(gs[0], gs[1], gs[2], gs[3], u.idx, a.gfinal))
+                note_grad(a, 'other')
             elif isinstance(u, ConvUnit):
                 if not u.outs[0].needs_grad:
                     continue
@@ -644,15 +665,41 @@ class Plan:
                     if slot in slot_user:              # the weight gradient that last read this ring slot must be done
                         recs.append(('@join', side, slot_user.pop(slot)))
                     dy = self.dy_ring[slot][:o0.n * o0.h * o0.w * u.K].view(o0.n, o0.h, o0.w, u.K)
-                # BatchNorm / SiLU backward: statistics (reduce + finalize) and, unless the fused kernel applies them, dy
-                if pair:
+                # BatchNorm / SiLU backward: statistics (reduce + finalize) and, unless the fused kernel applies them, dy.
+                M = o0.n * o0.h * o0.w
+                c1, c2 = self.bn_c12[0, :u.K], self.bn_c12[1, :u.K]
+                prod = None
+                if PRODUCER_STATS != '0' and self.dtype == torch.bfloat16 and u.has_bn and not u.frozen and not USE_GRAPHS:
+                    prod = [last.get(id(o)) for o in u.outs]
+                    kinds = ('dgrad', 'fused') if PRODUCER_STATS == '1' else ('fused',)
+                    ok = all(q is not None and q[0] in kinds and q[3] > 0 and o.gfinal is None and o.c % 8 == 0 and q[2] % 8 == 0 and
+                             len(pending.get(q[1], [])) < 2 for q, o in zip(prod, u.outs))
+                    if ok and len(u.outs) == 2 and prod[0][1] == prod[1][1]:
+                        ok = len(pending.get(prod[0][1], [])) == 0
+                    if not ok:
+                        prod = None
+                if prod is not None:
+                    k0 = 0
+                    for m, o, (kind, idx, off, nslabs) in zip(u.mods, u.outs, prod):
+                        K = o.c
+                        slabs = self._new(nslabs, 2, K, dtype=torch.float32, zero=True)     # workgroups without tiles never write theirs
+                        pending.setdefault(idx, []).append(ops.StatRequest(u.yraw[..., k0:k0 + K], u.scale[k0:k0 + K], u.shift[k0:k0 + K], slabs, off, u.act))
+                        recs.append(ops.rec_bn_bwd_finalize_slabs(slabs, M, u.mean[k0:k0 + K], u.invstd[k0:k0 + K], self._grad_views(m.bn.weight),
+                                                                  self._grad_views(m.bn.bias), c1[k0:k0 + K], c2[k0:k0 + K]))
+                        k0 += K
+                    if not fused:
+                        recs.append(ops.rec_bn_act_bwd_apply(u.outs[0].gread(), u.outs[1].gread() if len(u.outs) > 1 else None, u.yraw, u.scale, u.shift, u.mean,
+                                                             u.invstd, c1, c2, dy, act=u.act))
+                elif pair:
                     ma, mb = u.mods
                     recs.append(ops.rec_bn_act_bwd_pair(u.outs[0].gread(), u.outs[1].gread(), u.yraw, u.scale, u.shift, u.mean, u.invstd, dy,
                                                         self._grad_views(ma.bn.weight), self._grad_views(ma.bn.bias),
                                                         self._grad_views(mb.bn.weight), self._grad_views(mb.bn.bias), self.bn_ws, act=u.act))
+                    if fused:
+                        c1, c2 = ops.bn_bwd_coeffs(self.bn_ws, M, u.K)
                 k0 = 0
                 for m, o in zip(u.mods, u.outs):
-                    if pair:
+                    if pair or prod is not None:
                         break
                     K = m.conv.out_channels
                     dyk = None if dy is None else dy[..., k0:k0 + K]
@@ -663,6 +710,8 @@ class Plan:
                         recs.append(ops.rec_bn_act_bwd(o.gread(), u.yraw[..., k0:k0 + K], u.scale[k0:k0 + K], u.shift[k0:k0 + K],
                                                        u.mean[k0:k0 + K], u.invstd[k0:k0 + K], dyk,
                                                        self._grad_views(m.bn.weight), self._grad_views(m.bn.bias), self.bn_ws, act=u.act))
+                        if fused:
+                            c1, c2 = ops.bn_bwd_coeffs(self.bn_ws, M, u.K)
                     k0 += K
                 x = self.prep if u.stem else u.x.t()
                 stem_hw = (self.H, self.W) if u.stem else None
@@ -682,20 +731,27 @@ class Plan:
                         acc = self._contrib(xv)
                 if fused:
                     if want_w or want_x:
-                        M = o0.n * o0.h * o0.w
-                        c1, c2 = ops.bn_bwd_coeffs(self.bn_ws, M, u.K)
                         ga = self._grad_views(u.mods[0].conv.weight) if want_w else None
                         gb = self._grad_views(u.mods[1].conv.weight) if want_w and len(u.mods) > 1 else None
-                        recs.append(ops.rec_conv1x1_bwd_fused(u.outs[0].gread(), u.outs[1].gread() if len(u.mods) > 1 else None, u.yraw, u.scale,
-                                                              u.shift, u.mean, u.invstd, c1, c2, x, u.wpd if want_x else None,
-                                                              xv.g() if want_x else None, ga, gb, self.f1_ws, accumulate_dx=acc))
+                        mk = (lambda st, u=u, x=x, xv=xv, c1=c1, c2=c2, ga=ga, gb=gb, acc=acc, want_x=want_x: ops.rec_conv1x1_bwd_fused(
+                            u.outs[0].gread(), u.outs[1].gread() if len(u.mods) > 1 else None, u.yraw, u.scale, u.shift, u.mean, u.invstd, c1, c2, x,
+                            u.wpd if want_x else None, xv.g() if want_x else None, ga, gb, self.f1_ws, accumulate_dx=acc, stats=st))
+                        recs.append(mk(None))
+                        if want_x:
+                            note_grad(xv, 'fused', len(recs) - 1, mk, ops.fused_1x1_stat_slabs(M, u.C, u.K, self.dtype))
                     continue
                 ga = self._grad_views(u.mods[0].conv.weight)
                 gb = self._grad_views(u.mods[1].conv.weight) if len(u.mods) > 1 else None
                 if want_w:
                     wgrad(ops.rec_conv_wgrad(x, dy, ga, gb, u.k, u.k, u.s, u.p, self.wg_ws, stem_hw=stem_hw), reads_dy_slot=slot)
                 if want_x:
-                    recs.append(ops.rec_conv_dgrad(dy, u.wpd, xv.g(), u.k, u.k, u.s, u.p, accumulate=acc))
+                    mk = (lambda st, u=u, dy=dy, xv=xv, acc=acc: ops.rec_conv_dgrad(dy, u.wpd, xv.g(), u.k, u.k, u.s, u.p, accumulate=acc, stats=st))
+                    recs.append(mk(None))
+                    note_grad(xv, 'dgrad', len(recs) - 1, mk,
+                              ops.conv_dgrad_stat_slabs(xv.n, xv.h, xv.w, xv.c, u.K, u.k, u.k, u.s, u.p, self.dtype) if self.dtype == torch.bfloat16 else 0)
+        for idx, reqs in pending.items():                   # rebuild the producers with the statistics requests they serve
+            recs[idx] = remake[idx](reqs)
+        self.producer_stat_units = sum(len(v) for v in pending.values())
         self._mark_buckets(recs, side)
         if side is not None and nfork[0]:
             recs.append(('@join', side, nfork[0] - 1))          # side-stream work is in order: the last fork covers all

@@ -98,6 +98,38 @@ int hdy_conv_wgrad(const void* x, int ldx, const void* dy, int lddy, int N, int 
  * hdy_bn_act_bwd(dy = NULL), computes dy = scale*(dz*silu'(u) - c1 - xhat*c2) on the fly and from it BOTH dx (+)= dy * W (NULL: skipped)
  * and the weight gradient grad_a / grad_b (+)= dy^T * x (NULL: skipped) in one pass: dy never goes to HBM.  bf16, C == K in {32, 64, 128}
  * (hdy_conv1x1_bwd_fused_ok); w_packed_dgrad = hdy_conv_pack(kind = HDY_PACK_DGRAD). */
+/* Producer-side BatchNorm-backward statistics.  The kernel that writes the LAST contribution of a gradient tensor (a data-gradient
+ * launch) can also serve the reduce pass of the Conv+BN+act unit(s) whose output gradient that tensor is: for its output channels
+ * [c0, c1) it reads the unit's raw conv output y (same pixels; channel c0 <-> element 0 of y / scale / shift), forms
+ * du = dz * act'(y*scale + shift) and writes per workgroup one fp32 slab [2][c1 - c0] = (SUM du, SUM du*y) to slabs[wg][2][c1-c0].
+ * hdy_bn_bwd_finalize_slabs (SUM du*xhat = invstd * (SUM du*y - mean * SUM du)) then gives dgamma / dbeta / c1 / c2 without the
+ * unit's own pass over dz and y.  Served by launches whose gradient is at most 64 channels wide (the wider instances have no
+ * registers to spare): hdy_conv_dgrad_stat_slabs / hdy_conv1x1_bwd_fused_stat_slabs return 0 otherwise.
+ * (reference: what autograd's BatchNorm backward reduces, metayolo/models/layers.py:37 under train.py:472) */
+typedef struct {
+    const void* y; int ldy;
+    const float *scale, *shift;
+    float* slabs;
+    int c0, c1, act;
+} hdy_stat_req;
+int hdy_conv1x1_bwd_fused_stat_slabs(long long M, int C, int K, int dtype);
+/* slabs a stats-serving launch writes (= its workgroups); 0: this shape cannot serve statistics */
+int hdy_conv_dgrad_stat_slabs(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dtype);
+int hdy_conv_dgrad_stats(const void* dy, int lddy, const void* w_packed_dgrad, void* dx, int lddx, int N, int H, int W, int C, int K, int R,
+                         int S, int stride, int pad, int accumulate, int dtype, const hdy_stat_req* stats, int nstat, void* stream);
+int hdy_conv1x1_bwd_fused_stats(const void* dz_a, int lddz_a, const void* dz_b, int lddz_b, int Ka, const void* y, int ldy, const float* scale,
+                                const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2, const void* x, int ldx,
+                                const void* w_packed_dgrad, void* dx, int lddx, int accumulate_dx, float* grad_a, int K_a, float* grad_b, int K_b,
+                                int accumulate_w, long long M, int C, int K, void* workspace, size_t ws_bytes, int dtype, const hdy_stat_req* stats,
+                                int nstat, void* stream);
+/* from `nslabs` slabs [2][K] of (SUM du, SUM du*y): dbeta (+)= SUM du, dgamma (+)= invstd * (SUM du*y - mean * SUM du);
+ * c1 = dbeta / count, c2 = dgamma / count (either may be NULL) */
+int hdy_bn_bwd_finalize_slabs(const float* slabs, int nslabs, int K, long long count, const float* mean, const float* invstd, float* dgamma,
+                              float* dbeta, int accumulate, float* c1, float* c2, void* stream);
+/* the apply pass alone: dy = scale * (dz*act'(u) - c1 - xhat*c2) with c1 / c2 given */
+int hdy_bn_act_bwd_apply(const void* dz, int lddz, const void* dz_b, int lddz_b, int Ka, const void* y, int ldy, const float* scale,
+                         const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2, void* dy, int lddy,
+                         long long M, int K, int act, int dtype, void* stream);
 int hdy_conv1x1_bwd_fused_ok(int C, int K, int dtype);
 int hdy_conv1x1_bwd_fused_grid(long long M, int K);
 size_t hdy_conv1x1_bwd_fused_workspace_bytes(long long M, int C, int K);

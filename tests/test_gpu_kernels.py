@@ -527,3 +527,68 @@ def test_fused_1x1_backward_matches_reference_and_the_three_launch_path(K, M, pa
     assert torch.equal(dx_o, dx_f) and torch.equal(gw_o, gw_f)
     assert xd._base[..., :16].float().eq(7.0).all()         # poison outside the slices untouched
     assert dx_f._base[..., :8].float().eq(7.0).all()
+
+
+def test_patch_resident_wgrad_stride2_variant():
+    """conv_wgrad3x3.hip also has a stride-2 path that is off by default (measured load bound): the bf16 stride-2 cases of
+    test_conv_fwd_dgrad_wgrad re-run in a child process with HDY_WGRAD3X3_S2=1 keep it correct."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HDY_WGRAD3X3_S2='1', HDY_WGRAD3X3_CHILD='1')
+    if os.environ.get('HDY_WGRAD3X3_CHILD'):
+        return
+    p = subprocess.run([sys.executable, '-m', 'pytest', 'tests/test_gpu_kernels.py', '-q', '-x', '-k', 'test_conv_fwd_dgrad_wgrad and dtype1'], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:]
+    assert ' passed' in p.stdout
+
+
+@pytest.mark.parametrize('case', [(2, 24, 20, 64, 32, 1, 1, 0, False), (3, 16, 16, 32, 64, 3, 1, 1, True), (2, 16, 24, 64, 128, 3, 2, 1, False),
+                                  (2, 40, 40, 64, 128, 3, 1, 1, False), (5, 128, 128, 32, 64, 3, 2, 1, True)])
+def test_dgrad_serves_batchnorm_backward_statistics(case):
+    """hdy_conv_dgrad_stats: the data-gradient launch that completes dx also leaves, for two channel ranges of dx that are the output
+    gradients of two Conv+BN+SiLU units, per-workgroup slabs of (SUM du, SUM du*xhat); hdy_bn_bwd_finalize_slabs reduces them to the same
+    dgamma / dbeta / c1 / c2 as the unit's own reduce pass (hdy_bn_act_bwd) on the finished dx."""
+    N, H, W, C, K, R, stride, pad, acc = case
+    dt = torch.bfloat16
+    Ho, Wo = ops.out_dim(H, R, stride, pad), ops.out_dim(W, R, stride, pad)
+    dy = to_dev_nhwc(rnd((N, K, Ho, Wo), 1), dt)
+    w = rnd((K, C, R, R), 2, 0.2)
+    wpd = ops.pack_alloc(K, C, R, R, stride, pad, ops.PACK_DGRAD, dt, DEV)
+    ops.run([ops.rec_pack(w.to(DEV), None, stride, pad, ops.PACK_DGRAD, wpd)])
+    dx0 = rnd((N, C, H, W), 3, 0.5)
+    nslabs = ops.conv_dgrad_stat_slabs(N, H, W, C, K, R, R, stride, pad, dt)
+    assert nslabs > 0 and ops.conv_dgrad_stat_slabs(N, H, W, 128, K, R, R, stride, pad, dt) == 0     # 128-wide gradients are not served
+    Ca = C // 2                                                      # two units: channels [0, Ca) and [Ca, C), their raw outputs in separate buffers
+    units = []
+    for i, (c0, c1) in enumerate([(0, Ca), (Ca, C)]):
+        y = to_dev_nhwc(rnd((N, c1 - c0, H, W), 10 + i, 2.0) + rnd((1, c1 - c0, 1, 1), 20 + i), dt, ld=c1 - c0 + 8, off=8 * i)
+        yq = y.float()
+        mean, var = yq.mean((0, 1, 2)), yq.var((0, 1, 2), unbiased=False)
+        invstd = 1.0 / torch.sqrt(var + 1e-3)
+        gamma, beta = (rnd((c1 - c0,), 30 + i) + 1.5).to(DEV), rnd((c1 - c0,), 40 + i, 0.3).to(DEV)
+        scale, shift = (gamma * invstd).contiguous(), (beta - mean * gamma * invstd).contiguous()
+        slabs = torch.zeros((nslabs, 2, c1 - c0), device=DEV)
+        units.append(dict(y=y, scale=scale, shift=shift, mean=mean.contiguous(), invstd=invstd.contiguous(), slabs=slabs, c0=c0, c1=c1))
+    reqs = [ops.StatRequest(u['y'], u['scale'], u['shift'], u['slabs'], u['c0'], ops.ACT_SILU) for u in units]
+    dx = to_dev_nhwc(dx0, dt, ld=C + 16, off=8)
+    dx_plain = to_dev_nhwc(dx0, dt, ld=C + 16, off=8)
+    ops.run([ops.rec_conv_dgrad(dy, wpd, dx, R, R, stride, pad, accumulate=acc, stats=reqs),
+             ops.rec_conv_dgrad(dy, wpd, dx_plain, R, R, stride, pad, accumulate=acc)])
+    torch.cuda.synchronize()
+    assert_close(dx.float().cpu(), dx_plain.float().cpu(), 8e-3, 'dx with / without statistics (generic vs filter-resident kernel)')
+    M = N * H * W
+    for u in units:
+        Kc = u['c1'] - u['c0']
+        dg, db, c1, c2 = (torch.zeros(Kc, device=DEV) for _ in range(4))
+        ops.run([ops.rec_bn_bwd_finalize_slabs(u['slabs'], M, u['mean'], u['invstd'], dg, db, c1, c2)])
+        # the unit's own reduce pass over the finished gradient
+        ws = torch.empty(ops.bn_bwd_ws_floats(M, Kc), dtype=torch.float32, device=DEV)
+        dg2, db2 = torch.zeros(Kc, device=DEV), torch.zeros(Kc, device=DEV)
+        ops.run([ops.rec_bn_act_bwd(dx[..., u['c0']:u['c1']], u['y'], u['scale'], u['shift'], u['mean'], u['invstd'], None, dg2, db2, ws)])
+        r1, r2 = ops.bn_bwd_coeffs(ws, M, Kc)
+        torch.cuda.synchronize()
+        for got, ref, what in ((dg, dg2, 'dgamma'), (db, db2, 'dbeta'), (c1, r1, 'c1'), (c2, r2, 'c2')):
+            assert_close(got.cpu(), ref.cpu(), 1e-4, what)       # SUM du*xhat as invstd*(SUM du*y - mean*SUM du): mild cancellation
+    assert dx._base[..., :8].float().eq(7.0).all()

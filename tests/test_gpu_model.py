@@ -483,6 +483,8 @@ def test_bf16_plan_layer_by_layer_against_fp32_torch():
     assert plan.dtype == torch.bfloat16
     units = [u for u in plan.units if isinstance(u, planmod.ConvUnit)]
     assert sum(plan._fusable_1x1(u) for u in units) >= 8, 'the fused 1x1 backward must be part of what is checked'
+    if os.environ.get('HDY_EXPECT_PRODUCER_STATS'):
+        assert plan.producer_stat_units >= 10, plan.producer_stat_units
 
     def consumers(v):
         n = 0
@@ -559,3 +561,17 @@ def test_bf16_plan_layer_by_layer_against_fp32_torch():
                 checked_dx += 1
     assert checked_dx >= 10, checked_dx
     print('bf16 layerwise worst errors:', {k: f'{v:.2e}' for k, v in worst.items()})
+
+
+def test_bf16_plan_layer_by_layer_with_producer_side_statistics():
+    """The alternative backward in which the launch that completes a gradient also serves the BatchNorm-backward statistics of the unit(s)
+    that gradient belongs to (HDY_PRODUCER_STATS=1; measured slower, hence off by default) goes through the same unit-by-unit check."""
+    import subprocess
+    import sys
+    if os.environ.get('HDY_PRODUCER_STATS_CHILD'):
+        return
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HDY_PRODUCER_STATS='1', HDY_PRODUCER_STATS_CHILD='1', HDY_EXPECT_PRODUCER_STATS='1')
+    p = subprocess.run([sys.executable, '-m', 'pytest', 'tests/test_gpu_model.py', '-q', '-x', '-k', 'test_bf16_plan_layer_by_layer_against_fp32_torch'],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and ' passed' in p.stdout, p.stdout[-3000:]
