@@ -88,9 +88,9 @@ def make_optimizer(model, hyp, batch_total):
 
 def pmc_traffic():
     """HBM bytes per launch of the roofline kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, see
-    profiles/r01_conv3x3_pmc.json and scripts/roofline_kernel.py); None when the file is absent."""
+    profiles/r02_conv3x3_pmc.json and scripts/roofline_kernel.py); None when the file is absent."""
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r01_conv3x3_pmc.json')) as f:
+        with open(os.path.join(ROOT, 'profiles', 'r02_conv3x3_pmc.json')) as f:
             return json.load(f)['traffic_bytes_per_launch']
     except (OSError, KeyError, ValueError):
         return None

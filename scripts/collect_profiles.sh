@@ -1,0 +1,29 @@
+#!/bin/bash
+# Collect the round's rocprofv3 summaries on a GPU box (run through gpurun from the repo root):
+#   gpurun --timeout 1100 -- 'bash scripts/collect_profiles.sh r02'
+# Each counter set is its own run; programs are started directly after `--` (no shell hop between rocprofv3 and python).
+set -o pipefail
+R=${1:-r02}
+OUT=gpurun_out/prof_$R
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace --stats -d $OUT/bench -o bench --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-infer > $OUT/bench.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/roof -o roof --output-format csv -- python3 scripts/roofline_kernel.py > $OUT/roof.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o fetch --output-format csv -- python3 scripts/roofline_kernel.py > $OUT/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o write --output-format csv -- python3 scripts/roofline_kernel.py > $OUT/write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/mfma -o mfma --output-format csv -- python3 scripts/roofline_kernel.py > $OUT/mfma.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/lds -o lds --output-format csv -- python3 scripts/roofline_kernel.py > $OUT/lds.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/infer -o infer --output-format csv -- python3 scripts/bench_infer.py l 128 1024 3 > $OUT/infer.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/hnet -o hnet --output-format csv -- python3 scripts/bench_hnet.py s 16 1280 4 > $OUT/hnet.log 2>&1
+python3 scripts/layer_bench.py > $OUT/layer_table.txt 2>&1
+for v in "m 32 640" "l 16 640" "m6 16 1280"; do set -- $v; python3 bench.py --variant $1 --batch $2 --size $3 --steps 10 --warmup 3 --no-cpu-baseline --no-infer --no-roofline 2>/dev/null | tail -1 | cut -c1-420 >> $OUT/variants.log; done
+python3 scripts/bench_mask.py s 16 1280 4 2>/dev/null | tail -1 >> $OUT/variants.log
+python3 scripts/bench_latency.py 2>/dev/null | tail -3 >> $OUT/variants.log
+python3 scripts/trace_gaps.py $OUT/bench/bench_kernel_trace.csv 6 > $OUT/trace_gaps.txt 2>&1
+python3 scripts/pmc_summary.py $OUT/fetch/fetch_counter_collection.csv $OUT/write/write_counter_collection.csv conv3x3_c64_kernel $OUT/conv3x3_pmc.json > /dev/null 2>&1
+python3 scripts/counters_summary.py $OUT/mfma/mfma_counter_collection.csv $OUT/lds/lds_counter_collection.csv conv3x3_c64_kernel $OUT/roof/roof_kernel_stats.csv $OUT/conv3x3_counters.json > /dev/null 2>&1
+ls $OUT $OUT/* | head -60
+tail -1 $OUT/bench.log | cut -c1-300
+tail -1 $OUT/infer.log | cut -c1-300
+tail -1 $OUT/hnet.log | cut -c1-300
+cat $OUT/variants.log | cut -c1-300
