@@ -14,11 +14,11 @@
 //    16x16 MFMA tiles.  One template serves both arithmetic types: LDS rows are 128 B (64 bf16 / 32 f32), a
 //    fragment is one 16-byte ds_read_b128 per lane, mma16() is one v_mfma_f32_16x16x32_bf16 or four
 //    v_mfma_f32_16x16x4_f32 (exact fp32: the 1e-4 parity mode).
-//  * staging is LDS-DMA (global_load_lds_dwordx4): no staging VGPRs, no ds_write pass (ds_write_b128 moves
+//  * staging is LDS-DMA (buffer_load_dwordx4 ... lds): no staging VGPRs, no ds_write pass (ds_write_b128 moves
 //    ~79 B/clk/CU and was the limiter of the register-staged version).  The DMA writes LDS linearly
 //    (wave base + lane*16), so the XOR swizzle that makes the fragment reads conflict-free is applied to the
-//    SOURCE address: lane l of a row fetches logical chunk (l&7) ^ ((row>>1)&7).  Padding / tail lanes fetch
-//    from a 16-byte zero page instead of being masked (a masked lane would leave stale LDS bytes).
+//    SOURCE address: lane l of a row fetches logical chunk (l&7) ^ ((row>>1)&7).  Padding / tail lanes carry an
+//    offset beyond the descriptor's range and receive zeros (a masked lane would leave stale LDS bytes).
 //  * persistent workgroups: each block walks a contiguous range of output tiles; the loader runs one k-block
 //    ahead of the MFMAs ACROSS tile boundaries, so the 1x1 layers (one or two k-blocks per tile) still overlap
 //    their loads with compute and the per-launch ramp is paid once.  Tile ranges follow the XCD-aware order,
@@ -66,6 +66,15 @@ __device__ __forceinline__ void glds16(const void* g, unsigned char* lds_wave_ba
                                      (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
 }
 
+// LDS-DMA through a buffer descriptor: lane l's 16 bytes at base + voff + soff land at lds + l*16; a lane whose offset fails the
+// descriptor's range check (>= num_records) gets zeros.
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, unsigned char* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (void __attribute__((address_space(3)))*)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
+}
+
+// n / d for n < 2^31 with the host-made reciprocal of hdy_magic(): mulhi(2n, mg) >> sh
+__device__ __forceinline__ unsigned fdiv(unsigned n, unsigned mg, int sh) { return __umulhi(n << 1, mg) >> sh; }
+
 // BM x BN output tile, NTHR = 2*BM threads (BM/64 x 2 waves, each 64 x BN/2), NS-deep LDS ring of (A | B) stages.
 //   <128, *, 2>  4 waves, 2 stages: many small workgroups per CU (K <= 64, small problems)
 //   <256, *, 3>  8 waves (2 per SIMD), 3 stages with counted vmcnt: half the filter re-fetch per output, two k-blocks of
@@ -107,94 +116,148 @@ __global__ __launch_bounds__(2 * BM, (BM == 256 || BN == 128 || STAT) ? 2 : (BN 
 
     const T* __restrict__ x = (const T*)p.x;
     const T* __restrict__ w = (const T*)p.w;
-    const unsigned char* zero = (const unsigned char*)g_hdy_zero16;
 
     // ------------------------------------------------------------------ loader (runs NS-1 k-blocks ahead)
-    // Address arithmetic is hoisted: per m-tile each staged row keeps a byte pointer to its tap-(0,0) pixel and that pixel's
-    // input coordinates; per k-block the thread derives ONE tap offset (its chunk's tap and channel), and a row costs two adds,
-    // two compares and a select.  (With the full 64-bit pixel address recomputed per row and k-block this issue phase took
-    // 42-52 % of the kernel's cycles on the 256->256 3x3 layer of yolov5l — more than twice the MFMA phase.)
-    // Measured and NOT adopted (same layer, same box): the two waves of a SIMD alternating as loader of a stage (1043 us vs 968 us);
-    // taps as the inner k-loop for L2 locality of the shifted re-reads (1107 us).  What bounds this kernel is the ~7 TB/s the
-    // CUs can fetch chip-wide: 85 FLOP per fetched byte at 256x128 tiles -> ~600 TFLOP/s, which is what it delivers.
-    // Also measured and not adopted for the single-tap layers: skipping the filter block once every ring slot holds it (+2 %), and a
-    // resident filter with a 7-deep activation-only ring in ONE 4-wave workgroup per CU (64->64 @160x160: 165 us vs 97 us): those
-    // layers are bound by the per-tile epilogue (~3k cycles per wave), which only co-resident workgroups overlap today.
-    // A 256x256 tile (2 stages, 128 FLOP per fetched byte) for K % 256 == 0: 1134 us vs 940 us on 256->256 3x3 @64x64 B=128.
+    // The generic layers are bound by how many instructions a k-block costs, not by bytes (PMC on 32->64 3x3/s2 @320x320: 13 VALU
+    // instructions per MFMA, 60 % of them address arithmetic of the LDS-DMA), so the loader keeps everything it can out of the VALU:
+    //  * both operands go through buffer descriptors (`buffer_load_dwordx4 ... offen lds`): a 32-bit per-lane offset that is CONSTANT for
+    //    a whole m-tile (row origin + the lane's 16-byte chunk) plus a scalar offset for the k-block (tap and channel block), so a k-block
+    //    whose 128 bytes lie inside one tap (C % BKE == 0: `utap`) costs no vector instruction at all for interior rows;
+    //  * padding is the descriptor's range check: a tap outside the image sets the offset to 2^31 = num_records, and the DMA writes
+    //    zeros (probed: scripts/probes/buffer_lds_oob.hip; the range check includes the scalar offset).  Per row one bit per tap of the
+    //    union window says "outside"; a wave whose rows are all interior skips the test;
+    //  * the descriptor base moves with the m-tile (first row's window origin, 64-bit scalar arithmetic), so offsets stay far below 2^31
+    //    whatever the tensor size;
+    //  * row -> (image, row, column) is a multiply-high by host-made reciprocals, done by ONE lane per row (lanes 0..31 of a wave own
+    //    its 32 rows) and handed to the 8 lanes of the row by ds_bpermute; the LDS destination of every DMA is scalar (m0 by SALU).
+    // Measured and NOT adopted earlier (same kernel, flat addressing): the two waves of a SIMD alternating as loader of a stage; taps as
+    // the inner k-loop; skipping the filter block once every ring slot holds it; a resident filter with a 7-deep activation ring; a
+    // 256x256 tile (numbers in DESIGN.md §4).
+    const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r0 = tid >> 3;
     const int lc = (tid & 7) ^ ((tid >> 4) & 7);       // logical chunk fetched into physical slot (tid & 7)
-    const unsigned char* rptr[AR];                       // &x[n][hi0][wi0][0] as bytes (never dereferenced when out of range)
-    unsigned hw0[AR];                                    // tap-(0,0) input coordinates, (hi0 + 4096) << 16 | (wi0 + 4096); rows >= M: 0xFFFF....
+    constexpr unsigned OOB = 0x80000000u;               // = num_records of both descriptors
+    constexpr int ES = (int)sizeof(T);
+    unsigned roff[AR];                                   // byte offset of the row's window-origin pixel (+ lc * 16) from the tile base
+    unsigned inv[AR];                                    // bit (th * UW + tw): that tap of the union window is outside the image; bit 31: always
+    unsigned woff[BR];                                   // filter rows: byte offset of (row r0 + RSTEP * i, chunk lc) from the column tile's first row
+    bool any_inv = true;                                 // wave-uniform: some row of this wave has an outside tap
     int ld_tile = tile_begin, ld_kb = 0, ld_mtile = -1;
-    int cc = 0, th = 0, tw = 0;
-    const T* wrow0 = w;
-    size_t wstep = (size_t)RSTEP * p.Kdp;                // distance between a thread's staged filter rows
     const int HoWo = p.Ho * p.Wo;
-    // tap window of the loader's current tile: taps run th in [l_th0, l_TH), tw in [l_tw0, l_TW) relative to class 0's origin
-    int l_th0 = 0, l_tw0 = 0, l_TH = p.TH, l_TW = p.TW, l_nkb = nkb;
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, OOB, 0x00020000);
+    __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, OOB, 0x00020000);
+    // tap window of the loader's current tile inside the union window (origin uh0 / uw0): l_THc x l_TWc taps from (l_th0, l_tw0)
+    int l_th0 = p.dh0 - p.uh0, l_tw0 = p.dw0 - p.uw0, l_TW = l_tw0 + p.TW, l_nkb = nkb;
+    unsigned l_mg_tw = p.mg_tw[0];
+    int l_sh_tw = p.sh_tw[0], l_TWc = p.TW, l_THc = p.TH;
+    int s_th = 0, s_tw = 0, s_cb = 0;                    // utap: scalar tap and channel block of the next k-block
+    unsigned w_soff = 0;                                 // scalar byte offset of the column tile's first filter row
+    int l_Kdp = p.Kdp;
+    const int rowB = p.Win * p.ldx * ES, pixB = p.ldx * ES;
+
+    auto set_woff = [&]() {
+#pragma unroll
+        for (int i = 0; i < BR; ++i) woff[i] = (unsigned)((r0 + RSTEP * i) * l_Kdp * ES + lc * 16);
+    };
+    set_woff();
 
     auto loader_set_tile = [&](int t) {
-        const T* wbase = w;
-        int Kdp = p.Kdp;
         if (walk) {
             const int cls = t & 3;
             t >>= 2;
-            l_th0 = p.c_dh[cls] - p.dh0; l_tw0 = p.c_dw[cls] - p.dw0;
-            l_TH = l_th0 + p.c_TH[cls]; l_TW = l_tw0 + p.c_TW[cls];
+            l_th0 = p.c_dh[cls] - p.uh0; l_tw0 = p.c_dw[cls] - p.uw0;
+            l_THc = p.c_TH[cls]; l_TWc = p.c_TW[cls];
+            l_TW = l_tw0 + l_TWc;
+            l_mg_tw = p.mg_tw[cls]; l_sh_tw = p.sh_tw[cls];
             l_nkb = p.c_nkb[cls];
-            Kdp = l_nkb * BKE;
-            wbase = w + p.c_w[cls];
-            wstep = (size_t)RSTEP * Kdp;
+            l_Kdp = l_nkb * BKE;
+            rw = __builtin_amdgcn_make_buffer_rsrc((void*)(w + p.c_w[cls]), 0, OOB, 0x00020000);
+            set_woff();
         }
         const int mt = t / ntiles, nt = t - mt * ntiles;
         if (mt != ld_mtile) {
+            const int mb = mt * BM;                      // first row of the tile (always < M)
+            // this lane's row: lanes 0..31 (and their copies 32..63) own rows 8 * wave + (lane & 7) + RSTEP * ((lane >> 3) & 3)
+            const int m = mb + 8 * wave_s + (lane & 7) + RSTEP * ((lane >> 3) & 3);
+            unsigned my_off, my_inv;
+            if (p.pointwise) {                           // input pixel == output pixel: nothing to recover
+                rx = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)x + (long long)mb * pixB), 0, OOB, 0x00020000);
+                my_off = (unsigned)((m - mb) * pixB);
+                my_inv = m < p.M ? 0x80000000u : 0xFFFFFFFFu;
+            } else {
+                const int nb = (int)fdiv((unsigned)mb, p.mg_howo, p.sh_howo), remb = mb - nb * HoWo;
+                const int oib = (int)fdiv((unsigned)remb, p.mg_wo, p.sh_wo), ojb = remb - oib * p.Wo;
+                const int hb = oib * p.ih_mul + p.uh0, wb = ojb * p.iw_mul + p.uw0;
+                rx = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)x + (((long long)nb * p.Hin + hb) * p.Win + wb) * pixB), 0, OOB, 0x00020000);
+                const int mc = min(m, p.M - 1);
+                const int n = (int)fdiv((unsigned)mc, p.mg_howo, p.sh_howo), rem = mc - n * HoWo;
+                const int oi = (int)fdiv((unsigned)rem, p.mg_wo, p.sh_wo), oj = rem - oi * p.Wo;
+                const int h = oi * p.ih_mul + p.uh0, w_ = oj * p.iw_mul + p.uw0;
+                my_off = (unsigned)((((n - nb) * p.Hin + (h - hb)) * p.Win + (w_ - wb)) * pixB);
+                unsigned wmask = 0;
+                for (int tw = 0; tw < p.UW; ++tw) wmask |= ((unsigned)(w_ + tw) >= (unsigned)p.Win ? 1u : 0u) << tw;
+                const unsigned full = (1u << p.UW) - 1u;
+                my_inv = 0x80000000u;
+                for (int th = 0; th < p.UH; ++th) my_inv |= ((unsigned)(h + th) >= (unsigned)p.Hin ? full : wmask) << (th * p.UW);
+                if (m >= p.M) my_inv = 0xFFFFFFFFu;
+            }
+            any_inv = __builtin_amdgcn_ballot_w64((my_inv & 0x7FFFFFFFu) != 0) != 0;
 #pragma unroll
             for (int i = 0; i < AR; ++i) {
-                const int m = mt * BM + r0 + RSTEP * i;
-                if (p.pointwise) {                       // input pixel == output pixel: no coordinates to recover
-                    rptr[i] = (const unsigned char*)(x + (long long)m * p.ldx);
-                    hw0[i] = m < p.M ? ((4096u << 16) | 4096u) : 0xFFFFFFFFu;
-                } else {
-                    const int mc = min(m, p.M - 1);
-                    const int n = mc / HoWo, rem = mc - n * HoWo;
-                    const int oi = rem / p.Wo, oj = rem - oi * p.Wo;
-                    const int h = oi * p.ih_mul + p.dh0, w_ = oj * p.iw_mul + p.dw0;
-                    rptr[i] = (const unsigned char*)(x + (((long long)n * p.Hin + h) * p.Win + w_) * p.ldx);
-                    hw0[i] = m < p.M ? (((unsigned)(h + 4096) << 16) | (unsigned)(w_ + 4096)) : 0xFFFFFFFFu;
-                }
+                const int src = (i * 8 + (lane >> 3)) << 2;
+                roff[i] = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)my_off) + (unsigned)(lc * 16);
+                inv[i] = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)my_inv);
             }
             ld_mtile = mt;
         }
-        wrow0 = wbase + (size_t)(nt * BN + r0) * Kdp + lc * VE;
-        cc = lc * VE; th = l_th0; tw = l_tw0;
-        while (cc >= p.C) {
-            cc -= p.C;
-            if (++tw == l_TW) { tw = l_tw0; ++th; }
-        }
+        w_soff = (unsigned)(nt * BN * l_Kdp * ES);
+        s_th = l_th0; s_tw = l_tw0; s_cb = 0;
     };
 
     auto loader_issue = [&](int buf) {
-        unsigned char* sa = smem + buf * STAGE;
+        unsigned char* sa = smem + buf * STAGE + wave_s * 1024;
         unsigned char* sb = sa + ASZ;
-        const long long koff = (long long)(((th * p.Win + tw) * p.ldx + cc) * (int)sizeof(T));      // this chunk's tap and channel
-        const bool tap_ok = th < l_TH;                   // false only in the zero padding of the last k-block
+        if (p.utap) {
+            // the whole k-block lies inside tap (s_th, s_tw), channels [s_cb, s_cb + BKE): one scalar offset, one mask bit
+            const unsigned koff = (unsigned)(s_th * rowB + s_tw * pixB + s_cb * ES);
+            if (any_inv) {
+                const unsigned bit = (unsigned)(s_th * p.UW + s_tw);
 #pragma unroll
-        for (int i = 0; i < AR; ++i) {
-            const int hi = (int)(hw0[i] >> 16) - 4096 + th, wi = (int)(hw0[i] & 0xFFFFu) - 4096 + tw;
-            const bool ok = tap_ok && (unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win;
-            glds16(ok ? (const void*)(rptr[i] + koff) : (const void*)zero, sa + (wave * 64 + NTHR * i) * 16);
+                for (int i = 0; i < AR; ++i) {
+                    const int out = __builtin_amdgcn_sbfe(inv[i], bit, 1);       // 0 / -1
+                    lds_dma16(rx, (out & (int)OOB) | roff[i], koff, sa + NTHR * 16 * i);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < AR; ++i) lds_dma16(rx, roff[i], koff, sa + NTHR * 16 * i);
+            }
+        } else {
+            // k-blocks straddle taps (C < BKE or C % BKE != 0): this lane's chunk has its own tap and channel
+            const unsigned ke = (unsigned)(ld_kb * BKE + lc * VE);
+            const unsigned tap = fdiv(ke, p.mg_c, p.sh_c);
+            const int c = (int)(ke - tap * (unsigned)p.C);
+            const int thr = (int)fdiv(tap, l_mg_tw, l_sh_tw), twr = (int)tap - thr * l_TWc;
+            const int th = l_th0 + thr, tw = l_tw0 + twr;
+            const unsigned koff = (unsigned)(th * rowB + tw * pixB + c * ES - lc * 16);     // roff[] carries lc * 16 (the utap form of the chunk offset)
+            const unsigned bit = thr < l_THc ? (unsigned)(th * p.UW + tw) : 31u;    // beyond the last tap: the zero padding of the last k-block
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                const int out = __builtin_amdgcn_sbfe(inv[i], bit, 1);
+                lds_dma16(rx, (out & (int)OOB) | (roff[i] + koff), 0, sa + NTHR * 16 * i);
+            }
         }
+        const unsigned wk = w_soff + (unsigned)(ld_kb * 128);
 #pragma unroll
-        for (int i = 0; i < BR; ++i) glds16(wrow0 + i * wstep + (size_t)ld_kb * BKE, sb + (wave * 64 + NTHR * i) * 16);
+        for (int i = 0; i < BR; ++i) lds_dma16(rw, woff[i], wk, sb + NTHR * 16 * i);
         // advance to the next k-block, possibly of the next tile
         if (++ld_kb == l_nkb) {
             ld_kb = 0;
             if (++ld_tile < tile_end) loader_set_tile(ld_tile);
         } else {
-            cc += BKE;
-            while (cc >= p.C) {
-                cc -= p.C;
-                if (++tw == l_TW) { tw = l_tw0; ++th; }
+            s_cb += BKE;
+            if (s_cb >= p.C) {
+                s_cb = 0;
+                if (++s_tw == l_TW) { s_tw = l_tw0; ++s_th; }
             }
         }
     };
@@ -402,8 +465,8 @@ __global__ __launch_bounds__(2 * BM, (BM == 256 || BN == 128 || STAT) ? 2 : (BN 
                 if (kc < p.K) {
                     auto pixel = [&](int m) -> size_t {
                         if (p.dense_out) return (size_t)m;
-                        const int n = m / HoWo, rem = m - n * HoWo;
-                        const int oi = rem / p.Wo, oj = rem - oi * p.Wo;
+                        const int n = (int)fdiv((unsigned)m, p.mg_howo, p.sh_howo), rem = m - n * HoWo;
+                        const int oi = (int)fdiv((unsigned)rem, p.mg_wo, p.sh_wo), oj = rem - oi * p.Wo;
                         return ((size_t)n * p.Hout + (oh_off + oi * p.oh_mul)) * p.Wout + (ow_off + oj * p.ow_mul);
                     };
                     // statistics: the raw-output vector of the NEXT row is requested before this row is processed (one load in flight)
@@ -474,8 +537,8 @@ __global__ __launch_bounds__(2 * BM, (BM == 256 || BN == 128 || STAT) ? 2 : (BN 
             if (p.dense_out) {
                 opix = (size_t)m;
             } else {
-                const int n = m / HoWo, rem = m - n * HoWo;
-                const int oi = rem / p.Wo, oj = rem - oi * p.Wo;
+                const int n = (int)fdiv((unsigned)m, p.mg_howo, p.sh_howo), rem = m - n * HoWo;
+                const int oi = (int)fdiv((unsigned)rem, p.mg_wo, p.sh_wo), oj = rem - oi * p.Wo;
                 opix = ((size_t)n * p.Hout + (oh_off + oi * p.oh_mul)) * p.Wout + (ow_off + oj * p.ow_mul);
             }
             OT* yrow = y + opix * p.ldy;
@@ -509,6 +572,10 @@ __global__ __launch_bounds__(2 * BM, (BM == 256 || BN == 128 || STAT) ? 2 : (BN 
         for (int t = tile_begin; t < tile_end; ++t) total += p.c_nkb[t & 3];
         c_nkb = p.c_nkb[tile_begin & 3];
     }
+    // fragment addresses inside a stage: 16 rows further down is +2048 bytes with the same chunk swizzle, so the (a, b) tiles are
+    // immediate offsets of four per-lane bases
+    const unsigned fa[2] = {(unsigned)swz(wm * 64 + fr, fq), (unsigned)swz(wm * 64 + fr, 4 + fq)};
+    const unsigned fb[2] = {(unsigned)(ASZ + swz(wn * (BN / 2) + fr, fq)), (unsigned)(ASZ + swz(wn * (BN / 2) + fr, 4 + fq))};
     int issued = 0;
     loader_set_tile(tile_begin);
     for (; issued < NS - 1 && issued < total; ++issued) loader_issue(issued % NS);
@@ -531,17 +598,16 @@ __global__ __launch_bounds__(2 * BM, (BM == 256 || BN == 128 || STAT) ? 2 : (BN 
         __syncthreads();
         stores_pending = false;
         if (issued < total) { loader_issue(issued % NS); ++issued; }
-        const unsigned char* a_s = smem + (it % NS) * STAGE;
-        const unsigned char* b_s = a_s + ASZ;
+        const unsigned char* st_s = smem + (it % NS) * STAGE;
         if constexpr (BN >= 64 && sizeof(T) == 2) {
             // both k-halves' fragments are requested before the first half's MFMAs start (the wide tiles have the registers for it)
             V16 af[2][MT], bf[2][NT];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-                for (int a = 0; a < MT; ++a) af[ks][a].i = *(const i32x4*)(a_s + swz(wm * 64 + a * 16 + fr, ks * 4 + fq));
+                for (int a = 0; a < MT; ++a) af[ks][a].i = *(const i32x4*)(st_s + fa[ks] + a * 2048);
 #pragma unroll
-                for (int b = 0; b < NT; ++b) bf[ks][b].i = *(const i32x4*)(b_s + swz(wn * (BN / 2) + b * 16 + fr, ks * 4 + fq));
+                for (int b = 0; b < NT; ++b) bf[ks][b].i = *(const i32x4*)(st_s + fb[ks] + b * 2048);
                 if (ks == 0) __builtin_amdgcn_sched_barrier(0);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -556,9 +622,9 @@ __global__ __launch_bounds__(2 * BM, (BM == 256 || BN == 128 || STAT) ? 2 : (BN 
             for (int ks = 0; ks < 2; ++ks) {
                 V16 af[MT], bf[NT];
 #pragma unroll
-                for (int a = 0; a < MT; ++a) af[a].i = *(const i32x4*)(a_s + swz(wm * 64 + a * 16 + fr, ks * 4 + fq));
+                for (int a = 0; a < MT; ++a) af[a].i = *(const i32x4*)(st_s + fa[ks] + a * 2048);
 #pragma unroll
-                for (int b = 0; b < NT; ++b) bf[b].i = *(const i32x4*)(b_s + swz(wn * (BN / 2) + b * 16 + fr, ks * 4 + fq));
+                for (int b = 0; b < NT; ++b) bf[b].i = *(const i32x4*)(st_s + fb[ks] + b * 2048);
 #pragma unroll
                 for (int a = 0; a < MT; ++a)
 #pragma unroll
@@ -726,6 +792,21 @@ int hdy_conv_igemm_launch(ConvArgs a, int dtype, int out_f32, hipStream_t st) {
                     "conv: bad statistics request %d", r);
         }
     }
+    // loader geometry: union tap window over the classes, reciprocals for the row / chunk decompositions
+    a.uh0 = a.dh0; a.uw0 = a.dw0;
+    int uh1 = a.dh0 + a.TH, uw1 = a.dw0 + a.TW;
+    for (int c = 0; c < (a.ncls > 1 ? 4 : 0); ++c) {
+        a.uh0 = a.c_dh[c] < a.uh0 ? a.c_dh[c] : a.uh0; a.uw0 = a.c_dw[c] < a.uw0 ? a.c_dw[c] : a.uw0;
+        uh1 = a.c_dh[c] + a.c_TH[c] > uh1 ? a.c_dh[c] + a.c_TH[c] : uh1; uw1 = a.c_dw[c] + a.c_TW[c] > uw1 ? a.c_dw[c] + a.c_TW[c] : uw1;
+    }
+    a.UH = uh1 - a.uh0; a.UW = uw1 - a.uw0;
+    HDY_ARG(a.UH * a.UW <= 31, "conv: %d x %d tap window beyond the loader's 31 tap bits", a.UH, a.UW);
+    HDY_ARG(((long long)(a.UH + 1) * a.Win + a.UW) * a.ldx * (dtype == HDY_BF16 ? 2 : 4) < (1LL << 28), "conv: tap window spans too many bytes");
+    a.utap = a.C % BKE == 0 ? 1 : 0;
+    hdy_magic((unsigned)(a.Ho * a.Wo), &a.mg_howo, &a.sh_howo);
+    hdy_magic((unsigned)a.Wo, &a.mg_wo, &a.sh_wo);
+    hdy_magic((unsigned)a.C, &a.mg_c, &a.sh_c);
+    for (int c = 0; c < 4; ++c) hdy_magic((unsigned)(a.ncls > 1 ? a.c_TW[c] : a.TW), &a.mg_tw[c], &a.sh_tw[c]);
     int rc = 0;
     if (a.ncls <= 1 && a.nstat == 0) {
         if (hdy_conv_stem_try(a, dtype, out_f32, st, &rc)) return rc;         // patch-resident 6x6/s2 stem

@@ -41,7 +41,20 @@ struct ConvArgs {
     int ncls;
     int c_dh[4], c_dw[4], c_TH[4], c_TW[4], c_nkb[4], c_oh[4], c_ow[4];
     long long c_w[4];
+    // derived by hdy_conv_igemm_launch for the loader: union tap window over the classes (origin uh0 / uw0, UH x UW taps <= 31),
+    // utap = every 128-byte k-block lies inside one tap (C % BKE == 0), reciprocals (hdy_magic) of Ho*Wo, Wo, C and the tap-window width
+    int uh0, uw0, UH, UW, utap;
+    unsigned mg_howo, mg_wo, mg_c, mg_tw[4];
+    int sh_howo, sh_wo, sh_c, sh_tw[4];
 };
+
+// reciprocal for n / d, n < 2^31: q = mulhi(2n, *mg) >> *sh (conv_igemm.hip fdiv)
+inline void hdy_magic(unsigned d, unsigned* mg, int* sh) {
+    int s = 0;
+    while ((1ull << s) < d) ++s;
+    *mg = (unsigned)((((unsigned long long)1 << (31 + s)) + d - 1) / d);
+    *sh = s;
+}
 
 struct WgradArgs {
     const void* x;        // [N][Hin][Win][ldx]

@@ -1,0 +1,17 @@
+#!/bin/bash
+# PMC passes on single layers of the C2 train plan (run through gpurun from the repo root):
+#   gpurun --timeout 900 -- 'bash scripts/probe_layer_pmc.sh "F fwd +32-> +64 k3 s2" tag'
+# One counter set per run; python3 directly after `--`.
+set -o pipefail
+PAT="$1"; TAG=${2:-layer}; REPS=${3:-5}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/probe_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+python3 scripts/layer_probe.py "$PAT" $REPS > $OUT/time.log 2>&1 || { tail -5 $OUT/time.log; exit 1; }
+i=0
+for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum" "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VMEM SQ_INSTS_LDS SQ_INSTS_VALU" "TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $set -d $OUT/p$i -o p$i --output-format csv -- python3 scripts/layer_probe.py "$PAT" $REPS > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -3 $OUT/p$i.log; }
+done
+cat $OUT/time.log | grep -v amdgpu.ids
+python3 scripts/pmc_table.py $((REPS)) 'conv_igemm|conv3x3|wgrad' $(ls $OUT/p*/p*_counter_collection.csv $OUT/p*/*/p*_counter_collection.csv 2>/dev/null) | tee $OUT/table.txt
