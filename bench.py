@@ -13,7 +13,10 @@ Extra objects on the line:
   roofline      the kernel on the layer the north star names — the fused 3x3 conv 64->64 at 80x80, batch 64 (filter-resident
                 conv3x3_c64) — timed live with HIP events on the launch stream; achieved = 2*N*K*C*9*Ho*Wo / t.  Its `layers_3x3`
                 lists EVERY 3x3 convolution launch of the benchmarked model (forward and data gradient) timed alone, `min_frac` is the
-                worst of them: the named kernel is 2 % of the step, the others are where the time goes.
+                worst of them: the named kernel is 2 % of the step, the others are where the time goes.  Each row also names the
+                roofline that bounds THAT layer (`bound`: max(FLOPs / 2.5 PFLOP/s, read-once/write-once bytes / 8 TB/s)) and its
+                `frac_of_bound`: the stride-2 layers at 320x320 / 160x160 are HBM-bound (0.24 of the MFMA peak AT the HBM roofline).
+  roofline_hbm  the step's dominant HBM-bound kernel (BatchNorm backward over the largest activation) timed alone, bytes / time vs 8 TB/s.
   step          whole-step fractions: conv FLOPs of the step / time / 2.5 PFLOP/s and read-once/write-once bytes of its conv and
                 BatchNorm launches / time / 8 TB/s.
   infer         BASELINE configs[3] (yolov5l, batch 128, 1024x1024 inference): tiles/s, decode and NMS microseconds per tile.
@@ -284,8 +287,10 @@ def main():
         if not args.no_roofline:
             line['roofline'] = conv_roofline(device)
             rows = bench_util.conv3x3_table(plan, PEAK_BF16_TFLOPS)
-            line['roofline']['layers_3x3'] = [{'layer': r[0], 'us': r[1], 'tflops': r[2], 'frac': r[3]} for r in rows]
-            line['roofline']['min_frac'] = min(r[3] for r in rows)
+            line['roofline']['layers_3x3'] = rows
+            line['roofline']['min_frac'] = min(r['frac'] for r in rows)
+            line['roofline']['min_frac_of_bound'] = min(r['frac_of_bound'] for r in rows)
+            line['roofline_hbm'] = bench_util.hbm_kernel_roofline(plan, PEAK_HBM_GBS)
         if world == 1 and not args.no_infer and args.variant == 's' and args.batch == 64:
             try:
                 line['infer'] = bench_util.infer_benchmark('l', 128, 1024, 3, device)

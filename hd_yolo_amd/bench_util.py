@@ -77,19 +77,40 @@ def time_record(rec, reps=10):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
-def conv3x3_table(plan, peak_tflops=2500.0, reps=8):
-    """Every 3x3 convolution launch (forward, and data gradient) of a plan timed alone: [(label, us, TFLOP/s, fraction of peak)]"""
+def conv3x3_table(plan, peak_tflops=2500.0, reps=8, peak_gbs=8000.0):
+    """Every 3x3 convolution launch (forward, and data gradient) of a plan timed alone.  Per layer: time, TFLOP/s, fraction of the
+    MFMA peak, and — because the stride-2 / narrow layers cannot reach 30 % of the MFMA peak even at the HBM roofline — the roofline
+    that bounds it (max(flop / MFMA peak, read-once/write-once bytes / HBM peak)) and the fraction of THAT bound."""
     rows, seen = [], set()
     for rec in flat_records(plan.fwd) + flat_records(plan.bwd):
         if rec[0] not in ('hdy_conv_fwd', 'hdy_conv_dgrad', 'hdy_conv_dgrad_stats'):
             continue
-        label, fl, _ = describe(rec)
+        label, fl, by = describe(rec)
         if ' k3 ' not in label or label in seen:
             continue
         seen.add(label)
         us = time_record(rec, reps)
-        rows.append((label, round(us, 1), round(fl / us / 1e6, 1), round(fl / us / 1e6 / peak_tflops, 4)))
+        t_mfma, t_hbm = fl / peak_tflops / 1e6, by / peak_gbs / 1e3          # microseconds at either peak
+        rows.append({'layer': label, 'us': round(us, 1), 'tflops': round(fl / us / 1e6, 1), 'frac': round(fl / us / 1e6 / peak_tflops, 4),
+                     'bound': 'mfma' if t_mfma >= t_hbm else 'hbm', 'frac_of_bound': round(max(t_mfma, t_hbm) / us, 4)})
     return rows
+
+
+def hbm_kernel_roofline(plan, peak_gbs=8000.0, reps=8):
+    """The step's dominant HBM-bound kernel — the BatchNorm-backward pass over the largest activation — timed alone:
+    achieved = algorithmic bytes (read dz, read y [, write dy]) / time."""
+    best = None
+    for rec in flat_records(plan.bwd):
+        if rec[0] not in ('hdy_bn_act_bwd', 'hdy_bn_act_bwd_pair'):
+            continue
+        label, _, by = describe(rec)
+        if best is None or by > best[2]:
+            best = (rec, label, by)
+    if best is None:
+        return None
+    us = time_record(best[0], reps)
+    return {'bound': 'hbm', 'kernel': best[0][0][4:] + ' ' + best[1], 'achieved': round(best[2] / us / 1e3, 1), 'peak': peak_gbs, 'unit': 'GB/s',
+            'frac': round(best[2] / us / 1e3 / peak_gbs, 4), 'us_per_launch': round(us, 1), 'algorithmic_mb_per_launch': round(best[2] / 1e6, 1)}
 
 
 def timed(fn, n):

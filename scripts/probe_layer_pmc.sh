@@ -14,4 +14,4 @@ for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BU
   rocprofv3 --kernel-trace --pmc $set -d $OUT/p$i -o p$i --output-format csv -- python3 scripts/layer_probe.py "$PAT" $REPS > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -3 $OUT/p$i.log; }
 done
 cat $OUT/time.log | grep -v amdgpu.ids
-python3 scripts/pmc_table.py $((REPS)) 'conv_igemm|conv3x3|wgrad' $(ls $OUT/p*/p*_counter_collection.csv $OUT/p*/*/p*_counter_collection.csv 2>/dev/null) | tee $OUT/table.txt
+python3 scripts/pmc_table.py $((REPS)) "${4:-conv_igemm}" $(ls $OUT/p*/p*_counter_collection.csv $OUT/p*/*/p*_counter_collection.csv 2>/dev/null) > $OUT/table.txt; grep -A1 "Li128ELi64\|n=$REPS" $OUT/table.txt | cut -c1-1200
