@@ -333,21 +333,9 @@ __global__ __launch_bounds__(256) void wgrad_stem_kernel(const WgradArgs p) {
 
 // grad[k][c][r][s] (+)= sum_split partial[split][k][q]
 // mode 0: q = (r*S + s)*C + c          mode 1 (stem): q = r*(S*4) + s*4 + c, c < 3
-// block = 64 outputs x 16 split-lanes: slabs are read coalesced along q and 16 splits are in flight per output
-__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ partial, int splits, size_t slab_stride, int K, int Q,
-                                                            int mode, int C, int R, int S, float* __restrict__ grad, int accumulate) {
-    __shared__ float red[16][65];
-    const int ql = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int idx = blockIdx.x * 64 + ql;
-    const bool ok = idx < K * Q;
-    float sum = 0.f;
-    if (ok)
-        for (int sp = sl; sp < splits; sp += 16) sum += partial[(size_t)sp * slab_stride + idx];
-    red[sl][ql] = sum;
-    __syncthreads();
-    if (sl != 0 || !ok) return;
-#pragma unroll
-    for (int i = 1; i < 16; ++i) sum += red[i][ql];
+// block = 64 four-output columns x 16 split-lanes; a lane keeps four 16-byte loads of different slabs in flight (the first version read
+// one dword per lane in a dependent loop: 1.5 TB/s on 32 MB of slabs, 1.25 ms of the train step).  Fixed summation order.
+__device__ __forceinline__ void wgrad_scatter(float v, int idx, int K, int Q, int mode, int C, int R, int S, float* __restrict__ grad, int accumulate) {
     const int k = idx / Q, q = idx - k * Q;
     int c, r, s;
     if (mode == 0) {
@@ -363,7 +351,59 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
         if (c >= C) return;
     }
     float* g = grad + (((size_t)k * C + c) * R + r) * S + s;
-    *g = accumulate ? *g + sum : sum;
+    *g = accumulate ? *g + v : v;
+}
+
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ partial, int splits, size_t slab_stride, int K, int Q,
+                                                            int mode, int C, int R, int S, float* __restrict__ grad, int accumulate) {
+    __shared__ f32x4 red[16][64];
+    const int ql = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int idx = (blockIdx.x * 64 + ql) * 4;
+    const bool ok = idx < K * Q;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    if (ok) {
+        const float* src = partial + idx;
+        int sp = sl;
+        for (; sp + 48 < splits; sp += 64) {
+            const f32x4 a = *(const f32x4*)(src + (size_t)sp * slab_stride);
+            const f32x4 b = *(const f32x4*)(src + (size_t)(sp + 16) * slab_stride);
+            const f32x4 c = *(const f32x4*)(src + (size_t)(sp + 32) * slab_stride);
+            const f32x4 d = *(const f32x4*)(src + (size_t)(sp + 48) * slab_stride);
+            s0 += a; s1 += b; s2 += c; s3 += d;
+        }
+        for (; sp < splits; sp += 16) s0 += *(const f32x4*)(src + (size_t)sp * slab_stride);
+    }
+    red[sl][ql] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sl != 0 || !ok) return;
+    f32x4 sum = red[0][ql];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) sum += red[i][ql];
+    if (mode == 0 && R == 1 && S == 1) {                 // 1x1: q == c, the four outputs are contiguous
+        f32x4* g = (f32x4*)(grad + idx);
+        *g = accumulate ? *g + sum : sum;
+        return;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) wgrad_scatter(sum[e], idx + e, K, Q, mode, C, R, S, grad, accumulate);
+}
+
+// the same for slabs that are not whole 16-byte columns (K*Q, the slab pitch or the base not a multiple of four floats)
+__global__ __launch_bounds__(1024) void wgrad_reduce_scalar_kernel(const float* __restrict__ partial, int splits, size_t slab_stride, int K, int Q,
+                                                                   int mode, int C, int R, int S, float* __restrict__ grad, int accumulate) {
+    __shared__ float red[16][65];
+    const int ql = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + ql;
+    const bool ok = idx < K * Q;
+    float sum = 0.f;
+    if (ok)
+        for (int sp = sl; sp < splits; sp += 16) sum += partial[(size_t)sp * slab_stride + idx];
+    red[sl][ql] = sum;
+    __syncthreads();
+    if (sl != 0 || !ok) return;
+#pragma unroll
+    for (int i = 1; i < 16; ++i) sum += red[i][ql];
+    wgrad_scatter(sum, idx, K, Q, mode, C, R, S, grad, accumulate);
 }
 
 // Packing: framework weight w[K][C][R][S] (fp32) -> out[row][t][cdim] of type T, pitch Kdp, zero padded.
@@ -506,8 +546,12 @@ int hdy_wgrad_stem_launch(const WgradArgs& a, int grid, hipStream_t st) {
 int hdy_wgrad_reduce_launch(const float* partial, int splits, size_t slab_stride, int K, int Q, int mode, int C, int R, int S, float* grad,
                             int accumulate, hipStream_t st) {
     const int n = K * Q;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(n, 64)), dim3(1024), 0, st, partial, splits, slab_stride, K, Q, mode, C, R, S, grad,
-                       accumulate);
+    const bool vec = n % 4 == 0 && slab_stride % 4 == 0 && ((uintptr_t)partial & 15) == 0 && (!(mode == 0 && R == 1 && S == 1) || ((uintptr_t)grad & 15) == 0);
+    if (vec)
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(n, 256)), dim3(1024), 0, st, partial, splits, slab_stride, K, Q, mode, C, R, S, grad, accumulate);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_scalar_kernel, dim3(cdiv(n, 64)), dim3(1024), 0, st, partial, splits, slab_stride, K, Q, mode, C, R, S, grad,
+                           accumulate);
     HDY_LAUNCH_CHECK("wgrad_reduce");
     return HDY_OK;
 }

@@ -28,6 +28,7 @@ from . import _lib, ops
 USE_GRAPHS = os.environ.get('HDY_GRAPH', '0') == '1'   # hipGraph replay of ~400-node graphs measured slower than eager on ROCm 7.2
 SIDE_WGRAD = os.environ.get('HDY_SIDE_WGRAD', '1') == '1' and not USE_GRAPHS      # weight gradients on a second stream
 DY_RING = int(os.environ.get('HDY_DY_RING', '4'))
+SKIP_WGRAD = os.environ.get('HDY_SKIP_WGRAD') == '1'     # measurement only: no weight-gradient launches at all
 # BN-backward reduce pass served by the launch that completes dz ('1': fused 1x1 backward and dgrad launches, 'fused': the former only).
 # Built, parity-tested (tests/test_gpu_kernels.py, test_gpu_model.py) and NOT the default: the epilogues that would serve the statistics are
 # themselves VALU-bound (exp + rcp per element on top of the store loop) — yolov5s B=64 step 14.09 ms without, 14.31 ('fused'), 14.37 ('1').
@@ -566,6 +567,8 @@ class Plan:
         nfork = [0]
 
         def wgrad(rec, reads_dy_slot=None):
+            if SKIP_WGRAD:          # timing experiment only (gradients wrong): what the step costs without the weight-gradient stream
+                return
             if side is None:
                 recs.append(rec)
                 return

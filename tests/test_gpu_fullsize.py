@@ -74,6 +74,51 @@ def test_named_layer_two_bf16_kernels_agree_at_full_size():
     assert relmax(a['y'], y32) < 1.5e-2
 
 
+@pytest.mark.parametrize('case', [
+    # C, K, R, stride, H, N          input / output bytes at bf16
+    (64, 128, 3, 1, 512, 72),        # 2.4 GB in, 4.8 GB out: output offsets beyond 2^32 (utap loader, two k-blocks per tap)
+    (32, 64, 3, 2, 1024, 68),        # 4.6 GB in: tile bases beyond 2^32, k-blocks that straddle taps
+    (128, 64, 1, 1, 512, 72),        # 1x1 (pointwise loader), 4.8 GB in
+])
+def test_conv_beyond_4GB_equals_the_same_images_alone(case):
+    """BASELINE configs[3] shapes put activations past 4 GB (yolov5l, batch 128, 1024x1024: 4.3 GB after the first layers).  The loader's
+    per-lane offsets are 32-bit and relative to a 64-bit tile base; the epilogue's are 64-bit.  Property: convolution is per image, so
+    the last two images of a > 4 GB batch must come out bit-identical to the same two images run as a batch of two — forward, and the
+    data gradient (class walk at stride 2) — and the first image too."""
+    C, K, R, stride, H, N = case
+    pad = R // 2
+    g = torch.Generator().manual_seed(3)
+    w = (torch.randn((K, C, R, R), generator=g) * (1.0 / (C * R * R)) ** 0.5).to(DEV)
+    base = torch.randn((4, H, H, C), generator=g).to(DEV).bfloat16()
+    x = base.repeat(N // 4, 1, 1, 1)                          # N images, period 4
+    assert x.numel() * 2 > (1 << 31) and x.is_contiguous()
+    Ho = ops.out_dim(H, R, stride, pad)
+    wp = ops.pack_alloc(K, C, R, R, stride, pad, ops.PACK_FWD, torch.bfloat16, DEV)
+    ops.run([ops.rec_pack(w, None, stride, pad, ops.PACK_FWD, wp)])
+
+    def fwd(inp):
+        y = torch.empty((inp.shape[0], Ho, Ho, K), dtype=torch.bfloat16, device=DEV)
+        ops.run([ops.rec_conv_fwd(inp, wp, y, K, R, R, stride, pad)])
+        return y
+    y = fwd(x)
+    y2 = fwd(x[-2:].contiguous())
+    assert torch.equal(y[-2:], y2) and torch.equal(y[:1], y2[:1] if N % 4 == 2 else fwd(x[:1].contiguous()))
+    assert max(x.numel(), y.numel()) * 2 > (1 << 32)
+    # data gradient of the same layer: dy (N, Ho, Ho, K) -> dx
+    wd = ops.pack_alloc(K, C, R, R, stride, pad, ops.PACK_DGRAD, torch.bfloat16, DEV)
+    ops.run([ops.rec_pack(w, None, stride, pad, ops.PACK_DGRAD, wd)])
+    del x
+
+    def dgrad(dy):
+        dx = torch.empty((dy.shape[0], H, H, C), dtype=torch.bfloat16, device=DEV)
+        ops.run([ops.rec_conv_dgrad(dy, wd, dx, R, R, stride, pad)])
+        return dx
+    dx = dgrad(y)
+    assert torch.equal(dx[-2:], dgrad(y[-2:].contiguous()))
+    ref = F.conv2d(base[2:4].float().permute(0, 3, 1, 2).cpu(), w.bfloat16().float().cpu(), None, stride, pad).permute(0, 2, 3, 1)
+    assert relmax(y[-2:], ref) < 1.5e-2
+
+
 def test_c4_size_nms_properties_and_oracle():
     """C4 geometry: 1024x1024 tiles -> 64512 candidates per tile, dense nuclei (4096 / 16384 survivors)."""
     from oracle import nms_ref
