@@ -83,7 +83,8 @@ def make_optimizer(model, hyp, batch_total):
             g_bn.append(m.weight)
         elif hasattr(m, 'weight') and isinstance(m.weight, torch.nn.Parameter):
             g_w.append(m.weight)
-    opt = torch.optim.SGD(g_bn, lr=hyp['lr0'], momentum=hyp['momentum'], nesterov=True)
+    from hd_yolo_amd.optim import SGD          # torch.optim.SGD's update, one launch for all tensors (csrc/optim.hip)
+    opt = SGD(g_bn, lr=hyp['lr0'], momentum=hyp['momentum'], nesterov=True)
     opt.add_param_group({'params': g_w, 'weight_decay': wd})
     opt.add_param_group({'params': g_b})
     return opt

@@ -22,6 +22,8 @@ _P, _I, _L, _F, _Z = c_void_p, c_int, c_longlong, c_float, c_size_t
 # name -> (restype, argtypes); must list every symbol include/hdyolo.h declares (tests check this)
 SIGNATURES = {
     'hdy_last_error': (c_char_p, []),
+    'hdy_sgd_blocks': (_I, [_L]),
+    'hdy_sgd_step': (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _I, _P]),
     'hdy_version': (_I, []),
     'hdy_conv_out_dim': (_I, [_I, _I, _I, _I]),
     'hdy_conv_mtiles': (_I, [_L]),
@@ -96,6 +98,12 @@ class PackDesc(ctypes.Structure):
 class BnEvalDesc(ctypes.Structure):
     """mirror of hdy_bn_eval_desc (include/hdyolo.h)"""
     _fields_ = [(n, c_void_p) for n in ('gamma', 'beta', 'running_mean', 'running_var', 'scale', 'shift')] + [('K', c_int), ('eps', c_float)]
+
+
+class SgdDesc(ctypes.Structure):
+    """mirror of hdy_sgd_desc (include/hdyolo.h)"""
+    _fields_ = [('p', c_void_p), ('g', c_void_p), ('buf', c_void_p), ('n', c_longlong), ('group', c_int), ('first', c_int), ('first_block', c_int),
+                ('pad_', c_int)]
 
 
 class StatReq(ctypes.Structure):

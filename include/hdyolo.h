@@ -281,6 +281,23 @@ int hdy_softdice(const float* logits, int ldl, const float* targets, const float
                  const float* upstream, float* dlogits, int lddl, float* workspace, void* stream);
 int hdy_softmax2d(const float* logits, int ldl, float* probs, int ldp, long long M, int nc, void* stream);
 
+/* ---- optimizer step of the training loop (reference: train.py:208-233 torch.optim.SGD(momentum, nesterov=True) in three parameter
+ * groups, stepped at train.py:478).  One launch for all tensors: a device table of descriptors (fp32 parameter, gradient, momentum
+ * buffer or NULL, element count, parameter group, first = the buffer is uninitialised: buf = g'), first_block = running sum of
+ * hdy_sgd_blocks(n).  g' = g + wd*p; buf = momentum*buf + (1-dampening)*g'; p -= lr * (nesterov ? g' + momentum*buf : buf).
+ * lr / momentum / dampening / weight_decay: HOST arrays of ngroups (<= HDY_SGD_MAX_GROUPS) values, passed by value to the kernel. */
+#define HDY_SGD_MAX_GROUPS 8
+typedef struct hdy_sgd_desc {
+    float* p;
+    const float* g;
+    float* buf;
+    long long n;
+    int group, first, first_block, pad_;
+} hdy_sgd_desc;
+int hdy_sgd_blocks(long long n);
+int hdy_sgd_step(const hdy_sgd_desc* table_device, int ndesc, int total_blocks, const float* lr, const float* momentum, const float* dampening,
+                 const float* weight_decay, int ngroups, int nesterov, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,7 +23,7 @@ python3 scripts/trace_gaps.py $OUT/bench/bench_kernel_trace.csv 6 > $OUT/trace_g
 python3 scripts/pmc_summary.py $OUT/fetch/fetch_counter_collection.csv $OUT/write/write_counter_collection.csv conv3x3_c64_kernel $OUT/conv3x3_pmc.json > /dev/null 2>&1
 python3 scripts/counters_summary.py $OUT/mfma/mfma_counter_collection.csv $OUT/lds/lds_counter_collection.csv conv3x3_c64_kernel $OUT/roof/roof_kernel_stats.csv $OUT/conv3x3_counters.json > /dev/null 2>&1
 ls $OUT $OUT/* | head -60
-tail -1 $OUT/bench.log | cut -c1-300
-tail -1 $OUT/infer.log | cut -c1-300
-tail -1 $OUT/hnet.log | cut -c1-300
+grep "^{" $OUT/bench.log | tail -1 | cut -c1-300
+grep "^{" $OUT/infer.log | tail -1 | cut -c1-300
+grep "^{" $OUT/hnet.log | tail -1 | cut -c1-300
 cat $OUT/variants.log | cut -c1-300

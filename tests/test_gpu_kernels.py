@@ -592,3 +592,48 @@ def test_dgrad_serves_batchnorm_backward_statistics(case):
         for got, ref, what in ((dg, dg2, 'dgamma'), (db, db2, 'dbeta'), (c1, r1, 'c1'), (c2, r2, 'c2')):
             assert_close(got.cpu(), ref.cpu(), 1e-4, what)       # SUM du*xhat as invstd*(SUM du*y - mean*SUM du): mild cancellation
     assert dx._base[..., :8].float().eq(7.0).all()
+
+
+def test_fused_sgd_matches_torch_sgd_step_by_step():
+    """hd_yolo_amd.optim.SGD (one launch for all tensors) against torch.optim.SGD on the reference's recipe (train.py:208-233: three
+    groups, Nesterov, weight decay on one group only, lr / momentum rewritten every step by the warm-up): parameters and momentum
+    buffers after each of 4 steps, a parameter without a gradient, odd sizes (scalar tail path), and state_dict interchange."""
+    from hd_yolo_amd.optim import SGD
+    g = torch.Generator().manual_seed(7)
+    shapes = [(64, 32, 3, 3), (39,), (128,), (5, 7), (1,), (256, 128, 1, 1), (4099,)]
+    mk = lambda: [torch.nn.Parameter(torch.randn(s, generator=torch.Generator().manual_seed(i)).to(DEV)) for i, s in enumerate(shapes)]
+    pa, pb = mk(), mk()
+
+    def build(cls, ps):
+        o = cls(ps[:2], lr=0.01, momentum=0.9, nesterov=True)
+        o.add_param_group({'params': ps[2:5], 'weight_decay': 5e-4})
+        o.add_param_group({'params': ps[5:]})
+        return o
+    oa, ob = build(SGD, pa), build(torch.optim.SGD, pb)
+    for step in range(4):
+        for j, (ga, gb) in enumerate(zip(oa.param_groups, ob.param_groups)):
+            ga['lr'] = gb['lr'] = 0.01 * (step + 1) / 4 if j < 2 else 0.1 - 0.02 * step
+            ga['momentum'] = gb['momentum'] = 0.8 + 0.03 * step
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            if i == 3 and step < 2:
+                a.grad = b.grad = None                      # joins later: its buffer starts at step 2
+                continue
+            gr = torch.randn(a.shape, generator=g).to(DEV)
+            a.grad, b.grad = gr.clone(), gr.clone()
+        oa.step(); ob.step()
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            assert torch.allclose(a, b, rtol=2e-6, atol=1e-7), (step, i)
+            sa, sb = oa.state[a].get('momentum_buffer'), ob.state[b].get('momentum_buffer')
+            assert (sa is None) == (sb is None)
+            if sa is not None:
+                assert torch.allclose(sa, sb, rtol=2e-6, atol=1e-7), (step, i)
+    # checkpoints are interchangeable
+    oc = build(torch.optim.SGD, mk())
+    oc.load_state_dict(oa.state_dict())
+    od = build(SGD, mk())
+    od.load_state_dict(ob.state_dict())
+    assert torch.allclose(od.state[od.param_groups[0]['params'][0]]['momentum_buffer'], ob.state[pb[0]]['momentum_buffer'])
+    with pytest.raises(TypeError):
+        bad = torch.nn.Parameter(torch.zeros(4))
+        bad.grad = torch.zeros(4)
+        SGD([bad], lr=0.1).step()

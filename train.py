@@ -66,7 +66,8 @@ def build_optimizer(model, hyp, name):
     elif name == 'AdamW':
         opt = AdamW(g_bn, lr=hyp['lr0'], betas=(hyp['momentum'], 0.999))
     else:
-        opt = SGD(g_bn, lr=hyp['lr0'], momentum=hyp['momentum'], nesterov=True)
+        from hd_yolo_amd.optim import SGD as FusedSGD          # torch.optim.SGD's update and state layout, one launch for all tensors
+        opt = FusedSGD(g_bn, lr=hyp['lr0'], momentum=hyp['momentum'], nesterov=True)
     opt.add_param_group({'params': g_w, 'weight_decay': hyp['weight_decay']})
     opt.add_param_group({'params': g_b})
     return opt
