@@ -32,7 +32,7 @@ SKIP_WGRAD = os.environ.get('HDY_SKIP_WGRAD') == '1'     # measurement only: no 
 # BN-backward reduce pass served by the launch that completes dz ('1': fused 1x1 backward and dgrad launches, 'fused': the former only).
 # Built, parity-tested (tests/test_gpu_kernels.py, test_gpu_model.py) and NOT the default: the epilogues that would serve the statistics are
 # themselves VALU-bound (exp + rcp per element on top of the store loop) — yolov5s B=64 step 14.09 ms without, 14.31 ('fused'), 14.37 ('1').
-PRODUCER_STATS = os.environ.get('HDY_PRODUCER_STATS', '0')
+PRODUCER_STATS = os.environ.get('HDY_PRODUCER_STATS', 'fused')       # 'fused': statistics served by the fused 1x1 backward kernel only (train step 13.47 vs 13.54 ms off); '1': by dgrad epilogues too (slower); '0': off
 FUSED_1X1 = os.environ.get('HDY_FUSED_1X1', '1') == '1'     # BN-apply + wgrad + dgrad of eligible 1x1 units in one kernel (conv1x1_bwd.hip)
 GRAD_BUCKET_BYTES = int(os.environ.get('HDY_GRAD_BUCKET_MB', '6')) << 20      # granularity of the "these gradients are final" marks
 

@@ -565,13 +565,15 @@ def test_bf16_plan_layer_by_layer_against_fp32_torch():
 
 def test_bf16_plan_layer_by_layer_with_producer_side_statistics():
     """The alternative backward in which the launch that completes a gradient also serves the BatchNorm-backward statistics of the unit(s)
-    that gradient belongs to (HDY_PRODUCER_STATS=1; measured slower, hence off by default) goes through the same unit-by-unit check."""
+    that gradient belongs to goes through the same unit-by-unit check in all three settings: the default serves statistics from the fused 1x1
+    backward kernel only ('fused'), HDY_PRODUCER_STATS=1 from the data-gradient epilogues too (measured slower), 0 switches it off."""
     import subprocess
     import sys
     if os.environ.get('HDY_PRODUCER_STATS_CHILD'):
         return
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, HDY_PRODUCER_STATS='1', HDY_PRODUCER_STATS_CHILD='1', HDY_EXPECT_PRODUCER_STATS='1')
-    p = subprocess.run([sys.executable, '-m', 'pytest', 'tests/test_gpu_model.py', '-q', '-x', '-k', 'test_bf16_plan_layer_by_layer_against_fp32_torch'],
-                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0 and ' passed' in p.stdout, p.stdout[-3000:]
+    for mode, expect in (('1', '1'), ('0', '')):
+        env = dict(os.environ, HDY_PRODUCER_STATS=mode, HDY_PRODUCER_STATS_CHILD='1', HDY_EXPECT_PRODUCER_STATS=expect)
+        p = subprocess.run([sys.executable, '-m', 'pytest', 'tests/test_gpu_model.py', '-q', '-x', '-k', 'test_bf16_plan_layer_by_layer_against_fp32_torch'],
+                           cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0 and ' passed' in p.stdout, (mode, p.stdout[-3000:])
