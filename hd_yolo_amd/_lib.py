@@ -22,6 +22,9 @@ _P, _I, _L, _F, _Z = c_void_p, c_int, c_longlong, c_float, c_size_t
 # name -> (restype, argtypes); must list every symbol include/hdyolo.h declares (tests check this)
 SIGNATURES = {
     'hdy_last_error': (c_char_p, []),
+    'hdy_bn_slab_sums': (_I, [_P, _I, _I, _I, _L, _P, _P]),
+    'hdy_bn_finalize_sums': (_I, [_P, _I, _P, _I, _I] + [_P] * 8 + [_F, _F] + [_P] * 5),
+    'hdy_bn_bwd_coeffs_sums': (_I, [_P, _I, _P, _P, _P]),
     'hdy_sgd_blocks': (_I, [_L]),
     'hdy_sgd_step': (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _I, _P]),
     'hdy_version': (_I, []),

@@ -80,7 +80,8 @@ __device__ __forceinline__ Lane lane_map(int VCt, int chunk) {
 // ---------------------------------------------------------------- finalize (forward)
 // Stage A (only for many tiles): grid (ceil(K/32), G): partial fp64 sums of a range of tiles -> part[g][2][K]
 __global__ __launch_bounds__(1024) void bn_partial_kernel(const float* __restrict__ stats, int stats_ld, int mtiles, int K, int tiles_per_group,
-                                                          double* __restrict__ part) {
+                                                          double* __restrict__ part, double* __restrict__ count_out = nullptr, double count = 0.0) {
+    if (count_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *count_out = count;      // SyncBatchNorm: the element count travels with the sums
     __shared__ double red[2][32][33];
     const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
     const int k = blockIdx.x * 32 + cl;
@@ -119,10 +120,12 @@ template <typename ST>
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const ST* __restrict__ stats, int stats_ld, int mtiles, int K, double count,
                                                            BnParams bn, float eps, float momentum,
                                                            float* __restrict__ scale, float* __restrict__ shift,
-                                                           float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+                                                           float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                           const double* __restrict__ count_dev = nullptr) {
     __shared__ double red[2][32][33];
     const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
     const int k = blockIdx.x * 32 + cl;
+    if (count_dev) count = *count_dev;                   // SyncBatchNorm: the all-reduced element count
     double s = 0.0, ss = 0.0;
     if (k < K) {
         // the whole kernel is one chain of load latencies: keep 8 independent loads in flight per lane
@@ -519,6 +522,45 @@ int hdy_bn_finalize_pair(const float* stats, int stats_ld, int mtiles, int K, in
                          void* workspace, void* stream) {
     const BnParams bn = {gamma_a, beta_a, running_mean_a, running_var_a, gamma_b, beta_b, running_mean_b, running_var_b, Ka};
     return bn_finalize_impl(stats, stats_ld, mtiles, K, count, bn, eps, momentum, scale, shift, save_mean, save_invstd, workspace, stream);
+}
+
+// ---- SyncBatchNorm (reference: train.py:281-283 converts the model with torch.nn.SyncBatchNorm when --sync-bn): the per-rank slabs are
+// summed to fp64 [2][K] + the element count, the caller all-reduces those 2K + 1 doubles, and the finalize reads sums and count from
+// device memory.  Backward: the local statistics pass stays as it is (dgamma / dbeta are local, the gradient all-reduce sums them), its
+// partial slabs go through hdy_bn_slab_sums + all-reduce and c1 / c2 come from the global sums.
+__global__ void bn_bwd_coeffs_sums_kernel(const double* __restrict__ sums, int K, float* __restrict__ c1, float* __restrict__ c2) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const double count = sums[2 * K];                    // [SUM du | SUM du*xhat | count] over all ranks
+    c1[k] = (float)(sums[k] / count);
+    c2[k] = (float)(sums[K + k] / count);
+}
+
+int hdy_bn_slab_sums(const float* slabs, int slab_ld, int nslabs, int K, long long count, double* sums, void* stream) {
+    HDY_ARG(slabs && sums && nslabs > 0 && K > 0 && slab_ld >= K && count > 0, "bn_slab_sums: bad args");
+    hipLaunchKernelGGL(bn_partial_kernel, dim3(cdiv(K, 32), 1), dim3(1024), 0, (hipStream_t)stream, slabs, slab_ld, nslabs, K, nslabs, sums, sums + 2 * K,
+                       (double)count);
+    HDY_LAUNCH_CHECK("bn_slab_sums");
+    return HDY_OK;
+}
+
+int hdy_bn_finalize_sums(const double* sums, int sums_ld, const double* count, int K, int Ka, const float* gamma_a, const float* beta_a, float* running_mean_a, float* running_var_a,
+                         const float* gamma_b, const float* beta_b, float* running_mean_b, float* running_var_b, float eps, float momentum,
+                         float* scale, float* shift, float* save_mean, float* save_invstd, void* stream) {
+    const BnParams bn = {gamma_a, beta_a, running_mean_a, running_var_a, gamma_b, beta_b, running_mean_b, running_var_b, Ka};
+    HDY_ARG(sums && count && gamma_a && beta_a && scale && shift && save_mean && save_invstd && K > 0 && sums_ld >= K, "bn_finalize_sums: bad args");
+    HDY_ARG(Ka == K || (Ka > 0 && Ka < K && gamma_b && beta_b), "bn_finalize_sums: second module's parameters missing or split point outside (0, K)");
+    hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3(cdiv(K, 32)), dim3(1024), 0, (hipStream_t)stream, sums, sums_ld, 1, K, 1.0, bn, eps, momentum, scale,
+                       shift, save_mean, save_invstd, count);
+    HDY_LAUNCH_CHECK("bn_finalize_sums");
+    return HDY_OK;
+}
+
+int hdy_bn_bwd_coeffs_sums(const double* sums, int K, float* c1, float* c2, void* stream) {
+    HDY_ARG(sums && c1 && c2 && K > 0, "bn_bwd_coeffs_sums: bad args");
+    hipLaunchKernelGGL(bn_bwd_coeffs_sums_kernel, dim3(cdiv(K, 256)), dim3(256), 0, (hipStream_t)stream, sums, K, c1, c2);
+    HDY_LAUNCH_CHECK("bn_bwd_coeffs_sums");
+    return HDY_OK;
 }
 
 int hdy_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, int K,

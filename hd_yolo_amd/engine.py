@@ -198,6 +198,7 @@ class Engine:
         self.grad_hooks = []          # callables run after every backward, before publish (data-parallel all-reduce)
         self.bucket_hooks = []        # callables (store, a, b, side_stream) run DURING backward when flat gradient range [a, b) is final
         self.mask_token = None
+        self.sync_bn = None           # SyncBatchNorm: None, True (default process group) or a group; set by parallel.DataParallel(sync_bn=...)
 
     # An engine is a cache of device buffers and marshalled launch records for the module OBJECTS it was traced from: a copied or
     # unpickled module (ModelEMA, Deploy(fuse=True), torch.save of a whole model) gets none and builds its own on first use.
@@ -257,7 +258,7 @@ class Engine:
     def plan_for(self, x, training, dtype):
         ops.require_gpu(x)
         _lib.load()
-        key = (tuple(x.shape), dtype, bool(training), x.device.index, self._check_and_sign())
+        key = (tuple(x.shape), dtype, bool(training), x.device.index, self._check_and_sign(), bool(self.sync_bn) and bool(training))
         plan = self.plans.get(key)
         if plan is None:
             if training and self.store is None:
@@ -269,7 +270,7 @@ class Engine:
             tap_params = []
             if self.extra is not None and training:
                 tap_params = [q for m in (self.extra if not isinstance(self.extra, nn.Module) else [self.extra]) for q in m.parameters()]
-            plan = Plan(b, n, h, tuple(x.shape), dtype, training, x.device, grad_store=self.store, taps=self.taps, tap_params=tap_params)
+            plan = Plan(b, n, h, tuple(x.shape), dtype, training, x.device, grad_store=self.store, taps=self.taps, tap_params=tap_params, sync=self.sync_bn)
             plan.bucket_hook = self._bucket_ready
             self.plans[key] = plan
         self.last_plan = plan

@@ -318,6 +318,25 @@ def rec_bn_finalize_pair(stats, mtiles, K, Ka, count, bn_a, bn_b, scale, shift, 
                                      ptr(rvb), eps, momentum, ptr(scale), ptr(shift), ptr(save_mean), ptr(save_invstd), ptr(ws)))
 
 
+def rec_bn_slab_sums(slabs, nslabs, K, count, sums):
+    """SyncBatchNorm: fp32 slabs [nslabs][2][K] -> sums = 2K + 1 doubles [SUM | SUM2 | count] (the buffer the caller all-reduces)."""
+    assert sums.dtype == torch.float64 and sums.numel() == 2 * K + 1 and sums.is_contiguous()
+    return _rec(locals(), 'hdy_bn_slab_sums', (ptr(slabs), K, nslabs, K, count, ptr(sums)))
+
+
+def rec_bn_finalize_sums(sums, Ktot, k0, K, Ka, bn_a, bn_b, scale, shift, save_mean, save_invstd, eps=BN_EPS, momentum=BN_MOMENTUM):
+    """finalize of the channels [k0, k0 + K) of an all-reduced sums block over Ktot channels; bn_b: the second module of a pair (Ka < K)"""
+    ga, ba, rma, rva = bn_a
+    gb, bb, rmb, rvb = bn_b if bn_b is not None else (None, None, None, None)
+    base = sums.data_ptr()
+    return _rec(locals(), 'hdy_bn_finalize_sums', (base + 8 * k0, Ktot, base + 16 * Ktot, K, Ka, ptr(ga), ptr(ba), ptr(rma), ptr(rva), ptr(gb), ptr(bb), ptr(rmb),
+                                     ptr(rvb), eps, momentum, ptr(scale), ptr(shift), ptr(save_mean), ptr(save_invstd)))
+
+
+def rec_bn_bwd_coeffs_sums(sums, K, c1, c2):
+    return _rec(locals(), 'hdy_bn_bwd_coeffs_sums', (ptr(sums), K, ptr(c1), ptr(c2)))
+
+
 def rec_bn_eval_coeffs(gamma, beta, rmean, rvar, scale, shift, eps=BN_EPS):
     return _rec(locals(), 'hdy_bn_eval_coeffs', (ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), eps, gamma.numel(), ptr(scale), ptr(shift)))
 
@@ -353,6 +372,10 @@ def rec_bn_act_bwd_pair(dz_a, dz_b, y, scale, shift, mean, invstd, dy, dgamma_a,
     assert Ka + Kb == K and dz_a.dtype == dz_b.dtype == y.dtype and ws.numel() >= bn_bwd_ws_floats(N * H * W, K)
     return _rec(locals(), 'hdy_bn_act_bwd_pair', (dap, ldda, dbp, lddb, Ka, yp, ldy, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), dyp, lddy, ptr(dgamma_a),
                                     ptr(dbeta_a), ptr(dgamma_b), ptr(dbeta_b), int(accumulate), N * H * W, K, act, dcode(dz_a.dtype), ptr(ws)))
+
+
+def bn_bwd_blocks(M):
+    return _lib.query('hdy_bn_bwd_blocks', M)
 
 
 def bn_bwd_ws_floats(M, K):

@@ -142,9 +142,11 @@ class DataParallel:
     """Thin wrapper with the call surface the entry points need (`model(x, targets)`, `.module`-style access through
     hdy_dp_module): broadcasts rank 0's state once and installs the flat all-reduce as the engine's gradient hook."""
 
-    def __init__(self, model, nbuckets=None, overlap=True):
+    def __init__(self, model, nbuckets=None, overlap=True, sync_bn=False):
         self.hdy_dp_module = model
         broadcast_state(model, 0)
+        if sync_bn:                        # train.py --sync-bn (reference: train.py:281-283): BatchNorm statistics over all ranks' tiles
+            model._eng().sync_bn = True
         self.reducer = GradAllReduce(nbuckets, overlap=overlap)
         model._eng().grad_hooks.append(self.reducer)
         model._eng().bucket_hooks.append(self.reducer.bucket)

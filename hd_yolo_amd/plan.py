@@ -107,12 +107,15 @@ def _is(m, name):
 
 
 class Plan:
-    def __init__(self, backbone, neck, head, shape, dtype, training, device, grad_store=None, taps=(), tap_params=()):
+    def __init__(self, backbone, neck, head, shape, dtype, training, device, grad_store=None, taps=(), tap_params=(), sync=None):
         """backbone / neck: the metayolo CSPDarkNet / FPN containers (neck, head may be None);
         head: Detect module or None; shape = (B, 3, H, W).
         Feature-input plans (FPN.forward / Detect.forward called on bare feature maps): backbone is None and shape is
         {layer index: (B, C, H, W)}; eval only."""
         self.dtype, self.training, self.device = dtype, training, device
+        # SyncBatchNorm (train.py --sync-bn; reference: train.py:281-283): None = per-rank statistics; True = the default process group, or a
+        # group object: every training BatchNorm all-reduces its (SUM, SUM2, count) forward and its (SUM du, SUM du*xhat, count) backward
+        self.sync = sync if training else None
         self.ext_shapes = dict(shape) if isinstance(shape, dict) else None
         if self.ext_shapes is not None:
             if backbone is not None or training:
@@ -389,6 +392,7 @@ class Plan:
         self.bn_ws = self._new(max_bnws, dtype=f32)
         kmax = max(u.K for u in self.units if isinstance(u, ConvUnit))
         self.fin_ws = self._new(32 * 2 * kmax, dtype=torch.float64)
+        self.sync_sums = self._new(2 * kmax + 1, dtype=torch.float64) if self.sync else None
         # gradient storage mirrors activation storage
         for v in self.vals:
             if v.parts is not None or v.cat is None:
@@ -436,6 +440,24 @@ class Plan:
                     M = o0.n * o0.h * o0.w
                     stats = None if u.frozen else self.stats[:u.mtiles * 2 * u.K].view(u.mtiles, 2, u.K)
                     recs.append(ops.rec_conv_fwd(x, u.wp, u.yraw, u.K, u.k, u.k, u.s, u.p, stats=stats, stem_hw=stem_hw))
+                    if self.sync and not u.frozen:
+                        # SyncBatchNorm: slabs -> [SUM | SUM2 | count] in fp64, all-reduced, then the usual finalize from the global sums
+                        buf = self.sync_sums[:2 * u.K + 1]
+                        recs.append(ops.rec_bn_slab_sums(stats, u.mtiles, u.K, M, buf))
+                        recs.append(self._sync_call(buf))
+                        pair_fwd = len(u.mods) == 2 and u.res is None
+                        k0 = 0
+                        for i, (m, o) in enumerate(zip(u.mods, u.outs)):
+                            K = m.conv.out_channels
+                            recs.append(ops.rec_bn_finalize_sums(buf, u.K, k0, K, K, self._bn(m), None, u.scale[k0:], u.shift[k0:], u.mean[k0:], u.invstd[k0:],
+                                                                 eps=m.bn.eps, momentum=m.bn.momentum))
+                            if not pair_fwd:
+                                res = u.res.t() if u.res is not None else None
+                                recs.append(ops.rec_bn_act_fwd(u.yraw[..., k0:k0 + K], u.scale[k0:k0 + K], u.shift[k0:k0 + K], o.t(), res=res, act=u.act))
+                            k0 += K
+                        if pair_fwd:
+                            recs.append(ops.rec_bn_act_fwd_pair(u.yraw, u.scale, u.shift, u.outs[0].t(), u.outs[1].t(), act=u.act))
+                        continue
                     if len(u.mods) == 2 and not u.frozen and u.res is None:
                         # the C3 pair: per-channel BatchNorm over the whole 2c-wide raw tensor in one finalize + one apply pass
                         Ka = u.mods[0].conv.out_channels
@@ -554,6 +576,12 @@ class Plan:
         v.ginit = True
         return acc
 
+    def _sync_call(self, buf):
+        """launch-list record that all-reduces a SyncBatchNorm sums buffer in place (on the current stream, as every other record)"""
+        import torch.distributed as dist
+        group = None if self.sync is True else self.sync
+        return ('@call', lambda buf=buf, group=group: dist.all_reduce(buf, group=group))
+
     def _compile_backward(self):
         recs = []
         self._grad_log = []
@@ -659,7 +687,8 @@ class Plan:
                 if not u.outs[0].needs_grad:
                     continue
                 o0 = u.outs[0]
-                fused = self._fusable_1x1(u)
+                sync = bool(self.sync) and u.has_bn and not u.frozen
+                fused = self._fusable_1x1(u) and not sync
                 pair = len(u.mods) == 2 and not u.frozen
                 dy = None
                 if not fused:
@@ -672,7 +701,23 @@ class Plan:
                 M = o0.n * o0.h * o0.w
                 c1, c2 = self.bn_c12[0, :u.K], self.bn_c12[1, :u.K]
                 prod = None
-                if PRODUCER_STATS != '0' and self.dtype == torch.bfloat16 and u.has_bn and not u.frozen and not USE_GRAPHS:
+                if sync:
+                    # SyncBatchNorm: local statistics pass (local dgamma / dbeta: the gradient all-reduce sums them), its partial slabs -> fp64 sums
+                    # -> all-reduce -> c1 / c2 of the GLOBAL batch -> one apply pass
+                    nb = ops.bn_bwd_blocks(M)
+                    k0 = 0
+                    for m, o in zip(u.mods, u.outs):
+                        K = m.conv.out_channels
+                        buf = self.sync_sums[:2 * K + 1]
+                        recs.append(ops.rec_bn_act_bwd(o.gread(), u.yraw[..., k0:k0 + K], u.scale[k0:k0 + K], u.shift[k0:k0 + K], u.mean[k0:k0 + K],
+                                                       u.invstd[k0:k0 + K], None, self._grad_views(m.bn.weight), self._grad_views(m.bn.bias), self.bn_ws, act=u.act))
+                        recs.append(ops.rec_bn_slab_sums(self.bn_ws[:nb * 2 * K].view(nb, 2, K), nb, K, M, buf))
+                        recs.append(self._sync_call(buf))
+                        recs.append(ops.rec_bn_bwd_coeffs_sums(buf, K, c1[k0:k0 + K], c2[k0:k0 + K]))
+                        k0 += K
+                    recs.append(ops.rec_bn_act_bwd_apply(u.outs[0].gread(), u.outs[1].gread() if len(u.outs) > 1 else None, u.yraw, u.scale, u.shift, u.mean,
+                                                         u.invstd, c1, c2, dy, act=u.act))
+                if not sync and PRODUCER_STATS != '0' and self.dtype == torch.bfloat16 and u.has_bn and not u.frozen and not USE_GRAPHS:
                     prod = [last.get(id(o)) for o in u.outs]
                     kinds = ('dgrad', 'fused') if PRODUCER_STATS == '1' else ('fused',)
                     ok = all(q is not None and q[0] in kinds and q[3] > 0 and o.gfinal is None and o.c % 8 == 0 and q[2] % 8 == 0 and
@@ -693,6 +738,8 @@ class Plan:
                     if not fused:
                         recs.append(ops.rec_bn_act_bwd_apply(u.outs[0].gread(), u.outs[1].gread() if len(u.outs) > 1 else None, u.yraw, u.scale, u.shift, u.mean,
                                                              u.invstd, c1, c2, dy, act=u.act))
+                elif sync:
+                    pass
                 elif pair:
                     ma, mb = u.mods
                     recs.append(ops.rec_bn_act_bwd_pair(u.outs[0].gread(), u.outs[1].gread(), u.yraw, u.scale, u.shift, u.mean, u.invstd, dy,
@@ -702,7 +749,7 @@ class Plan:
                         c1, c2 = ops.bn_bwd_coeffs(self.bn_ws, M, u.K)
                 k0 = 0
                 for m, o in zip(u.mods, u.outs):
-                    if pair or prod is not None:
+                    if pair or prod is not None or sync:
                         break
                     K = m.conv.out_channels
                     dyk = None if dy is None else dy[..., k0:k0 + K]

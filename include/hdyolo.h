@@ -281,6 +281,17 @@ int hdy_softdice(const float* logits, int ldl, const float* targets, const float
                  const float* upstream, float* dlogits, int lddl, float* workspace, void* stream);
 int hdy_softmax2d(const float* logits, int ldl, float* probs, int ldp, long long M, int nc, void* stream);
 
+/* ---- SyncBatchNorm (reference: train.py:281-283, torch.nn.SyncBatchNorm.convert_sync_batchnorm when --sync-bn).  sums = 2*K + 1 doubles:
+ * [SUM x | SUM x^2 | element count].  Forward: hdy_bn_slab_sums over the conv's statistic slabs -> all-reduce(sums) by the caller ->
+ * hdy_bn_finalize_sums (same outputs and running-statistic update as hdy_bn_finalize[_pair]; sums may point at a channel slice of a
+ * wider [2][sums_ld] block, count at its 2*sums_ld-th double; Ka == K: one module).  Backward: hdy_bn_act_bwd[_pair] with dy == NULL (local statistics, local dgamma / dbeta) -> hdy_bn_slab_sums over its
+ * workspace partials (hdy_bn_bwd_blocks(M) slabs of [2][K]) -> all-reduce -> hdy_bn_bwd_coeffs_sums -> hdy_bn_act_bwd_apply. */
+int hdy_bn_slab_sums(const float* slabs, int slab_ld, int nslabs, int K, long long count, double* sums, void* stream);
+int hdy_bn_finalize_sums(const double* sums, int sums_ld, const double* count, int K, int Ka, const float* gamma_a, const float* beta_a, float* running_mean_a, float* running_var_a,
+                         const float* gamma_b, const float* beta_b, float* running_mean_b, float* running_var_b, float eps, float momentum,
+                         float* scale, float* shift, float* save_mean, float* save_invstd, void* stream);
+int hdy_bn_bwd_coeffs_sums(const double* sums, int K, float* c1, float* c2, void* stream);
+
 /* ---- optimizer step of the training loop (reference: train.py:208-233 torch.optim.SGD(momentum, nesterov=True) in three parameter
  * groups, stepped at train.py:478).  One launch for all tensors: a device table of descriptors (fp32 parameter, gradient, momentum
  * buffer or NULL, element count, parameter group, first = the buffer is uninitialised: buf = g'), first_block = running sum of

@@ -32,10 +32,11 @@ def test_train_py_trains_validates_checkpoints_and_resumes(tmp_path):
     assert 'fitness' in out
 
 
-def test_train_py_two_ranks_gloo(tmp_path):
+@pytest.mark.parametrize('extra', [[], ['--sync-bn']])
+def test_train_py_two_ranks_gloo(tmp_path, extra):
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', '29531', 'train.py', '--variant', 'n', '--nc', '2', '--batch-size', '8', '--imgsz', '64', '--epochs', '1',
-           '--steps-per-epoch', '3', '--val-batches', '1', '--project', str(tmp_path), '--name', 'dp', '--exist-ok']
+           '--master-port', '29531' if not extra else '29533', 'train.py', '--variant', 'n', '--nc', '2', '--batch-size', '8', '--imgsz', '64', '--epochs', '1',
+           '--steps-per-epoch', '3', '--val-batches', '1', '--project', str(tmp_path), '--name', 'dp', '--exist-ok'] + extra
     out = run(cmd, env={'HDY_DIST_BACKEND': 'gloo'})
     assert 'epochs completed' in out
 

@@ -116,9 +116,8 @@ def train(hyp, opt, device):
     with_masks = opt.masks and any(getattr(h, 'nc_masks', 0) > 0 for h in model.headers.values())
     if opt.masks and not with_masks:
         raise SystemExit('--masks: the model config has no mask branch (Detect args[3] must be >= 0)')
-    if opt.sync_bn:
-        # The reference's optional SyncBatchNorm (train.py:281-283) is not built: BatchNorm statistics stay per rank (its default)
-        raise SystemExit('--sync-bn is not supported on this path: BatchNorm statistics are per GPU (the reference default)')
+    if opt.sync_bn and WORLD_SIZE == 1:
+        LOGGER.info('--sync-bn has no effect with one process (the reference converts the model only in DDP mode, train.py:281-283)')
     gs = 32
     imgsz = check_img_size(opt.imgsz, gs, floor=gs * 2)
     batch_size = opt.batch_size // WORLD_SIZE                         # per-rank batch, as train.py:287
@@ -147,7 +146,7 @@ def train(hyp, opt, device):
         h['cls'] *= header.nc / 80 * 3 / nl
         h['obj'] *= (imgsz / 640) ** 2 * 3 / nl
     model.half()                                                       # bf16 operands, fp32 master weights
-    net = DataParallel(model) if WORLD_SIZE > 1 else model
+    net = DataParallel(model, sync_bn=opt.sync_bn) if WORLD_SIZE > 1 else model       # --sync-bn: BatchNorm statistics over all ranks (train.py:281-283)
 
     mk = dict(task=task0, masks=with_masks)
     if with_masks:
@@ -246,7 +245,7 @@ def argument_parser():
     p.add_argument('--masks', action='store_true', help='Train mask header.')
     p.add_argument('--label-smoothing', type=float, default=0.0, help='Label smoothing epsilon')
     p.add_argument('--save-period', type=int, default=-1, help='Save checkpoint every x epochs (disabled if < 1)')
-    p.add_argument('--sync-bn', action='store_true', help='(reference flag) SyncBatchNorm: not built, exits with a message')
+    p.add_argument('--sync-bn', action='store_true', help='use SyncBatchNorm, only available in DDP mode')
     p.add_argument('--nosave', action='store_true')
     p.add_argument('--noval', action='store_true')
     p.add_argument('--device', default='')
