@@ -31,6 +31,7 @@ import time
 
 os.environ.setdefault('YOLOv5_VERBOSE', 'false')
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL across processes needs it on this driver
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')               # side stream + comm stream + RCCL's own: see hd_yolo_amd/__init__.py
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -173,8 +174,14 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
+    # HDY_FORCE_DIST=1: go through process-group init, DataParallel and the overlapped all-reduce with ONE rank too — the only way to run
+    # RCCL itself on a one-GPU box (rehearsal of the N > 1 path, tests/test_gpu_entrypoints.py)
+    force_dist = os.environ.get('HDY_FORCE_DIST') == '1'
+    if world > 1 or force_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29541')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         torch.cuda.set_device(local % torch.cuda.device_count())
         # 'gloo' lets several ranks share one GPU when rehearsing the N>1 path; it is also what a box with fewer GPUs than ranks gets
         backend = os.environ.get('HDY_DIST_BACKEND', 'nccl' if torch.cuda.device_count() >= world else 'gloo')
@@ -201,7 +208,7 @@ def main():
     model = model.to(device).train()
     if args.dtype == 'bf16':
         model.half()                      # bf16 operands, fp32 accumulate / master weights
-    net = DataParallel(model) if world > 1 else model
+    net = DataParallel(model) if (world > 1 or force_dist) else model
     opt = make_optimizer(model, hyp, args.batch * world)
 
     x = synth.synth_images(args.batch, args.size, seed=rank).to(device)
@@ -234,7 +241,7 @@ def main():
         return loss
 
     def fence():
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -260,7 +267,7 @@ def main():
         loss = step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or force_dist:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = tmax.item()
@@ -275,7 +282,7 @@ def main():
             'config': {'workload': f'metayolo yolov5{args.variant} {args.nc}-class nuclei, {args.size}x{args.size} RGB tiles, '
                                    f'batch {args.batch}/GPU, train step = fwd + DetLoss + bwd + all-reduce + SGD(nesterov)',
                        'global_batch': args.batch * world, 'parallelism': f'dp{world}',
-                       'world_size': dist.get_world_size() if world > 1 else 1, 'backend': backend},
+                       'world_size': dist.get_world_size() if (world > 1 or force_dist) else 1, 'backend': backend},
             'final_loss': round(final_loss, 4),
         }
         from hd_yolo_amd import bench_util
@@ -300,7 +307,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.variant, args.nc, args.size)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

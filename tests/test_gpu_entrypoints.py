@@ -100,3 +100,16 @@ def test_train_py_reads_reference_style_checkpoint(tmp_path):
     out = run([sys.executable, 'val_nuclei.py', '--variant', 'n', '--nc', '2', '--imgsz', '64', '--batch-size', '2', '--batches', '1',
                '--weights', str(tmp_path / 'ref.pt')])
     assert 'fitness' in out
+
+
+def test_bench_py_single_rank_over_rccl():
+    """The N > 1 path with the real collective library: one rank, backend nccl (= RCCL), process group + DataParallel + the overlapped
+    bucketed all-reduce on the comm stream — what a one-GPU box can exercise of `python bench.py --gpus N`."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(HDY_FORCE_DIST='1', HDY_DIST_BACKEND='nccl', YOLOv5_VERBOSE='false', HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_PORT='29547')
+    p = subprocess.run([sys.executable, 'bench.py', '--gpus', '1', '--steps', '3', '--warmup', '1', '--batch', '8', '--no-roofline', '--no-cpu-baseline',
+                        '--no-infer'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=500)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['config']['backend'] == 'nccl' and line['config']['world_size'] == 1 and line['value'] > 0

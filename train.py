@@ -28,6 +28,8 @@ import time
 from copy import deepcopy
 from pathlib import Path
 
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')               # before the HIP runtime loads: see hd_yolo_amd/__init__.py
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 import torch
 import torch.distributed as dist
 from torch.optim import SGD, Adam, AdamW, lr_scheduler

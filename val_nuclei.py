@@ -9,6 +9,8 @@ import os
 import sys
 
 import numpy as np
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')               # before the HIP runtime loads: see hd_yolo_amd/__init__.py
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
