@@ -282,7 +282,8 @@ def main():
             'config': {'workload': f'metayolo yolov5{args.variant} {args.nc}-class nuclei, {args.size}x{args.size} RGB tiles, '
                                    f'batch {args.batch}/GPU, train step = fwd + DetLoss + bwd + all-reduce + SGD(nesterov)',
                        'global_batch': args.batch * world, 'parallelism': f'dp{world}',
-                       'world_size': dist.get_world_size() if (world > 1 or force_dist) else 1, 'backend': backend},
+                       'world_size': dist.get_world_size() if (world > 1 or force_dist) else 1, 'backend': backend,
+                       'allreduce_calls_per_step': (round(net.reducer.calls / (args.steps + args.warmup), 2) if (world > 1 or force_dist) else 0)},
             'final_loss': round(final_loss, 4),
         }
         from hd_yolo_amd import bench_util

@@ -113,3 +113,4 @@ def test_bench_py_single_rank_over_rccl():
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][-1])
     assert line['config']['backend'] == 'nccl' and line['config']['world_size'] == 1 and line['value'] > 0
+    assert line['config'].get('allreduce_calls_per_step', 0) >= 1, line['config']          # the bucketed all-reduce really went through RCCL
