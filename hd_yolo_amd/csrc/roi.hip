@@ -112,20 +112,37 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const T* __restrict__ fe
     st_vec<T>(out + (((size_t)r * P + ph) * P + pw) * C + vc * VE, acc);
 }
 
-// Backward with the scatter privatised per roi: one workgroup per (roi, 32-channel block) accumulates the roi's 14 x 14 x S^2
-// samples into an LDS image of the roi's footprint on the feature map (LDS atomics) and only then adds the footprint to the fp32
-// gradient image — one global atomic per footprint pixel and channel instead of 16 per bin and channel.  The matched truths of a
-// nuclei tile are a few feature pixels wide, so ~200 bins fall onto a handful of pixels: the direct scatter spent 8 ms per call
-// serialising on them.  Rois whose footprint exceeds the LDS tile scatter directly (they are large, hence uncontended).
+// Backward, privatised per roi and WITHOUT scatter: the bilinear weights of a sample factor into a row weight and a column weight, and
+// so does the validity test, hence the gradient of a roi's footprint F (fh x fw feature pixels) is two small matrix products per channel,
+//     dF = Wy^T (D Wx),   Wy[ph][fy] = SUM_iy wy(sample row (ph, iy), fy),   Wx[pw][fx] likewise,   D = dout of the roi / S^2  (P x P),
+// computed deterministically in LDS by one workgroup per (roi, 32-channel block); only the finished footprint goes to the fp32
+// gradient image with one global atomic per pixel and channel (rois overlap).  The matched truths of a nuclei tile are a few feature
+// pixels wide, so ~200 bins x 4 samples fall onto a handful of pixels: the first version scattered them with global atomics (8 ms per
+// call), the second with LDS atomics into the footprint (1.36 ms per call at B=16, 1280x1280: up to 8 bins in flight hit one address).
+// Rois whose footprint exceeds the LDS tile scatter directly (they are large, hence uncontended).
 constexpr int FT = 24;                   // footprint tile side (feature pixels)
 constexpr int CB = 32;                   // channels per workgroup
+constexpr int PM = 16;                   // largest output side handled by the footprint path (P = 14 for the mask head)
+
+__device__ __forceinline__ void axis_sample(float v, int size, bool* ok, int* i0, int* i1, float* lo, float* hi) {
+    *ok = !(v < -1.0f || v > (float)size);
+    if (v <= 0.f) v = 0.f;
+    *i0 = (int)v;
+    if (*i0 >= size - 1) { *i0 = *i1 = size - 1; v = (float)*i0; } else *i1 = *i0 + 1;
+    *hi = v - (float)*i0;                // weight of i1
+    *lo = 1.f - *hi;                     // weight of i0
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void roi_align_bwd_tiled_kernel(float* __restrict__ dfeat, int B, int H, int W, int C, const float* __restrict__ rois,
                                                                   float scale, int P, int S, int aligned, const T* __restrict__ dout) {
-    __shared__ float tile[FT * FT * CB];
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Wy = sm;                          // [PM][FT]
+    float* Wx = Wy + PM * FT;                // [PM][FT]
+    float* D = Wx + PM * FT;                 // [P*P][CB]
+    float* Tm = D + PM * PM * CB;            // [P][fw][CB]
     const int r = blockIdx.x, c0 = blockIdx.y * CB;
-    const int cl = threadIdx.x & (CB - 1), bl = threadIdx.x / CB;      // channel lane, bin lane (8 bins in flight)
+    const int cl = threadIdx.x & (CB - 1), bl = threadIdx.x / CB;      // channel lane, 8 row lanes
     const RoiGeom g = roi_geom(rois + (size_t)r * 5, scale, P, aligned);
     if (g.b < 0 || g.b >= B) return;
     // footprint of all samples (after the clamp of sample_at): rows [fy0, fy1], columns [fx0, fx1]
@@ -134,28 +151,19 @@ __global__ __launch_bounds__(256) void roi_align_bwd_tiled_kernel(float* __restr
     const int fy0 = min(max((int)floorf(fmaxf(ylo, 0.f)), 0), H - 1), fy1 = min(max((int)floorf(fmaxf(yhi, 0.f)) + 1, 0), H - 1);
     const int fx0 = min(max((int)floorf(fmaxf(xlo, 0.f)), 0), W - 1), fx1 = min(max((int)floorf(fmaxf(xhi, 0.f)) + 1, 0), W - 1);
     const int fh = fy1 - fy0 + 1, fw = fx1 - fx0 + 1;
-    const bool tiled = fh <= FT && fw <= FT;
-    if (tiled) {
-        for (int i = threadIdx.x; i < fh * fw * CB; i += 256) tile[i] = 0.f;
-        __syncthreads();
-    }
+    const bool tiled = fh <= FT && fw <= FT && P <= PM;
     const float inv = 1.0f / (float)(S * S);
     const bool ch_ok = c0 + cl < C;
-    for (int bin = bl; bin < P * P; bin += 256 / CB) {
-        const int ph = bin / P, pw = bin - ph * P;
-        const float d = ch_ok ? (float)dout[(((size_t)r * P + ph) * P + pw) * C + c0 + cl] * inv : 0.f;
-        for (int iy = 0; iy < S; ++iy) {
-            const float y = g.y0 + (float)ph * g.bin_h + ((float)iy + 0.5f) * g.bin_h / (float)S;
-            for (int ix = 0; ix < S; ++ix) {
-                const float x = g.x0 + (float)pw * g.bin_w + ((float)ix + 0.5f) * g.bin_w / (float)S;
-                const Sample s = sample_at(y, x, H, W);
-                if (!s.ok || !ch_ok) continue;
-                if (tiled) {
-                    atomicAdd(&tile[((s.y0 - fy0) * fw + (s.x0 - fx0)) * CB + cl], d * s.w00);
-                    atomicAdd(&tile[((s.y0 - fy0) * fw + (s.x1 - fx0)) * CB + cl], d * s.w01);
-                    atomicAdd(&tile[((s.y1 - fy0) * fw + (s.x0 - fx0)) * CB + cl], d * s.w10);
-                    atomicAdd(&tile[((s.y1 - fy0) * fw + (s.x1 - fx0)) * CB + cl], d * s.w11);
-                } else {
+    if (!tiled) {
+        for (int bin = bl; bin < P * P; bin += 256 / CB) {
+            const int ph = bin / P, pw = bin - ph * P;
+            const float d = ch_ok ? (float)dout[(((size_t)r * P + ph) * P + pw) * C + c0 + cl] * inv : 0.f;
+            for (int iy = 0; iy < S; ++iy) {
+                const float y = g.y0 + (float)ph * g.bin_h + ((float)iy + 0.5f) * g.bin_h / (float)S;
+                for (int ix = 0; ix < S; ++ix) {
+                    const float x = g.x0 + (float)pw * g.bin_w + ((float)ix + 0.5f) * g.bin_w / (float)S;
+                    const Sample s = sample_at(y, x, H, W);
+                    if (!s.ok || !ch_ok) continue;
                     const size_t base = (size_t)g.b * H * W;
                     atomicAdd(dfeat + (base + (size_t)s.y0 * W + s.x0) * C + c0 + cl, d * s.w00);
                     atomicAdd(dfeat + (base + (size_t)s.y0 * W + s.x1) * C + c0 + cl, d * s.w01);
@@ -164,14 +172,42 @@ __global__ __launch_bounds__(256) void roi_align_bwd_tiled_kernel(float* __restr
                 }
             }
         }
+        return;
     }
-    if (!tiled) return;
+    // axis weight tables: thread t < P builds row t of Wy, thread P <= t < 2P row t - P of Wx (no two threads share an entry)
+    if ((int)threadIdx.x < 2 * P) {
+        const bool isx = (int)threadIdx.x >= P;
+        const int pb = isx ? (int)threadIdx.x - P : (int)threadIdx.x;
+        float* row = (isx ? Wx : Wy) + pb * FT;
+        const int n = isx ? fw : fh, f0 = isx ? fx0 : fy0, size = isx ? W : H;
+        const float o = isx ? g.x0 : g.y0, bs = isx ? g.bin_w : g.bin_h;
+        for (int j = 0; j < n; ++j) row[j] = 0.f;
+        for (int i = 0; i < S; ++i) {
+            const float v = o + (float)pb * bs + ((float)i + 0.5f) * bs / (float)S;
+            bool ok; int i0, i1; float lo, hi;
+            axis_sample(v, size, &ok, &i0, &i1, &lo, &hi);
+            if (!ok) continue;
+            row[i0 - f0] += lo;
+            row[i1 - f0] += hi;
+        }
+    }
+    // D: the roi's output gradient, scaled
+    for (int bin = bl; bin < P * P; bin += 256 / CB) D[bin * CB + cl] = ch_ok ? (float)dout[((size_t)r * P * P + bin) * C + c0 + cl] * inv : 0.f;
     __syncthreads();
-    for (int i = threadIdx.x; i < fh * fw * CB; i += 256) {
-        const int c = i & (CB - 1), px = i / CB;
-        const int fy = px / fw, fx = px - fy * fw;
-        const float v = tile[i];
-        if (v != 0.f && c0 + c < C) atomicAdd(dfeat + (((size_t)g.b * H + fy0 + fy) * W + fx0 + fx) * C + c0 + c, v);
+    // Tm[ph][fx][c] = SUM_pw D[ph][pw][c] * Wx[pw][fx]
+    for (int o = bl; o < P * fw; o += 256 / CB) {
+        const int ph = o / fw, fx = o - ph * fw;
+        float acc = 0.f;
+        for (int pw = 0; pw < P; ++pw) acc += D[(ph * P + pw) * CB + cl] * Wx[pw * FT + fx];
+        Tm[o * CB + cl] = acc;
+    }
+    __syncthreads();
+    // dF[fy][fx][c] = SUM_ph Wy[ph][fy] * Tm[ph][fx][c]  -> one global atomic per footprint pixel and channel
+    for (int o = bl; o < fh * fw; o += 256 / CB) {
+        const int fy = o / fw, fx = o - fy * fw;
+        float acc = 0.f;
+        for (int ph = 0; ph < P; ++ph) acc += Wy[ph * FT + fy] * Tm[(ph * fw + fx) * CB + cl];
+        if (acc != 0.f && ch_ok) atomicAdd(dfeat + (((size_t)g.b * H + fy0 + fy) * W + fx0 + fx) * C + c0 + cl, acc);
     }
 }
 
@@ -234,11 +270,19 @@ int hdy_roi_align_bwd(const void* dout, float* dfeat_f32, int B, int H, int W, i
     const int VE = dtype == HDY_BF16 ? 8 : 4;
     HDY_ARG(dout && rois && dfeat_f32 && C % VE == 0 && (((uintptr_t)dout) & 15) == 0, "roi_align_bwd: pointers / channel vectors");
     const dim3 grid(R, (C + CB - 1) / CB);
+    const int pp = P <= PM ? P : 1;
+    const size_t smem = (size_t)(2 * PM * FT + PM * PM * CB + pp * FT * CB) * sizeof(float);        // Wy, Wx, D, Tm: 70 KB at P = 14
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)roi_align_bwd_tiled_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * PM * FT + PM * PM * CB + PM * FT * CB) * 4);
+        (void)hipFuncSetAttribute((const void*)roi_align_bwd_tiled_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * PM * FT + PM * PM * CB + PM * FT * CB) * 4);
+        attr_set = true;
+    }
     if (dtype == HDY_BF16)
-        hipLaunchKernelGGL(roi_align_bwd_tiled_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, dfeat_f32, B, H, W, C, rois, spatial_scale, P,
+        hipLaunchKernelGGL(roi_align_bwd_tiled_kernel<bf16_t>, grid, dim3(256), smem, (hipStream_t)stream, dfeat_f32, B, H, W, C, rois, spatial_scale, P,
                            sampling_ratio, aligned, (const bf16_t*)dout);
     else
-        hipLaunchKernelGGL(roi_align_bwd_tiled_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, dfeat_f32, B, H, W, C, rois, spatial_scale, P,
+        hipLaunchKernelGGL(roi_align_bwd_tiled_kernel<float>, grid, dim3(256), smem, (hipStream_t)stream, dfeat_f32, B, H, W, C, rois, spatial_scale, P,
                            sampling_ratio, aligned, (const float*)dout);
     HDY_LAUNCH_CHECK("roi_align_bwd");
     return HDY_OK;
