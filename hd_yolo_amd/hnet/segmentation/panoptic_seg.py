@@ -53,8 +53,7 @@ class _SegFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        dl = ctx.dl * g.reshape(-1)[:1]
-        dfeats = ctx.run.backward(dl, ctx.grad_of)
+        dfeats = ctx.run.backward(ctx.dl, ctx.grad_of, scale=g)          # the upstream factor goes in at the connector's resolution
         return (None, None, None, None) + tuple(d.permute(0, 3, 1, 2).to(t) for d, t in zip(dfeats, ctx.dtypes))
 
 

@@ -95,20 +95,30 @@ class PanopticRun:
         low = torch.zeros((N, H, W, kp), dtype=torch.float32, device=total.device)
         ops.run([ops.rec_conv_fwd(total, wl, low[..., :nc], nc, 1, 1, 1, 0, shift=cc.bias.detach().float())])
         out_size = (H, W) if out_size is None else tuple(out_size)
-        logits = low if out_size == (H, W) else ops.bilinear_fwd(low, out_size)
+        # the resized logits are the largest tensor of the branch (mask resolution): they carry the classes padded to one 16-byte vector
+        # only (4 floats for <= 4 classes), not to the conv's 8 — at 3 classes half the bytes of the resize, the dice passes and their backward
+        nc4 = (nc + 3) // 4 * 4
+        logits = low if out_size == (H, W) else ops.bilinear_fwd(low[..., :nc4], out_size)
         self.total, self.low_shape, self.out_size = total, (N, H, W, kp), out_size
         if not train:
             self.tape = None
-        return logits                                          # fp32 NHWC (N, Ho, Wo, kp), channels [nc, kp) are zero
+        return logits                                          # fp32 NHWC (N, Ho, Wo, nc4 or kp), channels [nc, ..) are zero
 
-    def backward(self, dlogits, grad_of):
-        """dlogits fp32 (N, Ho, Wo, kp) -> list of feature gradients (NHWC, finest first); parameter gradients into grad_of(p)."""
+    def backward(self, dlogits, grad_of, scale=None):
+        """dlogits fp32 (N, Ho, Wo, nc4 | kp) -> list of feature gradients (NHWC, finest first); parameter gradients into grad_of(p).
+        scale: 1-element tensor multiplied in AFTER the resize backward (linear: the same result, on 1/64 of the elements)."""
         dt = self.dtype
         N, H, W, kp = self.low_shape
         dev = dlogits.device
         cc = self.class_conv
         nc = cc.out_channels
-        dlow = dlogits if self.out_size == (H, W) else ops.bilinear_bwd(dlogits, (H, W))
+        if self.out_size == (H, W):
+            dlow = dlogits
+        else:
+            dlow = torch.zeros((N, H, W, kp), dtype=torch.float32, device=dev)
+            ops.bilinear_bwd(dlogits, (H, W), out=dlow[..., :dlogits.shape[3]])
+        if scale is not None:
+            dlow = dlow * scale.reshape(-1)[:1].to(dlow.dtype)
         g = dlow.to(dt)
         ws_bn = torch.empty(ops.bn_bwd_ws_floats(N * H * W, max(kp, 8)), dtype=torch.float32, device=dev)
         tmp = torch.empty(kp, dtype=torch.float32, device=dev)
