@@ -54,6 +54,7 @@ SIGNATURES = {
     'hdy_groupnorm_bwd': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     'hdy_bilinear_fwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'hdy_bilinear_bwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'hdy_bilinear_bwd_axis': (_I, [_P, _I, _P, _I, _L, _I, _I, _I, _I, _I, _I, _P]),
     'hdy_softdice_workspace_floats': (_Z, [_I, _I]),
     'hdy_softdice': (_I, [_P, _I, _P, _P, _I, _I, _I, _P, _P, _P, _I, _P, _P]),
     'hdy_softmax2d': (_I, [_P, _I, _P, _I, _L, _I, _P]),

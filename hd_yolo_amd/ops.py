@@ -729,6 +729,12 @@ def bilinear_bwd(dy, in_size, out=None, accumulate=False):
         out = torch.empty((N, Hi, Wi, C), dtype=dy.dtype, device=dy.device)
         accumulate = False
     op, _, _, _, _, ldo = nhwc(out)
+    if Wo >= 2 * Wi and Ho >= 2 * Hi:
+        # separable: W pass over every gradient row (contiguous reads, result Wo / Wi times smaller), then the H pass
+        tmp = torch.empty((N, Ho, Wi, C), dtype=dy.dtype, device=dy.device)
+        _lib.call('hdy_bilinear_bwd_axis', dyp, lddy, tmp.data_ptr(), C, N * Ho, Wi, Wo, 1, C, 0, dcode(dy.dtype), stream_ptr())
+        _lib.call('hdy_bilinear_bwd_axis', tmp.data_ptr(), C, op, ldo, N, Hi, Ho, Wi, C, int(accumulate), dcode(dy.dtype), stream_ptr())
+        return out
     _lib.call('hdy_bilinear_bwd', dyp, lddy, op, ldo, N, Hi, Wi, Ho, Wo, C, int(accumulate), dcode(dy.dtype), stream_ptr())
     return out
 

@@ -276,6 +276,10 @@ int hdy_groupnorm_bwd(const void* dout, int lddo, const void* x, int ldx, const 
                       void* stream);
 int hdy_bilinear_fwd(const void* x, int ldx, void* y, int ldy, int N, int Hi, int Wi, int Ho, int Wo, int C, int accumulate, int dtype, void* stream);
 int hdy_bilinear_bwd(const void* dy, int lddy, void* dx, int lddx, int N, int Hi, int Wi, int Ho, int Wo, int C, int accumulate, int dtype, void* stream);
+/* one axis of the same (the resize is separable): tensors [outer][Ao -> Ai][inner][ld]; W pass outer = N*Ho, inner = 1, then H pass outer = N,
+ * inner = Wi over the W pass's result — 8x fewer candidate reads than the 2-D gather at the x8 resize of the segmentation logits */
+int hdy_bilinear_bwd_axis(const void* dy, int lddy, void* dx, int lddx, long long outer, int Ai, int Ao, int inner, int C, int accumulate, int dtype,
+                          void* stream);
 size_t hdy_softdice_workspace_floats(int N, int nc);
 int hdy_softdice(const float* logits, int ldl, const float* targets, const float* class_weight, int N, int HW, int nc, float* loss,
                  const float* upstream, float* dlogits, int lddl, float* workspace, void* stream);
