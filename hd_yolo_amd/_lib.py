@@ -22,6 +22,8 @@ _P, _I, _L, _F, _Z = c_void_p, c_int, c_longlong, c_float, c_size_t
 # name -> (restype, argtypes); must list every symbol include/hdyolo.h declares (tests check this)
 SIGNATURES = {
     'hdy_last_error': (c_char_p, []),
+    'hdy_conv_wgrad_stem_fused_ok': (_I, [_I, _I, _I, _I]),
+    'hdy_conv_wgrad_stem_fused': (_I, [_P, _P, _I, _P, _I] + [_P] * 6 + [_I, _I, _I, _I, _P, _I, _P, _I, _I, _P, _Z, _P]),
     'hdy_bn_slab_sums': (_I, [_P, _I, _I, _I, _L, _P, _P]),
     'hdy_bn_finalize_sums': (_I, [_P, _I, _P, _I, _I] + [_P] * 8 + [_F, _F] + [_P] * 5),
     'hdy_bn_bwd_coeffs_sums': (_I, [_P, _I, _P, _P, _P]),

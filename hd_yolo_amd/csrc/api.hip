@@ -344,4 +344,37 @@ int hdy_conv_wgrad(const void* x, int ldx, const void* dy, int lddy, int N, int 
     return rc;
 }
 
+// The stem's weight gradient with the BatchNorm / SiLU backward of its unit applied while the tile is staged (conv_wgrad.hip,
+// wgrad_stem_kernel<.., true>): dz = gradient of the unit's output, y = its raw conv output, c1 / c2 from the statistics pass
+// (hdy_bn_act_bwd with dy == NULL).  The stem has no data gradient, so dy is never materialised.  bf16, K in {16, 32, 64}.
+int hdy_conv_wgrad_stem_fused_ok(int N, int H, int W, int K) {
+    if (K != 16 && K != 32 && K != 64) return 0;
+    const int Ho = hdy_conv_out_dim(H, 6, 2, 2), Wo = hdy_conv_out_dim(W, 6, 2, 2);
+    return hdy_wgrad_stem_grid(N, Ho, Wo, K, HDY_BF16) > 0 ? 1 : 0;
+}
+
+int hdy_conv_wgrad_stem_fused(const void* x, const void* dz, int lddz, const void* y, int ldy, const float* scale, const float* shift, const float* mean,
+                              const float* invstd, const float* c1, const float* c2, int N, int H, int W, int K, float* grad_a, int K_a, float* grad_b,
+                              int K_b, int accumulate, void* workspace, size_t ws_bytes, void* stream) {
+    HDY_ARG(x && dz && y && grad_a && K_a > 0 && K_a + K_b <= K && K_b >= 0 && (K_b == 0) == (grad_b == nullptr), "conv_wgrad_stem_fused: bad arguments");
+    HDY_ARG(hdy_conv_wgrad_stem_fused_ok(N, H, W, K), "conv_wgrad_stem_fused: shape not served (K in {16, 32, 64}, output a multiple of 16 x 32)");
+    HDY_ARG(workspace && ws_bytes >= hdy_conv_wgrad_workspace_bytes(N, H, W, 3, K, 6, 6, 2, 2, HDY_BF16, 1), "conv_wgrad_stem_fused: workspace too small");
+    WgradArgs a = {};
+    a.x = x; a.dy = dz; a.lddy = lddz; a.partial = (float*)workspace;
+    a.y = y; a.ldy = ldy; a.bn_scale = scale; a.bn_shift = shift; a.bn_mean = mean; a.bn_invstd = invstd; a.bn_c1 = c1; a.bn_c2 = c2;
+    a.N = N; a.K = K;
+    a.Ho = hdy_conv_out_dim(H, 6, 2, 2);
+    a.Wo = hdy_conv_out_dim(W, 6, 2, 2);
+    a.Hin = H + 4; a.Win = W + 4; a.C = 24; a.ldx = 4; a.span_pixels = 1;
+    a.ih_mul = a.iw_mul = 2; a.dh0 = a.dw0 = 0; a.TH = 6; a.TW = 1;
+    const int Q = a.TH * a.TW * a.C;
+    a.splits = hdy_wgrad_stem_grid(N, a.Ho, a.Wo, K, HDY_BF16);
+    int rc = hdy_wgrad_stem_launch(a, a.splits, (hipStream_t)stream);
+    if (rc) return rc;
+    rc = hdy_wgrad_reduce_launch(a.partial, a.splits, (size_t)K * Q, K_a, Q, 1, 3, 6, 6, grad_a, accumulate, (hipStream_t)stream);
+    if (rc) return rc;
+    if (K_b) rc = hdy_wgrad_reduce_launch(a.partial + (size_t)K_a * Q, a.splits, (size_t)K * Q, K_b, Q, 1, 3, 6, 6, grad_b, accumulate, (hipStream_t)stream);
+    return rc;
+}
+
 }  // extern "C"

@@ -242,7 +242,15 @@ constexpr int PROW = PWX * 8, PATCH_B = PH * PROW;      // 544, 19584
 constexpr int PCH = PATCH_B / 16;                       // 1224 16-byte pieces
 constexpr int Q = 144;                                  // 6 x 6 x 4
 
-template <int MT>   // K = 16 * MT
+__device__ __forceinline__ float stem_dsilu(float u) {
+    const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-u));
+    return s * (1.0f + u * (1.0f - s));
+}
+
+// FUSED: the stem has no data gradient, so its BatchNorm-backward output dy has exactly one reader — this kernel.  Instead of an apply
+// pass that writes dy (read dz, read y, write dy: 1.26 GB at 64 x 320 x 320 x 32) and a DMA that reads it back, the tile is staged through
+// registers from dz and y with the apply pass's arithmetic (same expression, same bf16 rounding point: the results are bit-identical).
+template <int MT, bool FUSED>   // K = 16 * MT
 __global__ __launch_bounds__(256) void wgrad_stem_kernel(const WgradArgs p) {
     constexpr int K = MT * 16, DROW = K * 2;             // bytes per dy pixel
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -272,6 +280,18 @@ __global__ __launch_bounds__(256) void wgrad_stem_kernel(const WgradArgs p) {
     }
     const int aoff = (8 * g + q4) * DROW + p4 * 8;
 
+    // FUSED: this thread's 16-byte chunk of a dy pixel is always the same 8 channels (256 % (K/8) == 0): their coefficients stay in registers
+    float sc[8], sh[8], mu[8], is[8], k1[8], k2[8];
+    const bf16_t* __restrict__ yraw = (const bf16_t*)p.y;
+    if constexpr (FUSED) {
+        const int c0 = (tid % (K / 8)) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            sc[i] = p.bn_scale[c0 + i]; sh[i] = p.bn_shift[c0 + i]; mu[i] = p.bn_mean[c0 + i];
+            is[i] = p.bn_invstd[c0 + i]; k1[i] = p.bn_c1[c0 + i]; k2[i] = p.bn_c2[c0 + i];
+        }
+    }
+
     for (int t = blockIdx.x; t < tiles_total; t += gridDim.x) {
         const int n = t / per_img, rem = t - n * per_img;
         const int th = rem / tiles_w, tw = rem - th * tiles_w;
@@ -282,13 +302,41 @@ __global__ __launch_bounds__(256) void wgrad_stem_kernel(const WgradArgs p) {
                                              (void __attribute__((address_space(3)))*)(sP + (pos - lane) * 16), 16, 0, 0);
         }
         const bf16_t* dorg = dy + (((long long)n * p.Ho + th * TOH) * p.Wo + tw * TOW) * p.lddy;
+        if constexpr (FUSED) {
+            constexpr int NV = TOH * TOW * (K / 8) / 256;
+            const bf16_t* yorg = yraw + (((long long)n * p.Ho + th * TOH) * p.Wo + tw * TOW) * p.ldy;
+            i32x4 gq[NV], vq[NV];
 #pragma unroll
-        for (int i = 0; i < TOH * TOW * (K / 8) / 256; ++i) {
-            const int pos = tid + 256 * i;
-            const int pix = pos / (K / 8), part = pos - pix * (K / 8);
-            const int py = pix / TOW, px = pix - py * TOW;
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(dorg + ((long long)py * p.Wo + px) * p.lddy + part * 8),
-                                             (void __attribute__((address_space(3)))*)(sD + (pos - lane) * 16), 16, 0, 0);
+            for (int i = 0; i < NV; ++i) {                 // all of the tile's dz / y vectors of this thread in flight at once
+                const int pos = tid + 256 * i;
+                const int pix = pos / (K / 8), part = pos - pix * (K / 8);
+                const int py = pix / TOW, px = pix - py * TOW;
+                gq[i] = *(const i32x4*)(dorg + ((long long)py * p.Wo + px) * p.lddy + part * 8);
+                vq[i] = *(const i32x4*)(yorg + ((long long)py * p.Wo + px) * p.ldy + part * 8);
+            }
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                V16 gv, yv, o;
+                gv.i = gq[i];
+                yv.i = vq[i];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v = (float)yv.h[e];
+                    const float du = (float)gv.h[e] * stem_dsilu(v * sc[e] + sh[e]);
+                    const float xh = (v - mu[e]) * is[e];
+                    o.h[e] = (bf16_t)(sc[e] * (du - k1[e] - xh * k2[e]));
+                }
+                *(i32x4*)(sD + (tid + 256 * i) * 16) = o.i;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TOH * TOW * (K / 8) / 256; ++i) {
+                const int pos = tid + 256 * i;
+                const int pix = pos / (K / 8), part = pos - pix * (K / 8);
+                const int py = pix / TOW, px = pix - py * TOW;
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(dorg + ((long long)py * p.Wo + px) * p.lddy + part * 8),
+                                                 (void __attribute__((address_space(3)))*)(sD + (pos - lane) * 16), 16, 0, 0);
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -531,12 +579,16 @@ int hdy_wgrad_stem_launch(const WgradArgs& a, int grid, hipStream_t st) {
     HDY_ARG(((uintptr_t)a.x & 15) == 0 && ((uintptr_t)a.dy & 15) == 0 && a.lddy % 8 == 0 && a.Win % 2 == 0, "wgrad(stem): x/dy alignment");
     const size_t smem = stemw::PATCH_B + 64 + (size_t)stemw::TOH * stemw::TOW * a.K * 2;
     const int mt = a.K / 16;
-#define STEMW_LAUNCH(MT)                                                                                                         \
-    {                                                                                                                          \
-        (void)hipFuncSetAttribute((const void*)stemw::wgrad_stem_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-        hipLaunchKernelGGL(stemw::wgrad_stem_kernel<MT>, dim3(grid), dim3(256), smem, st, a);                                  \
+#define STEMW_LAUNCH(MT, FU)                                                                                                         \
+    {                                                                                                                              \
+        (void)hipFuncSetAttribute((const void*)stemw::wgrad_stem_kernel<MT, FU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+        hipLaunchKernelGGL((stemw::wgrad_stem_kernel<MT, FU>), dim3(grid), dim3(256), smem, st, a);                                \
     }
-    if (mt == 1) STEMW_LAUNCH(1) else if (mt == 2) STEMW_LAUNCH(2) else if (mt == 3) STEMW_LAUNCH(3) else STEMW_LAUNCH(4)
+    if (a.y) {
+        HDY_ARG((mt == 1 || mt == 2 || mt == 4) && a.ldy % 8 == 0 && ((uintptr_t)a.y & 15) == 0 && a.bn_scale && a.bn_shift && a.bn_mean && a.bn_invstd &&
+                a.bn_c1 && a.bn_c2, "wgrad(stem, fused BatchNorm backward): K must be 16, 32 or 64 and all coefficient vectors given");
+        if (mt == 1) STEMW_LAUNCH(1, true) else if (mt == 2) STEMW_LAUNCH(2, true) else STEMW_LAUNCH(4, true)
+    } else if (mt == 1) STEMW_LAUNCH(1, false) else if (mt == 2) STEMW_LAUNCH(2, false) else if (mt == 3) STEMW_LAUNCH(3, false) else STEMW_LAUNCH(4, false)
 #undef STEMW_LAUNCH
     HDY_LAUNCH_CHECK("wgrad(stem)");
     return HDY_OK;

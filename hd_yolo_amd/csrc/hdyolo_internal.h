@@ -67,6 +67,10 @@ struct WgradArgs {
     int splits, pix_per_split;
     int ktiles, qtiles;
     int span_pixels;
+    // stem kernel only: y != NULL = `dy` holds dz (gradient of the unit's activation output) and the kernel applies the BatchNorm / SiLU
+    // backward itself while staging the tile: dy = scale * (dz * silu'(y*scale + shift) - c1 - (y - mean)*invstd * c2)
+    const void* y; int ldy;
+    const float *bn_scale, *bn_shift, *bn_mean, *bn_invstd, *bn_c1, *bn_c2;
 };
 
 int hdy_conv_bn_tile(int K);

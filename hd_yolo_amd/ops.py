@@ -224,6 +224,22 @@ def rec_conv_wgrad(x, dy, grad_a, grad_b, R, S, stride, pad, ws, accumulate=Fals
                                ptr(ws), ws.numel() * ws.element_size(), dcode(x.dtype), stem))
 
 
+def wgrad_stem_fused_ok(N, H, W, K, dtype):
+    return dtype == torch.bfloat16 and bool(_lib.query('hdy_conv_wgrad_stem_fused_ok', N, H, W, K))
+
+
+def rec_conv_wgrad_stem_fused(x, dz, y, scale, shift, mean, invstd, c1, c2, hw, grad_a, grad_b, ws, accumulate=False):
+    """stem weight gradient straight from (dz, y): the BatchNorm / SiLU backward is applied while the tile is staged (no dy tensor)"""
+    dzp, N, Ho, Wo, K, lddz = nhwc(dz)
+    yp, _, _, _, _, ldy = nhwc(y)
+    H, W = hw
+    K_a = grad_a.shape[0]
+    K_b = 0 if grad_b is None else grad_b.shape[0]
+    assert dz.dtype == torch.bfloat16 and y.dtype == torch.bfloat16 and grad_a.is_contiguous() and grad_a.dtype == torch.float32
+    return _rec(locals(), 'hdy_conv_wgrad_stem_fused', (ptr(x), dzp, lddz, yp, ldy, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(c1), ptr(c2), N, H, W, K,
+                                          ptr(grad_a), K_a, ptr(grad_b), K_b, int(accumulate), ptr(ws), ws.numel() * ws.element_size()))
+
+
 ALWAYS_REPACK = os.environ.get('HDY_ALWAYS_REPACK') is not None
 
 

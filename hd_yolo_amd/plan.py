@@ -33,6 +33,7 @@ SKIP_WGRAD = os.environ.get('HDY_SKIP_WGRAD') == '1'     # measurement only: no 
 # Built, parity-tested (tests/test_gpu_kernels.py, test_gpu_model.py) and NOT the default: the epilogues that would serve the statistics are
 # themselves VALU-bound (exp + rcp per element on top of the store loop) — yolov5s B=64 step 14.09 ms without, 14.31 ('fused'), 14.37 ('1').
 PRODUCER_STATS = os.environ.get('HDY_PRODUCER_STATS', 'fused')       # 'fused': statistics served by the fused 1x1 backward kernel only (train step 13.47 vs 13.54 ms off); '1': by dgrad epilogues too (slower); '0': off
+STEM_FUSED = os.environ.get('HDY_STEM_FUSED', '1') == '1'   # the stem's weight gradient applies its unit's BatchNorm / SiLU backward itself (no dy tensor)
 FUSED_1X1 = os.environ.get('HDY_FUSED_1X1', '1') == '1'     # BN-apply + wgrad + dgrad of eligible 1x1 units in one kernel (conv1x1_bwd.hip)
 GRAD_BUCKET_BYTES = int(os.environ.get('HDY_GRAD_BUCKET_MB', '6')) << 20      # granularity of the "these gradients are final" marks
 
@@ -656,6 +657,7 @@ class Plan:
                     o.needs_grad = up(u.x)
             elif isinstance(u, UpUnit):
                 u.out.needs_grad = up(u.x)
+        first_conv = next((q for q in self.units if isinstance(q, ConvUnit)), None)      # = the last unit the reversed walk reaches
         for u in reversed(self.units):
             if isinstance(u, DetUnit):
                 x = u.x
@@ -690,8 +692,13 @@ class Plan:
                 sync = bool(self.sync) and u.has_bn and not u.frozen
                 fused = self._fusable_1x1(u) and not sync
                 pair = len(u.mods) == 2 and not u.frozen
+                # the stem has no data gradient: its dy has one reader, the weight-gradient kernel, which can apply the BatchNorm / SiLU backward
+                # itself while it stages the tile (no apply pass, no dy tensor).  It is the last unit of the backward list, so the c1 / c2 it
+                # reads from the statistics workspace on the side stream are not overwritten before the list's final join.
+                stem_fused = (STEM_FUSED and u.stem and not sync and not u.frozen and u.has_bn and len(u.mods) == 1 and u is first_conv and
+                              u.mods[0].conv.weight.requires_grad and ops.wgrad_stem_fused_ok(self.B, self.H, self.W, u.K, self.dtype))
                 dy = None
-                if not fused:
+                if not fused and not stem_fused:
                     slot = nconv % len(self.dy_ring)
                     nconv += 1
                     if slot in slot_user:              # the weight gradient that last read this ring slot must be done
@@ -717,7 +724,7 @@ class Plan:
                         k0 += K
                     recs.append(ops.rec_bn_act_bwd_apply(u.outs[0].gread(), u.outs[1].gread() if len(u.outs) > 1 else None, u.yraw, u.scale, u.shift, u.mean,
                                                          u.invstd, c1, c2, dy, act=u.act))
-                if not sync and PRODUCER_STATS != '0' and self.dtype == torch.bfloat16 and u.has_bn and not u.frozen and not USE_GRAPHS:
+                if not sync and not stem_fused and PRODUCER_STATS != '0' and self.dtype == torch.bfloat16 and u.has_bn and not u.frozen and not USE_GRAPHS:
                     prod = [last.get(id(o)) for o in u.outs]
                     kinds = ('dgrad', 'fused') if PRODUCER_STATS == '1' else ('fused',)
                     ok = all(q is not None and q[0] in kinds and q[3] > 0 and o.gfinal is None and o.c % 8 == 0 and q[2] % 8 == 0 and
@@ -760,7 +767,7 @@ class Plan:
                         recs.append(ops.rec_bn_act_bwd(o.gread(), u.yraw[..., k0:k0 + K], u.scale[k0:k0 + K], u.shift[k0:k0 + K],
                                                        u.mean[k0:k0 + K], u.invstd[k0:k0 + K], dyk,
                                                        self._grad_views(m.bn.weight), self._grad_views(m.bn.bias), self.bn_ws, act=u.act))
-                        if fused:
+                        if fused or stem_fused:
                             c1, c2 = ops.bn_bwd_coeffs(self.bn_ws, M, u.K)
                     k0 += K
                 x = self.prep if u.stem else u.x.t()
@@ -792,6 +799,9 @@ class Plan:
                     continue
                 ga = self._grad_views(u.mods[0].conv.weight)
                 gb = self._grad_views(u.mods[1].conv.weight) if len(u.mods) > 1 else None
+                if stem_fused:
+                    wgrad(ops.rec_conv_wgrad_stem_fused(x, u.outs[0].gread(), u.yraw, u.scale, u.shift, u.mean, u.invstd, c1, c2, stem_hw, ga, None, self.wg_ws))
+                    continue
                 if want_w:
                     wgrad(ops.rec_conv_wgrad(x, dy, ga, gb, u.k, u.k, u.s, u.p, self.wg_ws, stem_hw=stem_hw), reads_dy_slot=slot)
                 if want_x:

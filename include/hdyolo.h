@@ -285,6 +285,15 @@ int hdy_softdice(const float* logits, int ldl, const float* targets, const float
                  const float* upstream, float* dlogits, int lddl, float* workspace, void* stream);
 int hdy_softmax2d(const float* logits, int ldl, float* probs, int ldp, long long M, int nc, void* stream);
 
+/* The stem's weight gradient (layers.py:31 Conv(3, c, 6, 2, 2), backward of train.py:472) with the BatchNorm / SiLU backward of its unit applied
+ * while the gradient tile is staged: dz = gradient of the unit's activation output, y = its raw conv output, c1 / c2 from
+ * hdy_bn_act_bwd(dy = NULL).  The stem has no data gradient, so its dy is never written.  x = the hdy_stem_prep buffer; bf16; K in
+ * {16, 32, 64}; workspace as hdy_conv_wgrad_workspace_bytes(..., stem = 1). */
+int hdy_conv_wgrad_stem_fused_ok(int N, int H, int W, int K);
+int hdy_conv_wgrad_stem_fused(const void* x, const void* dz, int lddz, const void* y, int ldy, const float* scale, const float* shift, const float* mean,
+                              const float* invstd, const float* c1, const float* c2, int N, int H, int W, int K, float* grad_a, int K_a, float* grad_b,
+                              int K_b, int accumulate, void* workspace, size_t ws_bytes, void* stream);
+
 /* ---- SyncBatchNorm (reference: train.py:281-283, torch.nn.SyncBatchNorm.convert_sync_batchnorm when --sync-bn).  sums = 2*K + 1 doubles:
  * [SUM x | SUM x^2 | element count].  Forward: hdy_bn_slab_sums over the conv's statistic slabs -> all-reduce(sums) by the caller ->
  * hdy_bn_finalize_sums (same outputs and running-statistic update as hdy_bn_finalize[_pair]; sums may point at a channel slice of a

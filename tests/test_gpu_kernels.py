@@ -637,3 +637,33 @@ def test_fused_sgd_matches_torch_sgd_step_by_step():
         bad = torch.nn.Parameter(torch.zeros(4))
         bad.grad = torch.zeros(4)
         SGD([bad], lr=0.1).step()
+
+
+def test_stem_weight_gradient_with_fused_batchnorm_backward_is_bit_identical():
+    """hdy_conv_wgrad_stem_fused (dy computed from dz, y and the BatchNorm coefficients while the tile is staged) against the two-launch
+    path it replaces: hdy_bn_act_bwd writing dy, then hdy_conv_wgrad(stem) reading it — the same arithmetic and the same bf16 rounding
+    point, so the weight gradient must be identical."""
+    N, H, W, K = 3, 64, 128, 32
+    dt = torch.bfloat16
+    img = rnd((N, 3, H, W), 1).to(DEV)
+    prep = torch.zeros((N, H + 4, W + 4, 4), dtype=dt, device=DEV)
+    ops.run([ops.rec_stem_prep(img, prep)])
+    Ho, Wo = H // 2, W // 2
+    y = rnd((N, Ho, Wo, K), 2).to(dt).to(DEV)
+    dz = rnd((N, Ho, Wo, K), 3).to(dt).to(DEV)
+    scale, shift = (rnd((K,), 4).abs() + 0.5).to(DEV), rnd((K,), 5).to(DEV)
+    mean, invstd = rnd((K,), 6, 0.1).to(DEV), (rnd((K,), 7).abs() + 0.5).to(DEV)
+    M = N * Ho * Wo
+    ws_bn = torch.empty(ops.bn_bwd_ws_floats(M, K), dtype=torch.float32, device=DEV)
+    dy = torch.empty_like(y)
+    dg, db = torch.zeros(K, device=DEV), torch.zeros(K, device=DEV)
+    ops.run([ops.rec_bn_act_bwd(dz, y, scale, shift, mean, invstd, dy, dg, db, ws_bn)])
+    c1, c2 = ops.bn_bwd_coeffs(ws_bn, M, K)
+    ws = torch.empty(ops.wgrad_ws_bytes(N, H, W, 3, K, 6, 6, 2, 2, dt, stem=True) // 4 + 16, dtype=torch.float32, device=DEV)
+    g_ref = torch.zeros((K, 3, 6, 6), dtype=torch.float32, device=DEV)
+    ops.run([ops.rec_conv_wgrad(prep, dy, g_ref, None, 6, 6, 2, 2, ws, stem_hw=(H, W))])
+    assert ops.wgrad_stem_fused_ok(N, H, W, K, dt)
+    g_fused = torch.full((K, 3, 6, 6), 7.0, dtype=torch.float32, device=DEV)
+    ops.run([ops.rec_conv_wgrad_stem_fused(prep, dz, y, scale, shift, mean, invstd, c1, c2, (H, W), g_fused, None, ws)])
+    assert torch.equal(g_fused, g_ref) and g_ref.abs().max().item() > 0
+    assert not ops.wgrad_stem_fused_ok(N, H, W, 48, dt) and not ops.wgrad_stem_fused_ok(N, 60, 60, K, dt)
