@@ -20,6 +20,11 @@ def describe(rec):
         N, H, W, C, K, R, S_, st, pad = a[4:13]
         Ho, Wo = ops.out_dim(H, R, st, pad), ops.out_dim(W, S_, st, pad)
         return f'wgrd {C:4d}x{K:4d} k{R} s{st} @{H}x{W}', 2.0 * N * Ho * Wo * K * C * R * S_, 2.0 * (N * H * W * C + N * Ho * Wo * K)
+    if name == 'hdy_conv_wgrad_stem_fused':
+        N, H, W, K = a[11:15]
+        Ho, Wo = ops.out_dim(H, 6, 2, 2), ops.out_dim(W, 6, 2, 2)
+        # reads the padded image and BOTH dz and y of the unit (the BatchNorm backward is applied on the way in)
+        return f'wgrd    3x{K:4d} k6 s2 @{H}x{W} +bn', 2.0 * N * Ho * Wo * K * 3 * 36, 2.0 * (N * H * W * 3 + 2 * N * Ho * Wo * K)
     if name == 'hdy_bn_act_fwd':
         M, K = a[8], a[9]
         return f'bnfw K={K} M={M}', 0.0, 2.0 * M * K * (3 if a[4] else 2)
