@@ -44,6 +44,7 @@ struct ConvArgs {
     // derived by hdy_conv_igemm_launch for the loader: union tap window over the classes (origin uh0 / uw0, UH x UW taps <= 31),
     // utap = every 128-byte k-block lies inside one tap (C % BKE == 0), reciprocals (hdy_magic) of Ho*Wo, Wo, C and the tap-window width
     int uh0, uw0, UH, UW, utap;
+    int tile_interleave;  // 1: tiles that share A rows (column tiles of one m-tile, parity classes) go to neighbouring workgroups instead of one
     unsigned mg_howo, mg_wo, mg_c, mg_tw[4];
     int sh_howo, sh_wo, sh_c, sh_tw[4];
 };
