@@ -37,7 +37,7 @@ constexpr int PB = 64;   // pixels per LDS stage
 // Output tile of a workgroup = (SD x TK dy-channels) x (SX x TK tap-channels); SD, SX in {1, 2}.  Each operand tile is SD
 // (SX) sub-tiles of [64 pixels][128 B]; with SD = SX = 2 every staged byte feeds twice as many MFMAs and each dy / x element
 // is fetched by half as many workgroups as with 64x64 tiles (the wgrad of the 128+-channel layers was L2-fetch bound).
-template <typename T, int SD, int SX>
+template <typename T, int SD, int SX, bool XCD_WGRAD = true>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     constexpr int VE = WT<T>::VE, TK = WT<T>::TK, WTL = WT<T>::WTL;
     constexpr int MTW = WTL * SD, NTW = WTL * SX;            // 16x16 MFMA tiles per wave along k / q
@@ -48,8 +48,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles = p.ktiles * p.qtiles;
-    const int split = blockIdx.x / tiles;
-    const int tile = blockIdx.x - split * tiles;
+    // the tiles of one pixel split read the same dy / x rows: consecutive LOGICAL ids, i.e. one XCD and its L2 (blockIdx.x itself goes round
+    // the eight XCDs, so every XCD used to fetch every split's operands for itself)
+    const int bid = XCD_WGRAD ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int split = bid / tiles;
+    const int tile = bid - split * tiles;
     const int kt = tile / p.qtiles, qt = tile - kt * p.qtiles;
     const int k0 = kt * TK * SD, q0 = qt * TK * SX;
     const int pbeg = split * p.pix_per_split;

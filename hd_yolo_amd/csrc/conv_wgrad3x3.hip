@@ -62,7 +62,8 @@ __global__ __launch_bounds__(768) void wgrad3x3_kernel(const W3Args p) {
     const int tr = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
     const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3;
     const int blocks = p.nkb * p.ncb;
-    const int split = blockIdx.x / blocks, blk = blockIdx.x - split * blocks;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);      // the (K, C) blocks of one spatial split share its dy tile and x patch: one XCD's L2
+    const int split = bid / blocks, blk = bid - split * blocks;
     const int kb = blk / p.ncb, cb = blk - kb * p.ncb;
     const int TP = p.TOH * p.TOW, PW = p.S * p.TOW + 3 - p.S, PP = (p.S * p.TOH + 3 - p.S) * PW;      // patch = S*T + 2 (stride 1), 2*T + 1 (stride 2)
     const int steps = (TP + 31) / 32;
