@@ -115,7 +115,8 @@ __global__ __launch_bounds__(2 * BM, (BM == 256 || BN == 128 || STAT) ? 2 : (BN 
     // (PMC: 256->256 1x1 fetched its input twice).  Interleaved (workgroup w takes tiles w, w + grid, ...) those tiles run at the same time
     // on neighbouring workgroups of one XCD and share its L2: yolov5l inference network 59.1 -> 56.5 ms, yolov5s train step 13.46 -> 13.35 ms.
     // The four parity classes of the stride-2 dgrad stay with one workgroup (bit 1 of the switch): interleaved their half-line writes no longer
-    // leave one CU back to back and the step lost 0.1 ms.
+    // leave one CU back to back and the step lost 0.1 ms (also when limited to the layers whose pixel rows are whole cache lines).  Interleaving
+    // the single-column-tile layers too changes nothing (12.95 / 12.97 vs 12.98 / 13.03 ms).
     const bool interleave = (walk && (p.tile_interleave & 2) && p.K * (int)sizeof(OT) >= 128) || (!walk && ntiles > 1 && (p.tile_interleave & 1));
     const int wg_id = xcd_remap(blockIdx.x, gridDim.x);
     const int tile_step = interleave ? (int)gridDim.x : 1;
