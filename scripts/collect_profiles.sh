@@ -15,6 +15,7 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/lds -o lds --output-format csv -- python3 scripts/roofline_kernel.py > $OUT/lds.log 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT/infer -o infer --output-format csv -- python3 scripts/bench_infer.py l 128 1024 3 > $OUT/infer.log 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT/hnet -o hnet --output-format csv -- python3 scripts/bench_hnet.py s 16 1280 4 > $OUT/hnet.log 2>&1
+bash scripts/step_profile.sh $R > /dev/null 2>&1 && cp gpurun_out/step_$R/kernel_stats.txt $OUT/step_kernel_stats.txt
 python3 scripts/layer_bench.py > $OUT/layer_table.txt 2>&1
 for v in "m 32 640" "l 16 640" "m6 16 1280"; do set -- $v; python3 bench.py --variant $1 --batch $2 --size $3 --steps 10 --warmup 3 --no-cpu-baseline --no-infer --no-roofline 2>/dev/null | tail -1 | cut -c1-420 >> $OUT/variants.log; done
 python3 scripts/bench_mask.py s 16 1280 4 2>/dev/null | tail -1 >> $OUT/variants.log
