@@ -65,6 +65,9 @@ CONV_CASES = [
     (3, 64, 96, 64, 128, 3, 2, 1),       # class walk over many tiles: workgroup ranges start mid-group
     (2, 48, 48, 128, 256, 3, 2, 1),      # two column tiles per class
     (3, 40, 40, 256, 512, 1, 1, 0),
+    (2, 20, 20, 128, 128, 3, 1, 1),      # wide 3x3 / stride 1: one column tile
+    (3, 40, 40, 128, 256, 3, 1, 1),      # ... two column tiles (interleaved tile order), tiles that straddle images
+    (1, 24, 56, 192, 128, 3, 1, 1),      # ... three channel blocks
     (2, 16, 32, 64, 64, 3, 1, 1),        # qualifies for the filter-resident 3x3 kernel (bf16): C=64, H%8==0, W%16==0
     (3, 32, 48, 64, 32, 3, 1, 1),
     (2, 24, 32, 64, 64, 3, 1, 1),        # H % 16 != 0
@@ -667,3 +670,4 @@ def test_stem_weight_gradient_with_fused_batchnorm_backward_is_bit_identical():
     ops.run([ops.rec_conv_wgrad_stem_fused(prep, dz, y, scale, shift, mean, invstd, c1, c2, (H, W), g_fused, None, ws)])
     assert torch.equal(g_fused, g_ref) and g_ref.abs().max().item() > 0
     assert not ops.wgrad_stem_fused_ok(N, H, W, 48, dt) and not ops.wgrad_stem_fused_ok(N, 60, 60, K, dt)
+
