@@ -39,8 +39,6 @@
 #include "common.h"
 #include "hdyolo_internal.h"
 
-__device__ uint4 g_hdy_zero16[4];   // zero page for padded / out-of-range 16-byte fetches
-
 namespace {
 
 template <typename T> struct Traits;
@@ -60,11 +58,6 @@ template <> __device__ __forceinline__ f32x4 mma16<float>(const V16& a, const V1
 }
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
-
-__device__ __forceinline__ void glds16(const void* g, unsigned char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g,
-                                     (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
-}
 
 // LDS-DMA through a buffer descriptor: lane l's 16 bytes at base + voff + soff land at lds + l*16; a lane whose offset fails the
 // descriptor's range check (>= num_records) gets zeros.
