@@ -30,6 +30,7 @@ SIGNATURES = {
     'hdy_sgd_blocks': (_I, [_L]),
     'hdy_sgd_step': (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _I, _P]),
     'hdy_version': (_I, []),
+    'hdy_fastdiv_magic': (_I, [ctypes.c_uint, _P, _P]),
     'hdy_conv_out_dim': (_I, [_I, _I, _I, _I]),
     'hdy_conv_mtiles': (_I, [_L]),
     'hdy_conv_stat_slabs': (_I, [_I] * 10),

@@ -58,6 +58,13 @@ const char* hdy_last_error(void) { return g_err; }
 
 int hdy_version(void) { return 1; }
 
+// the reciprocal the conv loader divides by (host-only; exported so that the identity can be tested without a GPU)
+int hdy_fastdiv_magic(unsigned d, unsigned* magic, int* shift) {
+    HDY_ARG(d > 0 && magic && shift, "fastdiv_magic: d must be positive");
+    hdy_magic(d, magic, shift);
+    return HDY_OK;
+}
+
 int hdy_conv_out_dim(int in, int k, int stride, int pad) { return (in + 2 * pad - k) / stride + 1; }
 
 int hdy_conv_mtiles(long long M) { return (int)((M + 127) / 128); }

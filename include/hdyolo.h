@@ -42,6 +42,8 @@ extern "C" {
 
 const char* hdy_last_error(void);
 int hdy_version(void);
+/* host-only: the reciprocal conv_igemm.hip divides row indices by (n / d == mulhi(2n, *magic) >> *shift for n < 2^31) */
+int hdy_fastdiv_magic(unsigned d, unsigned* magic, int* shift);
 
 /* ---- convolution family --------------------------------------------------------------------------------------
  * Replaces nn.Conv2d forward/backward as used by metayolo/models/layers.py:31,37-41 (Conv), :92-97 (Bottleneck),

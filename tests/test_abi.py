@@ -55,3 +55,23 @@ def test_invalid_arguments_return_status_not_crash(lib):
     assert rc < 0 and b'null' in lib.hdy_last_error()
     rc = lib.hdy_nms_batched(None, 1, 4, 7, 1, 0.1, 2.0, 10, 2.0, 0, None, None, None, None, None, None, None, None, 0, None)
     assert rc < 0
+
+
+def test_fastdiv_reciprocal_is_exact(lib):
+    """conv_igemm.hip recovers (image, row, column) from a flattened output index with n / d == mulhi(2n, magic) >> shift; the identity
+    must hold for every n < 2^31 the kernels can see: checked at the multiples of d and their neighbours, the top of the range and at
+    random points, for the divisors that occur (image sides, pixel counts, channel counts, tap-window widths)."""
+    import ctypes
+    import random
+    rng = random.Random(0)
+    ds = list(range(1, 70)) + [80, 96, 128, 160, 192, 320, 640, 1024, 1280, 20 * 20, 40 * 40, 80 * 80, 160 * 160, 320 * 320, 512 * 512, 1024 * 1024,
+                                1023, 1025, 65535, 65537, 999983] + [rng.randrange(2, 1 << 22) for _ in range(200)]
+    for d in ds:
+        mg, sh = ctypes.c_uint(), ctypes.c_int()
+        assert lib.hdy_fastdiv_magic(d, ctypes.byref(mg), ctypes.byref(sh)) == 0
+        pts = [0, 1, d - 1, d, d + 1, 2 * d - 1, 2 * d, (1 << 31) - 1, ((1 << 31) - 1) // d * d, ((1 << 31) - 1) // d * d - 1]
+        pts += [rng.randrange(0, 1 << 31) for _ in range(50)] + [k * d + e for k in (3, 1000, (1 << 31) // d - 2) for e in (-1, 0, 1)]
+        for n in pts:
+            if 0 <= n < (1 << 31):
+                assert ((2 * n * mg.value) >> 32) >> sh.value == n // d, (n, d)
+    assert lib.hdy_fastdiv_magic(0, ctypes.byref(mg), ctypes.byref(sh)) < 0
