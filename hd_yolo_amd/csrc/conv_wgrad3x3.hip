@@ -235,6 +235,9 @@ bool w3_plan(int N, int Ho, int Wo, int C, int K, int stride, W3Plan* pl) {
     if (off || C % 32 || K % 32 || (stride != 1 && !(stride == 2 && s2))) return false;
     pl->KB = K % 64 == 0 ? 64 : 32;
     pl->CB = C % 64 == 0 ? 64 : 32;
+    // several 32-wide blocks per split (yolov5m's 96 x 96 = 3 x 3 of them) do too little MFMA work per staged tile: 83 us against 70 us on the
+    // generic kernel at 96x96 @80x80, B=32; a single 32 x 32 block (yolov5s' 32->32 @160x160) is 84 against 168 us
+    if ((pl->KB == 32 || pl->CB == 32) && (K / pl->KB) * (C / pl->CB) > 1) return false;
     if (stride == 1) {
         if (Wo <= 40) { pl->TOW = Wo; pl->TOH = W3_MAXTP / Wo; }
         else if (Wo % 16 == 0) { pl->TOW = 16; pl->TOH = 16; }
