@@ -159,8 +159,8 @@ def cpu_baseline(variant, nc, size, tiles=8, iters=16):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=40)
-    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=60)
+    ap.add_argument('--warmup', type=int, default=15)
     ap.add_argument('--batch', type=int, default=64, help='tiles per GPU')
     ap.add_argument('--size', type=int, default=640)
     ap.add_argument('--variant', default='s')

@@ -23,9 +23,11 @@ for t in targets:
 acc = [0.0] * 4
 N = 60
 per = []
+evs = []
 for it in range(N + 5):
     if it == 5:
         torch.cuda.synchronize(); acc = [0.0] * 4; T0 = time.perf_counter()
+    ev = torch.cuda.Event(enable_timing=True); ev.record(); evs.append(ev)
     t0 = time.perf_counter()
     losses, _ = m(x, targets, compute_masks=False)
     t1 = time.perf_counter()
@@ -43,4 +45,5 @@ torch.cuda.synchronize()
 t_all = time.perf_counter() - T0
 print('host ms per step (forward+loss, backward, opt.step, zero_grad):', [round(a / N * 1e3, 3) for a in acc])
 print('host ms of each step:', per[5:])
+print('GPU ms between step starts after the sync:', [round(a.elapsed_time(b), 2) for a, b in zip(evs[5:35], evs[6:36])])
 print('host loop %.3f ms/step, with final sync %.3f ms/step' % (t_host / N * 1e3, t_all / N * 1e3))
