@@ -667,6 +667,10 @@ def main():
     if sys.argv[1:] == ['seg']:
         gen_seg()
         return
+    if sys.argv[1:] == ['m']:                  # BASELINE config C3's variant: channel widths 48 / 96 / 192 / 384 / 768, C3 depth 2 / 4 / 6 / 2
+        gen_train('m_128', 'm', 8, 2, 128, 10, 30)
+        gen_eval_compact('m_128', 'm', 8, 2, 128)
+        return
     if sys.argv[1:] == ['p6']:                 # only the P6 fixtures (the others are unchanged by construction)
         gen_stages('n6_128', 'n6', 3, 2, 128, full=False)
         gen_train('n6_128', 'n6', 3, 2, 128, 4, 12)
@@ -691,6 +695,8 @@ def main():
     gen_train('c1_640', 'n', 2, 4, 640, 50, 400)
     gen_eval_compact('c1_640', 'n', 2, 4, 640)
     gen_eval_compact('s_640', 's', 8, 2, 640)
+    gen_train('m_128', 'm', 8, 2, 128, 10, 30)
+    gen_eval_compact('m_128', 'm', 8, 2, 128)
 
 
 if __name__ == '__main__':

@@ -79,10 +79,11 @@ def test_eval_matches_reference_golden_fp32(golden_dir, tag, variant):
     assert total > 0
 
 
-@pytest.mark.parametrize('tag,variant', [('c1_640', 'n'), ('s_640', 's')])
+@pytest.mark.parametrize('tag,variant', [('c1_640', 'n'), ('s_640', 's'), ('m_128', 'm')])
 def test_full_size_eval_matches_reference_golden_fp32(golden_dir, tag, variant):
-    """BASELINE config C1 exactly (yolov5n, 2 classes, batch 4, 640x640) and yolov5s at 640x640: detection logits (checksums + a strip)
-    and the final per-image detections — 300 kept boxes each, in the reference's NMS order — against the reference's own run."""
+    """BASELINE config C1 exactly (yolov5n, 2 classes, batch 4, 640x640), yolov5s at 640x640 and yolov5m (config C3's widths: 48 / 96 /
+    192 / 384 / 768 channels) at 128x128: detection logits (checksums + a strip) and the final per-image detections — 300 kept boxes each
+    at 640x640, in the reference's NMS order — against the reference's own run."""
     g = np.load(os.path.join(golden_dir, f'eval_{tag}.npz'))
     batch, size, nc = (int(v) for v in g['meta'])
     model = build(variant, nc, synth.make_hyp(conf_thres=float(g['conf_thres']))).eval()
@@ -99,15 +100,16 @@ def test_full_size_eval_matches_reference_golden_fp32(golden_dir, tag, variant):
     for b in range(batch):
         o = outputs[b]['det']
         rb, rs, rl = g[f'out_{b}_boxes'], g[f'out_{b}_scores'], g[f'out_{b}_labels']
-        assert o['boxes'].shape == rb.shape and len(rb) == 300
+        n = len(rb)
+        assert o['boxes'].shape == rb.shape and n == (300 if size == 640 else n) and n >= 40
         # 25 200 candidates per tile computed on different hardware: a pair of scores closer than the 1e-6 agreement of the logits may
         # swap places, an IoU within 1e-6 of the threshold may flip one decision.  Kept-order exactness is what the oracle tests pin (same
         # inputs bit for bit); here: the same boxes up to two per image, and identical rows wherever the order did not move
         gb = o['boxes'].cpu().numpy()
         d = np.abs(gb[:, None, :] - rb[None, :, :]).max(-1)
-        assert (d.min(1) < 2e-3).sum() >= 298 and (d.min(0) < 2e-3).sum() >= 298, ((d.min(1) < 2e-3).sum(), (d.min(0) < 2e-3).sum())
+        assert (d.min(1) < 2e-3).sum() >= n - 2 and (d.min(0) < 2e-3).sum() >= n - 2, ((d.min(1) < 2e-3).sum(), (d.min(0) < 2e-3).sum())
         same = np.abs(gb - rb).max(-1) < 2e-3
-        assert same.sum() >= 290
+        assert same.sum() >= n - 10
         np.testing.assert_allclose(o['scores'].cpu().numpy()[same], rs[same], rtol=1e-4, atol=1e-6)
         assert np.array_equal(o['labels'].cpu().numpy()[same], rl[same])
 
@@ -183,7 +185,7 @@ def test_fuse_keeps_eval_outputs(golden_dir):
 
 
 @pytest.mark.parametrize('fused', ['1', '0'])
-@pytest.mark.parametrize('tag,variant', [('n_64', 'n'), ('s_128', 's'), ('n6_128', 'n6'), ('n_64_ragged', 'n'), ('c1_640', 'n')])
+@pytest.mark.parametrize('tag,variant', [('n_64', 'n'), ('s_128', 's'), ('n6_128', 'n6'), ('n_64_ragged', 'n'), ('c1_640', 'n'), ('m_128', 'm')])
 def test_train_step_matches_reference_golden_fp32(golden_dir, tag, variant, fused, monkeypatch):
     """fused = '1': target assignment + loss + logits gradient by csrc/loss.hip; '0': the tensor-expression DetLoss."""
     monkeypatch.setenv('HDY_FUSED_LOSS', fused)
@@ -462,7 +464,8 @@ def test_non_square_tiles_match_oracle():
         assert relmax(params[k].grad, sd[k].grad) < 2e-3, k
 
 
-def test_bf16_plan_layer_by_layer_against_fp32_torch():
+@pytest.mark.parametrize('variant', ['s', 'm'])
+def test_bf16_plan_layer_by_layer_against_fp32_torch(variant):
     """The bf16 training plan (every conv / BatchNorm / SiLU / residual / fused-backward launch, all pitches and channel slices) checked
     LOCALLY: each unit's outputs are recomputed in fp32 torch from that unit's OWN bf16 inputs as the plan left them in its buffers —
     forward (raw conv output, BatchNorm coefficients, activation) and backward (weight gradient, BatchNorm parameter gradients, and the
@@ -472,7 +475,7 @@ def test_bf16_plan_layer_by_layer_against_fp32_torch():
     import torch.nn.functional as F
     from hd_yolo_amd import plan as planmod
     nc, B, S = 8, 4, 128
-    model = build('s', nc).train()
+    model = build(variant, nc).train()          # 'm': BASELINE config C3's widths (48 / 96 / 192 / 384 / 768 channels, 16-byte rows that are not 128-byte multiples)
     model.half()
     x = synth.synth_images(B, S, seed=11).to(DEV)
     losses, _ = model(x, synth.synth_targets(B, S, nc, nmin=10, nmax=30, seed=5))
@@ -482,8 +485,9 @@ def test_bf16_plan_layer_by_layer_against_fp32_torch():
     plan = next(iter(eng.plans.values()))
     assert plan.dtype == torch.bfloat16
     units = [u for u in plan.units if isinstance(u, planmod.ConvUnit)]
-    assert sum(plan._fusable_1x1(u) for u in units) >= 8, 'the fused 1x1 backward must be part of what is checked'
-    if os.environ.get('HDY_EXPECT_PRODUCER_STATS'):
+    if variant == 's':
+        assert sum(plan._fusable_1x1(u) for u in units) >= 8, 'the fused 1x1 backward must be part of what is checked'
+    if os.environ.get('HDY_EXPECT_PRODUCER_STATS') and variant == 's':
         assert plan.producer_stat_units >= 10, plan.producer_stat_units
 
     def consumers(v):

@@ -121,7 +121,7 @@ def ragged(targets, tag):
     return targets
 
 
-@pytest.mark.parametrize('tag,v', [('n_64', 'n'), ('s_128', 's'), ('n6_128', 'n6'), ('n_64_ragged', 'n'), ('c1_640', 'n')])
+@pytest.mark.parametrize('tag,v', [('n_64', 'n'), ('s_128', 's'), ('n6_128', 'n6'), ('n_64_ragged', 'n'), ('c1_640', 'n'), ('m_128', 'm')])
 def test_train_loss_and_grads(golden_dir, tag, v):
     g = load(golden_dir, f'train_{tag}.npz')
     batch, size, nc, nmin, nmax = (int(t) for t in g['meta'])
