@@ -10,23 +10,28 @@
 //                  centre cell and up to two neighbour cells (the 0.5-offset rule), then for each match
 //                    - CIoU(pred box, target box) in forward-mode dual numbers -> d(1-CIoU)/d(4 box logits)
 //                    - class BCE (pos_weight, class weights, label smoothing) and its gradient
-//                    - atomic accumulation of the (unscaled) gradients into an fp32 scratch image,
-//                    - the objectness target: atomicMax of (candidate order << 32 | iou bits), so that among
-//                      candidates that hit the same cell the LAST one in the reference's enumeration order wins,
-//                      which is what the reference's sequential CPU scatter does (deterministic, unlike index_put on a GPU)
-//                    - per-level sums / counts (fp64 atomics)
-//   dense_kernel   one lane per cell x anchor: objectness BCE against the scattered target (+ its gradient), scales the
-//                  accumulated box / class gradients by gain/count, writes the logits gradient straight into the NHWC
-//                  buffer the backward plan consumes (bf16 or fp32, zero padded channels)
+//                    - one RECORD per match (4 box gradients, iou, candidate order, class gradients), appended to a dense array and
+//                      chained to its (cell, anchor) with one atomicExch on that cell's list head.  (First version: 12 fp32
+//                      atomicAdds into an image-sized scratch + a 64-bit atomicMax per match — 2.3 M device-scope atomics per step were
+//                      100 of the kernel's 166 us — and the scratch image had to be zeroed and re-read in full.)
+//                    - per-level sums / counts (fp64 atomics, one per workgroup)
+//   dense_kernel   one lane per (cell, 4 channels): walks the cell's record lists (mostly empty), sums the box / class gradients,
+//                  takes the objectness target from the record with the HIGHEST candidate order — among candidates that hit the same
+//                  cell the LAST one in the reference's enumeration order wins, which is what the reference's sequential CPU scatter
+//                  does (deterministic, unlike index_put on a GPU) — objectness BCE (+ its gradient), scales by gain/count, writes the
+//                  logits gradient straight into the NHWC buffer the backward plan consumes (bf16 or fp32, zero padded channels)
 //   final_kernel   loss = (box*sum_l mean_l + obj*sum_l balance_l*mean_l + cls*sum_l mean_l) * batch, and the three items
 //
-// Gradient accumulation uses fp32 atomics (a few thousand adds spread over the image): run-to-run differences are
-// in the last bits only; every mean is taken over fp64 sums.
+// Records of one cell are summed in list order, which depends on the order the matches arrived in: run-to-run differences are in the
+// last bits only (and only where three or more matches share a cell and anchor); every mean is taken over fp64 sums.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
 
 constexpr int MAXL = 5, MAXA = 8, MAXC = 128;
+constexpr int OSL = 64;      // objectness-sum slots per level: a workgroup adds to slot (its index % OSL); atomics on one address serialise
 
 template <typename T> struct Quad;                        // 4 consecutive channels in memory
 template <> struct Quad<float> { typedef f32x4 type; };
@@ -54,8 +59,10 @@ __device__ __forceinline__ D4 datan(const D4& a) { D4 r; r.v = atanf(a.v); const
 struct LossArgs {
     const float* logits[MAXL];   // [B][ny][nx][ldl], channel = a*no + o
     void* gdet[MAXL];            // [B][ny][nx][ldg]
-    float* scratch[MAXL];        // [B][ny][nx][ldl] fp32 gradient accumulators (zeroed here)
-    unsigned long long* tobj[MAXL];   // [B][na][ny][nx] packed (order+1)<<32 | iou bits (zeroed here)
+    int* head[MAXL];             // [B][ny][nx][na] list heads: record index + 1, 0 = empty (zeroed here)
+    float* recs;                 // [capacity][rs] match records: 0-3 box gradients, 4 iou, 5 candidate order, 6 next (index + 1), 8.. class gradients
+    int* nrec;                   // records in use (zeroed here)
+    int rs, capacity;
     int ny[MAXL], nx[MAXL];
     float anc[MAXL][MAXA][2];    // anchors in grid units
     float balance[MAXL];
@@ -65,7 +72,7 @@ struct LossArgs {
     float cw[MAXC];
     float cls_pw, obj_pw, anchor_t, smooth;
     float h_box, h_obj, h_cls;
-    double* acc;                 // [nl][6]: sum(1-ciou), n, sum cls bce, n_cls rows, sum obj bce, unused
+    double* acc;                 // [MAXL][6]: sum(1-ciou), n, sum cls bce, n_cls rows, unused x2; then [MAXL][OSL] partial sums of the obj bce
     float* out;                  // loss, lbox, lobj, lcls
 };
 
@@ -84,34 +91,86 @@ __global__ __launch_bounds__(256) void zero_kernel(uint4* p, size_t n16) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p[i] = uint4{0, 0, 0, 0};
 }
 
-__global__ __launch_bounds__(256) void match_kernel(const LossArgs p, int l) {
+// grid.y = pyramid level: the levels are independent and each is a chain of dependent global accesses per lane (target row -> logits ->
+// atomics), so they run side by side in one launch (three launches back to back: 178 us per yolov5s step)
+__global__ __launch_bounds__(256) void match_kernel(const LossArgs p) {
+    const int l = blockIdx.y;
     const int na = p.na, nt = p.nt, nc = p.nc, no = p.no;
     const int total = 5 * na * nt;
     const int ny = p.ny[l], nx = p.nx[l];
     double s_box = 0.0, s_cls = 0.0;
     int n_box = 0, n_cls = 0;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    // Only ~30 % of the (offset, anchor, target) candidates pass the anchor-ratio and the half-cell tests, in no pattern: evaluated in
+    // place, every wave ran the whole CIoU / BCE body for its few live lanes.  So a workgroup first runs the cheap tests for 1024
+    // candidates, packs the survivors into an LDS list, and then works through the list with full waves.
+    constexpr int CPT = 4;                                  // candidates per thread and trip
+    __shared__ int list[256 * CPT];
+    __shared__ int wcount[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    auto cell_of = [&](int idx, int& gi, int& gj, int& a, int& g) -> bool {
         const int j = idx / (na * nt);
         const int rem = idx - j * (na * nt);
-        const int a = rem / nt, g = rem - a * nt;
+        a = rem / nt;
+        g = rem - a * nt;
         const float* gt = p.gts + (size_t)g * 5;
         const float gx = gt[1] * nx, gy = gt[2] * ny, gw = gt[3] * nx, gh = gt[4] * ny;
         const float aw = p.anc[l][a][0], ah = p.anc[l][a][1];
         const float rw = gw / aw, rh = gh / ah;
         const float worst = fmaxf(fmaxf(rw, 1.f / rw), fmaxf(rh, 1.f / rh));
-        if (!(worst < p.anchor_t)) continue;
+        if (!(worst < p.anchor_t)) return false;
         float ox = 0.f, oy = 0.f;
-        if (j == 1) { if (!(fmodf(gx, 1.f) < 0.5f && gx > 1.f)) continue; ox = 0.5f; }
-        else if (j == 2) { if (!(fmodf(gy, 1.f) < 0.5f && gy > 1.f)) continue; oy = 0.5f; }
-        else if (j == 3) { const float ix = nx - gx; if (!(fmodf(ix, 1.f) < 0.5f && ix > 1.f)) continue; ox = -0.5f; }
-        else if (j == 4) { const float iy = ny - gy; if (!(fmodf(iy, 1.f) < 0.5f && iy > 1.f)) continue; oy = -0.5f; }
-        int gi = (int)(gx - ox), gj = (int)(gy - oy);            // truncation toward zero, as .long()
+        if (j == 1) { if (!(fmodf(gx, 1.f) < 0.5f && gx > 1.f)) return false; ox = 0.5f; }
+        else if (j == 2) { if (!(fmodf(gy, 1.f) < 0.5f && gy > 1.f)) return false; oy = 0.5f; }
+        else if (j == 3) { const float ix = nx - gx; if (!(fmodf(ix, 1.f) < 0.5f && ix > 1.f)) return false; ox = -0.5f; }
+        else if (j == 4) { const float iy = ny - gy; if (!(fmodf(iy, 1.f) < 0.5f && iy > 1.f)) return false; oy = -0.5f; }
+        gi = (int)(gx - ox);                                     // truncation toward zero, as .long()
+        gj = (int)(gy - oy);
         gi = min(max(gi, 0), nx - 1);
         gj = min(max(gj, 0), ny - 1);
+        return true;
+    };
+    for (int base = blockIdx.x * 256 * CPT; base < total; base += gridDim.x * 256 * CPT) {
+        bool ok[CPT];
+        int nmine = 0;
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int idx = base + k * 256 + threadIdx.x;
+            int gi, gj, a, g;
+            ok[k] = idx < total && cell_of(idx, gi, gj, a, g);
+            nmine += ok[k];
+        }
+        // exclusive prefix of nmine over the workgroup: lanes below in the wave, then the waves below
+        int below = 0;
+#pragma unroll
+        for (int k = 1; k <= CPT; ++k) below += k * __popcll(__ballot(nmine == k) & ((1ull << lane) - 1ull));
+        int wtot = 0;
+#pragma unroll
+        for (int k = 1; k <= CPT; ++k) wtot += k * __popcll(__ballot(nmine == k));
+        if (lane == 0) wcount[wave] = wtot;
+        __syncthreads();
+        int nlist = 0;
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) below += wcount[w];
+            nlist += wcount[w];
+        }
+#pragma unroll
+        for (int k = 0; k < CPT; ++k)
+            if (ok[k]) list[below++] = base + k * 256 + threadIdx.x;
+        __syncthreads();
+        if (threadIdx.x == 0) wcount[0] = nlist ? atomicAdd(p.nrec, nlist) : 0;      // this trip's records: [first, first + nlist)
+        __syncthreads();
+        const int first = wcount[0];
+        for (int t = threadIdx.x; t < nlist && first + t < p.capacity; t += 256) {
+        const int idx = list[t];
+        int gi, gj, a, g;
+        cell_of(idx, gi, gj, a, g);
+        const float* gt = p.gts + (size_t)g * 5;
+        const float gx = gt[1] * nx, gy = gt[2] * ny, gw = gt[3] * nx, gh = gt[4] * ny;
+        const float aw = p.anc[l][a][0], ah = p.anc[l][a][1];
         const int b = (int)gt[0];
         const size_t pix = ((size_t)b * ny + gj) * nx + gi;
         const float* lg = p.logits[l] + pix * p.ldl + a * no;
-        float* gr = p.scratch[l] + pix * p.ldl + a * no;
+        float* rec = p.recs + (size_t)(first + t) * p.rs;
         // ---- box: CIoU between the decoded prediction and the target, both relative to the cell
         const float s0 = sigm(lg[0]), s1 = sigm(lg[1]), s2 = sigm(lg[2]), s3 = sigm(lg[3]);
         const D4 x1 = var(s0 * 2.f - 0.5f, 0), y1 = var(s1 * 2.f - 0.5f, 1);
@@ -137,28 +196,29 @@ __global__ __launch_bounds__(256) void match_kernel(const LossArgs p, int l) {
         ++n_box;
         // d(1 - ciou)/d logit = -dciou/dp * dp/dlogit
         const float dpl[4] = {2.f * s0 * (1.f - s0), 2.f * s1 * (1.f - s1), 8.f * s2 * aw * s2 * (1.f - s2), 8.f * s3 * ah * s3 * (1.f - s3)};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) atomicAdd(gr + i, -ciou.d[i] * dpl[i]);
-        // ---- objectness target: last candidate in reference order wins
-        const float t_iou = fmaxf(ciou.v, 0.f);
-        const unsigned long long packed = ((unsigned long long)(idx + 1) << 32) | __float_as_uint(t_iou);
-        atomicMax(p.tobj[l] + (((size_t)b * na + a) * ny + gj) * nx + gi, packed);
+        // ---- the record: box gradients, objectness target (iou) and the candidate order that decides between targets of one cell
+        *(f32x4*)rec = f32x4{-ciou.d[0] * dpl[0], -ciou.d[1] * dpl[1], -ciou.d[2] * dpl[2], -ciou.d[3] * dpl[3]};
+        const int prev = atomicExch(p.head[l] + pix * na + a, first + t + 1);
+        *(f32x4*)(rec + 4) = f32x4{fmaxf(ciou.v, 0.f), __int_as_float(idx), __int_as_float(prev), 0.f};
         // ---- classes
         if (nc > 1) {
             const float* tc = p.tcls + (size_t)g * nc;
             float any = 0.f;
             for (int c = 0; c < nc; ++c) any += tc[c];
-            if (any > 0.f) {
-                ++n_cls;
-                for (int c = 0; c < nc; ++c) {
-                    const float t = tc[c] - (tc[c] - 0.5f) * p.smooth;
-                    float gd;
-                    const float ls = bce(lg[5 + c], t, p.cls_pw, &gd);
+            if (any > 0.f) ++n_cls;
+            for (int c = 0; c < nc; ++c) {
+                float gd = 0.f;
+                if (any > 0.f) {
+                    const float tt = tc[c] - (tc[c] - 0.5f) * p.smooth;
+                    const float ls = bce(lg[5 + c], tt, p.cls_pw, &gd);
                     s_cls += (double)(ls * p.cw[c]);
-                    atomicAdd(gr + 5 + c, gd * p.cw[c]);
+                    gd *= p.cw[c];
                 }
+                rec[8 + c] = gd;
             }
         }
+        }
+        __syncthreads();                                        // the list is rewritten by the next trip
     }
     // block reduction of the four statistics, one atomic each
     __shared__ double sh[4][256];
@@ -172,45 +232,75 @@ __global__ __launch_bounds__(256) void match_kernel(const LossArgs p, int l) {
     if (threadIdx.x < 4 && sh[threadIdx.x][0] != 0.0) atomicAdd(p.acc + l * 6 + threadIdx.x, sh[threadIdx.x][0]);
 }
 
-// One lane per (cell, 4-channel group): the accumulated gradients are read as 16-byte vectors and the logits gradient leaves as 8-
-// (bf16) or 16-byte (fp32) vectors, lanes of a wave covering consecutive addresses.  (One lane per cell walking its 40 channels with
-// scalar accesses 160 bytes apart took 87 us per level on average.)  Requires ldl % 4 == 0 and ldg % 4 == 0 (checked by the launcher).
+// One lane per (cell, 4-channel group); the logits gradient leaves as 8- (bf16) or 16-byte (fp32) vectors, lanes of a wave covering
+// consecutive addresses.  A group's four channels belong to one or two anchors; for each the lane walks that (cell, anchor)'s record
+// list — empty for ~96 % of them — adding the box / class gradients of its channels and, for an objectness channel, keeping the iou of
+// the record with the highest candidate order.  Requires ldl % 4 == 0 and ldg % 4 == 0 (checked by the launcher).
+// grid.y = pyramid level (one launch for all levels); index arithmetic in 32 bits (the launcher checks cells * groups < 2^31).
 template <typename T>
-__global__ __launch_bounds__(256) void dense_kernel(const LossArgs p, int l) {
+__global__ __launch_bounds__(256) void dense_kernel(const LossArgs p) {
+    const int l = blockIdx.y;
     const int na = p.na, no = p.no, ny = p.ny[l], nx = p.nx[l];
-    const long long cells = (long long)p.B * ny * nx;
+    const int cells = p.B * ny * nx;
     const double n_box = p.acc[l * 6 + 1], n_cls = p.acc[l * 6 + 3];
     const float bs = (float)p.B;
     const float k_box = n_box > 0 ? bs * p.h_box / (float)n_box : 0.f;
-    const float k_cls = n_cls > 0 ? bs * p.h_cls / (float)(n_cls * p.nc) : 0.f;
-    const float k_obj = bs * p.h_obj * p.balance[l] / (float)(cells * na);
+    const float k_cls = (n_cls > 0 && p.nc > 1) ? bs * p.h_cls / (float)(n_cls * p.nc) : 0.f;
+    const float k_obj = bs * p.h_obj * p.balance[l] / (float)((long long)cells * na);
     T* gd = (T*)p.gdet[l];
-    const int groups = p.ldg / 4;                          // 4-channel groups per cell (padding channels included)
-    const long long items = cells * groups;
+    const unsigned groups = p.ldg / 4;                     // 4-channel groups per cell (padding channels included)
+    const unsigned items = (unsigned)cells * groups;
+    const float* __restrict__ logits = p.logits[l];
+    const int* __restrict__ head = p.head[l];
     double s_obj = 0.0;
-    for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long long)gridDim.x * blockDim.x) {
-        const long long pix = it / groups;
+    for (unsigned it = blockIdx.x * blockDim.x + threadIdx.x; it < items; it += gridDim.x * blockDim.x) {
+        const unsigned pix = it / groups;
         const int c0 = (int)(it - pix * groups) * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (c0 < p.ldl) {
-            const f32x4 gr = *(const f32x4*)(p.scratch[l] + pix * p.ldl + c0);
-            int a = c0 / no, o = c0 - a * no;
+        const int a0 = (unsigned)c0 / (unsigned)no, o0 = c0 - a0 * no;
+        if (a0 < na) {
+            // channel i of the group is output o0 + i of anchor a0, or output o0 + i - no of anchor a0 + 1 (no >= 6: at most two anchors,
+            // at most one objectness logit: channel i4 of anchor a4 — its BCE is evaluated once, after the walk)
+            const bool two = o0 + 3 >= no && a0 + 1 < na;
+            int i4 = 4 - o0;
+            if (i4 < 0) i4 += no;
+            const int a4 = a0 + (o0 + i4 >= no ? 1 : 0);
+            const bool has_obj = i4 < 4 && a4 < na;
+            float tgt = 0.f;
+            int best = -1;
+            int r0 = head[(size_t)pix * na + a0];
+            int r1 = two ? head[(size_t)pix * na + a0 + 1] : 0;
+            if (r0 | r1) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (a < na) {
-                    if (o == 4) {
-                        const int x = (int)(pix % nx);
-                        const long long t = pix / nx;
-                        const int y = (int)(t % ny), b = (int)(t / ny);
-                        const unsigned long long pk = p.tobj[l][(((size_t)b * na + a) * ny + y) * nx + x];
-                        const float tgt = pk ? __uint_as_float((unsigned)(pk & 0xFFFFFFFFull)) : 0.f;
-                        float go;
-                        s_obj += (double)bce(p.logits[l][pix * p.ldl + c0 + i], tgt, p.obj_pw, &go);
-                        v[i] = go * k_obj;
-                    } else {
-                        v[i] = gr[i] * (o < 4 ? k_box : k_cls);
+                for (int half = 0; half < 2; ++half) {
+                    const int ob = half ? o0 - no : o0;                    // output index of channel 0 relative to this anchor
+                    for (int r = half ? r1 : r0; r != 0;) {
+                        const float* rec = p.recs + (size_t)(r - 1) * p.rs;
+                        const f32x4 h1 = *(const f32x4*)(rec + 4);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int o = ob + i;
+                            if (o < 0 || o >= no) continue;
+                            if (o < 4) v[i] += rec[o];
+                            else if (o == 4) {
+                                const int order = __float_as_int(h1[1]);
+                                if (order > best) { best = order; tgt = h1[0]; }
+                            } else if (p.nc > 1) v[i] += rec[8 + o - 5];
+                        }
+                        r = __float_as_int(h1[2]);
                     }
                 }
+            }
+            float g_obj = 0.f;
+            if (has_obj) {
+                float go;
+                s_obj += (double)bce(logits[(size_t)pix * p.ldl + c0 + i4], tgt, p.obj_pw, &go);
+                g_obj = go * k_obj;
+            }
+            int a = a0, o = o0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i] = a < na ? (o == 4 ? g_obj : v[i] * (o < 4 ? k_box : k_cls)) : 0.f;
                 if (++o == no) {
                     o = 0;
                     ++a;
@@ -218,7 +308,7 @@ __global__ __launch_bounds__(256) void dense_kernel(const LossArgs p, int l) {
             }
         }
         typename Quad<T>::type out = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
-        *(typename Quad<T>::type*)(gd + pix * p.ldg + c0) = out;
+        *(typename Quad<T>::type*)(gd + (size_t)pix * p.ldg + c0) = out;
     }
     __shared__ double sh[256];
     sh[threadIdx.x] = s_obj;
@@ -227,7 +317,7 @@ __global__ __launch_bounds__(256) void dense_kernel(const LossArgs p, int l) {
         if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
         __syncthreads();
     }
-    if (threadIdx.x == 0) atomicAdd(p.acc + l * 6 + 4, sh[0]);
+    if (threadIdx.x == 0 && sh[0] != 0.0) atomicAdd(p.acc + MAXL * 6 + l * OSL + (blockIdx.x % OSL), sh[0]);
 }
 
 __global__ void final_kernel(const LossArgs p) {
@@ -236,7 +326,9 @@ __global__ void final_kernel(const LossArgs p) {
         const double* a = p.acc + l * 6;
         if (a[1] > 0) lbox += a[0] / a[1];
         if (a[3] > 0) lcls += a[2] / (a[3] * p.nc);
-        lobj += a[4] / ((double)p.B * p.na * p.ny[l] * p.nx[l]) * p.balance[l];
+        double so = 0.0;
+        for (int i = 0; i < OSL; ++i) so += p.acc[MAXL * 6 + l * OSL + i];
+        lobj += so / ((double)p.B * p.na * p.ny[l] * p.nx[l]) * p.balance[l];
     }
     lbox *= p.h_box; lobj *= p.h_obj; lcls *= p.h_cls;
     p.out[0] = (float)((lbox + lobj + lcls) * p.B);
@@ -258,13 +350,13 @@ inline size_t a16(size_t v) { return (v + 15) / 16 * 16; }
 
 extern "C" {
 
-size_t hdy_det_loss_workspace_bytes(int nl, const int* ny, const int* nx, int B, int na, int ldl) {
-    size_t n = a16((size_t)MAXL * 6 * sizeof(double));
-    for (int l = 0; l < nl; ++l) {
-        const size_t cells = (size_t)B * ny[l] * nx[l];
-        n += a16(cells * ldl * sizeof(float)) + a16(cells * na * sizeof(unsigned long long));
-    }
-    return n;
+static int det_loss_record_floats(int nc) { return (8 + nc + 3) / 4 * 4; }
+
+// nt = the largest number of targets (rows of gts) a call will be given with this workspace
+size_t hdy_det_loss_workspace_bytes(int nl, const int* ny, const int* nx, int B, int na, int nc, int nt) {
+    size_t n = a16((size_t)MAXL * (6 + OSL) * sizeof(double) + sizeof(int));
+    for (int l = 0; l < nl; ++l) n += a16((size_t)B * ny[l] * nx[l] * na * sizeof(int));
+    return n + a16((size_t)nl * 5 * na * (size_t)nt * det_loss_record_floats(nc) * sizeof(float));
 }
 
 int hdy_det_loss(const float* const* logits, int ldl, void* const* gdet, int ldg, int dtype, const int* ny, const int* nx, int nl, int B,
@@ -276,21 +368,22 @@ int hdy_det_loss(const float* const* logits, int ldl, void* const* gdet, int ldg
     HDY_ARG(nt == 0 || (gts && tcls), "det_loss: targets missing");
     const int no = nc + 5;
     HDY_ARG(ldl >= na * no && ldg >= na * no && ldl % 4 == 0 && ldg % 4 == 0, "det_loss: pitches too small or not multiples of 4");
-    HDY_ARG(ws_bytes >= hdy_det_loss_workspace_bytes(nl, ny, nx, B, na, ldl) && ((uintptr_t)workspace & 15) == 0, "det_loss: workspace too small / unaligned");
+    HDY_ARG(ws_bytes >= hdy_det_loss_workspace_bytes(nl, ny, nx, B, na, nc, nt) && ((uintptr_t)workspace & 15) == 0,
+            "det_loss: workspace too small for %d targets / unaligned", nt);
     HDY_ARG(dtype == HDY_BF16 || dtype == HDY_F32, "det_loss: unknown dtype");
-    HDY_ARG((long long)5 * na * nt < (1LL << 31), "det_loss: too many targets");
+    HDY_ARG((long long)nl * 5 * na * nt < (1LL << 31), "det_loss: too many targets");
+    for (int l = 0; l < nl; ++l) HDY_ARG((long long)B * ny[l] * nx[l] * (ldg / 4) < (1LL << 31), "det_loss: level %d has too many cells", l);
     LossArgs a = {};
     char* w = (char*)workspace;
     a.acc = (double*)w;
-    w += a16((size_t)MAXL * 6 * sizeof(double));
+    a.nrec = (int*)(w + (size_t)MAXL * (6 + OSL) * sizeof(double));
+    w += a16((size_t)MAXL * (6 + OSL) * sizeof(double) + sizeof(int));
     for (int l = 0; l < nl; ++l) {
         HDY_ARG(logits[l] && gdet[l] && ny[l] > 0 && nx[l] > 0, "det_loss: level %d missing", l);
         const size_t cells = (size_t)B * ny[l] * nx[l];
         a.logits[l] = logits[l]; a.gdet[l] = gdet[l]; a.ny[l] = ny[l]; a.nx[l] = nx[l]; a.balance[l] = balance[l];
-        a.scratch[l] = (float*)w;
-        w += a16(cells * ldl * sizeof(float));
-        a.tobj[l] = (unsigned long long*)w;
-        w += a16(cells * na * sizeof(unsigned long long));
+        a.head[l] = (int*)w;
+        w += a16(cells * na * sizeof(int));
         for (int i = 0; i < na; ++i) { a.anc[l][i][0] = anchors_grid[(l * na + i) * 2]; a.anc[l][i][1] = anchors_grid[(l * na + i) * 2 + 1]; }
     }
     a.nl = nl; a.B = B; a.na = na; a.nc = nc; a.no = no; a.ldl = ldl; a.ldg = ldg; a.nt = nt; a.gts = gts; a.tcls = tcls;
@@ -298,21 +391,30 @@ int hdy_det_loss(const float* const* logits, int ldl, void* const* gdet, int ldg
     a.cls_pw = cls_pw; a.obj_pw = obj_pw; a.anchor_t = anchor_t; a.smooth = label_smoothing;
     a.h_box = h_box; a.h_obj = h_obj; a.h_cls = h_cls; a.out = out;
     hipStream_t st = (hipStream_t)stream;
-    const size_t used = (size_t)(w - (char*)workspace);
-    hipLaunchKernelGGL(zero_kernel, dim3(2048), dim3(256), 0, st, (uint4*)workspace, used / 16);
+    const size_t used = (size_t)(w - (char*)workspace);          // sums, record counter, list heads: zeroed; the records behind them are not
+    a.recs = (float*)w;
+    a.rs = det_loss_record_floats(nc);
+    a.capacity = nl * 5 * na * nt;
+    hipLaunchKernelGGL(zero_kernel, dim3(used / 16 / 256 < 2048 ? (unsigned)(used / 16 / 256 + 1) : 2048u), dim3(256), 0, st, (uint4*)workspace, used / 16);
     HDY_LAUNCH_CHECK("det_loss zero");
-    for (int l = 0; l < nl && nt > 0; ++l) {
+    if (nt > 0) {
         const int total = 5 * na * nt;
-        hipLaunchKernelGGL(match_kernel, dim3(cdiv(total, 256) < 1024 ? cdiv(total, 256) : 1024), dim3(256), 0, st, a, l);
+        hipLaunchKernelGGL(match_kernel, dim3(cdiv(total, 1024) < 1024 ? cdiv(total, 1024) : 1024, nl), dim3(256), 0, st, a);
         HDY_LAUNCH_CHECK("det_loss match");
     }
+    long long most = 0;
     for (int l = 0; l < nl; ++l) {
         const long long items = (long long)B * ny[l] * nx[l] * (ldg / 4);
-        const int grid = (int)((items + 255) / 256 < 4096 ? (items + 255) / 256 : 4096);
-        if (dtype == HDY_BF16) hipLaunchKernelGGL(dense_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, a, l);
-        else hipLaunchKernelGGL(dense_kernel<float>, dim3(grid), dim3(256), 0, st, a, l);
-        HDY_LAUNCH_CHECK("det_loss dense");
+        if (items > most) most = items;
     }
+    // the largest level sets grid.x, the others stride less.  Every workgroup ends with one fp64 atomic and atomics on one address
+    // serialise (~50-100 ns each): with one sum per level, 4096 workgroups made that tail longer than the pass itself (140 us; 71 us
+    // with 1024 workgroups) — hence the OSL slots per level
+    static const int dense_grid = getenv("HDY_LOSS_GRID") ? atoi(getenv("HDY_LOSS_GRID")) : 2048;
+    const int grid = (int)((most + 255) / 256 < dense_grid ? (most + 255) / 256 : dense_grid);
+    if (dtype == HDY_BF16) hipLaunchKernelGGL(dense_kernel<bf16_t>, dim3(grid, nl), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(dense_kernel<float>, dim3(grid, nl), dim3(256), 0, st, a);
+    HDY_LAUNCH_CHECK("det_loss dense");
     hipLaunchKernelGGL(final_kernel, dim3(1), dim3(1), 0, st, a);
     HDY_LAUNCH_CHECK("det_loss final");
     return HDY_OK;

@@ -12,10 +12,17 @@ constexpr int CG = 8;   // channels per workgroup in the SPPF kernels
 
 // One workgroup owns the whole H x W plane of CG channels of one image in LDS and produces the three chained
 // 5x5/s1/p2 max-pools (= 5x5, 9x9, 13x13 windows) in one launch.  Ties resolve to the first maximum in
-// row-major window order, as ATen's max_pool2d does; idx stores that window position (0..24) for backward.
-// The plane is held with a 2-pixel border ((H+4) x (W+4); -inf forward, "no source" backward), so the 25 taps are straight-line
+// row-major window order, as ATen's max_pool2d does.
+// The plane is held with a 2-pixel border ((H+4) x (W+4); -inf forward, "no source" backward), so the taps are straight-line
 // code at compile-time offsets from the element's own address: no bounds tests, no per-tap index arithmetic (the first version,
 // bounds-tested loops over an unpadded plane, took 158 us forward / 294 us backward on 64 x 20 x 20 x 256).
+// Each 5x5 maximum is a ROW maximum followed by a COLUMN maximum (10 taps for 25), with the position tracked through both stages:
+// the first maximum in row-major order is the first row (smallest dy) whose row maximum equals the window maximum, and in that row
+// the first column (smallest dx) — exactly what the two stages pick when each keeps its first maximum (and the LAST NaN, as the
+// 25-tap scan `v > best || v != v` does).  The byte stored per element is  dy | dx' << 4  where dy (0..4) is the column stage's
+// choice for THIS output and dx' (0..4) the row stage's choice for the row maximum at THIS position — the two tables the backward
+// needs: the gradient of an output goes to row maximum (h + dy - 2, w), the gradient of a row maximum to source (h, w + dx' - 2).
+// Backward is the same two stages transposed, each a 5-tap gather (deterministic, no atomics).  The 25-tap forms took 117 / 165 us.
 constexpr int PB = 2;                                    // border pixels
 
 // thread -> (pixel, 4-channel group) walk over the interior of the padded plane without divisions: 256 / (CG/4) pixels per trip.
@@ -100,78 +107,108 @@ __global__ __launch_bounds__(256) void sppf_pool_fwd_kernel(const T* __restrict_
         }
         return;
     }
+    unsigned char* rx = (unsigned char*)(pl + 2 * PP * CG);          // [(H+4)*(W+4)][CG] row-stage positions
 #pragma unroll
     for (int pass = 0; pass < 3; ++pass) {
-        for (PlaneWalk q(W); q.pix < HW; q.next(W)) {
-            const float* ctr = a + ((q.h + PB) * WP + q.w + PB) * CG + cl;
+        for (PlaneWalk q(W); q.pix < HW; q.next(W)) {              // rows: a -> b
+            const int o = ((q.h + PB) * WP + q.w + PB) * CG + cl;
             f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-            int bi[4] = {0, 0, 0, 0};
+            unsigned bi[4] = {0, 0, 0, 0};
 #pragma unroll
-            for (int dy = 0; dy < 5; ++dy)
+            for (int dx = 0; dx < 5; ++dx) {
+                const f32x4 v = *(const f32x4*)(a + o + (dx - 2) * CG);
 #pragma unroll
-                for (int dx = 0; dx < 5; ++dx) {
-                    const f32x4 v = *(const f32x4*)(ctr + ((dy - 2) * WP + (dx - 2)) * CG);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (v[i] > best[i] || v[i] != v[i]) { best[i] = v[i]; bi[i] = dy * 5 + dx; }   // border taps are -inf: never selected
-                }
-            *(f32x4*)(b + ((q.h + PB) * WP + q.w + PB) * CG + cl) = best;
-            store4<T>(outs[pass] + (base + q.pix) * ld + c0, best);
-            if (idxs[pass]) *(unsigned*)(idxs[pass] + (base + q.pix) * C + c0) = (unsigned)bi[0] | (unsigned)bi[1] << 8 | (unsigned)bi[2] << 16 | (unsigned)bi[3] << 24;
+                for (int i = 0; i < 4; ++i)
+                    if (v[i] > best[i] || v[i] != v[i]) { best[i] = v[i]; bi[i] = dx; }               // border taps are -inf: never selected
+            }
+            *(f32x4*)(b + o) = best;
+            *(unsigned*)(rx + o) = bi[0] | bi[1] << 8 | bi[2] << 16 | bi[3] << 24;
         }
         __syncthreads();
-        float* t = a; a = b; b = t;
+        for (PlaneWalk q(W); q.pix < HW; q.next(W)) {              // columns: b -> a (the next pool's source)
+            const int o = ((q.h + PB) * WP + q.w + PB) * CG + cl;
+            f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            unsigned bj[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int dy = 0; dy < 5; ++dy) {
+                const f32x4 v = *(const f32x4*)(b + o + (dy - 2) * WP * CG);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (v[i] > best[i] || v[i] != v[i]) { best[i] = v[i]; bj[i] = dy; }
+            }
+            *(f32x4*)(a + o) = best;
+            store4<T>(outs[pass] + (base + q.pix) * ld + c0, best);
+            *(unsigned*)(idxs[pass] + (base + q.pix) * C + c0) = (bj[0] | bj[1] << 8 | bj[2] << 16 | bj[3] << 24) | (*(const unsigned*)(rx + o) << 4);
+        }
+        __syncthreads();
     }
 }
 
-// dx = g0 + P1^T( g1 + P2^T( g2 + P3^T g3 ) ), P^T = scatter-to-argmax written as a gather (deterministic).
+// dx = g0 + P1^T( g1 + P2^T( g2 + P3^T g3 ) ), P^T = scatter-to-argmax written as two 5-tap gathers (deterministic):
+// column stage  r[h'][w] = SUM_dy [dy(h' - dy + 2, w) == dy] t[h' - dy + 2][w],  row stage  s[h][w'] = SUM_dx [dx'(h, w' - dx + 2) == dx] r[h][w' - dx + 2].
 template <typename T>
 __global__ __launch_bounds__(256) void sppf_pool_bwd_kernel(const T* __restrict__ g0, const T* __restrict__ g1, const T* __restrict__ g2,
                                                             const T* __restrict__ g3, int ldg, const unsigned char* __restrict__ i1,
                                                             const unsigned char* __restrict__ i2, const unsigned char* __restrict__ i3,
                                                             T* __restrict__ dx, int lddx, int H, int W, int C) {
-    extern __shared__ __attribute__((aligned(16))) float pl[];          // [2][(H+4)*(W+4)][CG] floats + [(H+4)*(W+4)][CG] bytes
+    extern __shared__ __attribute__((aligned(16))) float pl[];          // [2][(H+4)*(W+4)][CG] floats + [2][(H+4)*(W+4)][CG] bytes
     const int HW = H * W, WP = W + 2 * PB, PP = (H + 2 * PB) * WP;
     float* a = pl;
     float* b = pl + PP * CG;
-    unsigned char* ix = (unsigned char*)(pl + 2 * PP * CG);
+    unsigned char* ixb = (unsigned char*)(pl + 2 * PP * CG);
     const int cgs = C / CG;
     const int cl = (threadIdx.x % QPP) * 4;
     const int n = blockIdx.x / cgs, c0 = (blockIdx.x - n * cgs) * CG + cl;
     const size_t base = (size_t)n * HW;
     const T* gs[3] = {g2, g1, g0};
     const unsigned char* idxs[3] = {i3, i2, i1};
-    for (int e = threadIdx.x; e < PP * CG; e += 256) ix[e] = 255;                   // border: a window position that never matches
+    for (int e = threadIdx.x; e < 2 * PP * CG / 4; e += 256) ((unsigned*)ixb)[e] = 0xffffffffu;   // border: positions that never match
     for (int e = threadIdx.x; e < 2 * PP * CG; e += 256) pl[e] = 0.f;              // border sources are read (and discarded) below
     __syncthreads();
-    for (PlaneWalk q(W); q.pix < HW; q.next(W)) *(f32x4*)(a + ((q.h + PB) * WP + q.w + PB) * CG + cl) = load4<T>(g3 + (base + q.pix) * ldg + c0);
+    for (PlaneWalk q(W); q.pix < HW; q.next(W)) {
+        const int o = ((q.h + PB) * WP + q.w + PB) * CG + cl;
+        *(f32x4*)(a + o) = load4<T>(g3 + (base + q.pix) * ldg + c0);
+        *(unsigned*)(ixb + o) = *(const unsigned*)(idxs[0] + (base + q.pix) * C + c0);
+    }
+    __syncthreads();
 #pragma unroll
     for (int pass = 0; pass < 3; ++pass) {
-        for (PlaneWalk q(W); q.pix < HW; q.next(W))
-            *(unsigned*)(ix + ((q.h + PB) * WP + q.w + PB) * CG + cl) = *(const unsigned*)(idxs[pass] + (base + q.pix) * C + c0);
-        __syncthreads();
-        for (PlaneWalk q(W); q.pix < HW; q.next(W)) {
-            const int ctr = ((q.h + PB) * WP + q.w + PB) * CG + cl;
-            f32x4 s = load4<T>(gs[pass] + (base + q.pix) * ldg + c0);
-            // window centre (h - ey, w - ex) picked this pixel iff its stored position is (ey + 2, ex + 2); all 25 candidate reads are
-            // unconditional and independent (a compare-then-load chain per tap made this pass latency bound: 350 us)
+        const unsigned char* ix = ixb + (pass & 1) * PP * CG;
+        unsigned char* ixn = ixb + ((pass + 1) & 1) * PP * CG;
+        for (PlaneWalk q(W); q.pix < HW; q.next(W)) {              // columns: a -> b.  All candidate reads are unconditional and independent
+            const int o = ((q.h + PB) * WP + q.w + PB) * CG + cl;
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ey = -2; ey <= 2; ++ey)
+            for (int dy = 0; dy < 5; ++dy) {
+                const int src = o - (dy - 2) * WP * CG;
+                const unsigned pos = *(const unsigned*)(ix + src);
+                const f32x4 v = *(const f32x4*)(a + src);
 #pragma unroll
-                for (int ex = -2; ex <= 2; ++ex) {
-                    const int src = ctr - (ey * WP + ex) * CG;
-                    const unsigned pos = *(const unsigned*)(ix + src);
-                    const f32x4 v = *(const f32x4*)(a + src);
-                    const unsigned code = (ey + 2) * 5 + (ex + 2);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) s[i] += ((pos >> (8 * i)) & 255u) == code ? v[i] : 0.f;
-                }
-            *(f32x4*)(b + ctr) = s;
+                for (int i = 0; i < 4; ++i) s[i] += ((pos >> (8 * i)) & 15u) == (unsigned)dy ? v[i] : 0.f;
+            }
+            *(f32x4*)(b + o) = s;
         }
         __syncthreads();
-        float* t = a; a = b; b = t;
+        for (PlaneWalk q(W); q.pix < HW; q.next(W)) {              // rows: b -> a, plus this level's own gradient
+            const int o = ((q.h + PB) * WP + q.w + PB) * CG + cl;
+            f32x4 s = load4<T>(gs[pass] + (base + q.pix) * ldg + c0);
+#pragma unroll
+            for (int ex = 0; ex < 5; ++ex) {
+                const int src = o - (ex - 2) * CG;
+                const unsigned pos = *(const unsigned*)(ix + src);
+                const f32x4 v = *(const f32x4*)(b + src);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s[i] += ((pos >> (8 * i + 4)) & 15u) == (unsigned)ex ? v[i] : 0.f;
+            }
+            if (pass == 2) {
+                store4<T>(dx + (base + q.pix) * lddx + c0, s);
+            } else {
+                *(f32x4*)(a + o) = s;
+                *(unsigned*)(ixn + o) = *(const unsigned*)(idxs[pass + 1] + (base + q.pix) * C + c0);
+            }
+        }
+        if (pass < 2) __syncthreads();
     }
-    for (PlaneWalk q(W); q.pix < HW; q.next(W)) store4<T>(dx + (base + q.pix) * lddx + c0, *(const f32x4*)(a + ((q.h + PB) * WP + q.w + PB) * CG + cl));
 }
 
 template <typename T>
@@ -287,7 +324,7 @@ int hdy_sppf_pool_fwd(const void* x, void* y1, void* y2, void* y3, int ld, unsig
     HDY_ARG(x && y1 && y2 && y3 && N > 0 && H > 0 && W > 0 && C > 0, "sppf_pool_fwd: bad args");
     HDY_ARG(C % CG == 0 && ld >= C && ld % 4 == 0, "sppf_pool_fwd: C=%d must be a multiple of %d, ld >= C and a multiple of 4", C, CG);
     HDY_ARG((idx1 == nullptr) == (idx2 == nullptr) && (idx1 == nullptr) == (idx3 == nullptr), "sppf_pool_fwd: idx buffers all or none");
-    const size_t smem = (size_t)2 * (H + 2 * PB) * (W + 2 * PB) * CG * sizeof(float);
+    const size_t smem = (size_t)(H + 2 * PB) * (W + 2 * PB) * CG * (2 * sizeof(float) + (idx1 ? 1 : 0));
     HDY_ARG(smem <= 150 * 1024, "sppf_pool_fwd: plane %dx%d does not fit LDS", H, W);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == HDY_BF16) {
@@ -308,7 +345,7 @@ int hdy_sppf_pool_bwd(const void* g0, const void* g1, const void* g2, const void
                       void* stream) {
     HDY_ARG(g0 && g1 && g2 && g3 && idx1 && idx2 && idx3 && dx && N > 0 && H > 0 && W > 0, "sppf_pool_bwd: bad args");
     HDY_ARG(C % CG == 0 && ldg >= C && lddx >= C && ldg % 4 == 0 && lddx % 4 == 0, "sppf_pool_bwd: bad channel count / pitch");
-    const size_t smem = (size_t)(H + 2 * PB) * (W + 2 * PB) * CG * (2 * sizeof(float) + 1);
+    const size_t smem = (size_t)(H + 2 * PB) * (W + 2 * PB) * CG * (2 * sizeof(float) + 2);
     HDY_ARG(smem <= 150 * 1024, "sppf_pool_bwd: plane %dx%d does not fit LDS", H, W);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == HDY_BF16) {

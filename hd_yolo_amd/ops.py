@@ -676,8 +676,7 @@ class DetLossCall:
         self.cw = (ctypes.c_float * nc)(*[float(v) for v in cls_cw])
         self.hyp = hyp
         self.dtype = dcode(gdets[0].dtype)
-        nbytes = _lib.query('hdy_det_loss_workspace_bytes', nl, self.ny, self.nx, self.B, na, self.ldl)
-        self.ws = torch.empty(nbytes // 4 + 4, dtype=torch.float32, device=device)
+        self.ws, self.ws_targets, self.device = None, -1, device       # sized by the number of targets, grown when a batch has more
         self.out = out
         self.keep = (logits, gdets)
 
@@ -686,6 +685,10 @@ class DetLossCall:
         assert gts.dtype == torch.float32 and gts.is_contiguous() and (nt == 0 or gts.shape[1] == 5)
         assert tcls.dtype == torch.float32 and tcls.is_contiguous() and (nt == 0 or tuple(tcls.shape) == (nt, self.nc))
         h = self.hyp
+        if nt > self.ws_targets:
+            self.ws_targets = max(64, nt + nt // 2)
+            nbytes = _lib.query('hdy_det_loss_workspace_bytes', self.nl, self.ny, self.nx, self.B, self.na, self.nc, self.ws_targets)
+            self.ws = torch.empty(nbytes // 4 + 4, dtype=torch.float32, device=self.device)
         _lib.call('hdy_det_loss', self.lp, self.ldl, self.gp, self.ldg, self.dtype, self.ny, self.nx, self.nl, self.B, self.na, self.nc,
                   self.anc, self.bal, gts.data_ptr() if nt else None, tcls.data_ptr() if nt else None, nt, self.cw,
                   float(h['cls_pw']), float(h['obj_pw']), float(h['anchor_t']), float(h['label_smoothing']), float(h['box']),

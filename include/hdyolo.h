@@ -256,8 +256,10 @@ int hdy_cast_store(const float* src, void* dst, int ldd, long long M, int C, int
  * logits[l]: fp32 [B][ny][nx][ldl], channel a*no+o;  gdet[l]: dtype [B][ny][nx][ldg] (ldl, ldg multiples of 4, 16-byte aligned
  * bases; channels >= na*no of gdet are written as zero);  anchors_grid: nl*na*2 HOST floats in grid
  * units; balance: nl HOST floats; gts: device [nt][5] (img, cx, cy, w, h normalised); tcls: device [nt][nc] class targets;
- * cls_cw: nc HOST floats.  out: device [4] = loss (x batch), box, obj, cls items.  Supported: fl_gamma = 0, no autobalance. */
-size_t hdy_det_loss_workspace_bytes(int nl, const int* ny, const int* nx, int B, int na, int ldl);
+ * cls_cw: nc HOST floats.  out: device [4] = loss (x batch), box, obj, cls items.  Supported: fl_gamma = 0, no autobalance.
+ * workspace: hdy_det_loss_workspace_bytes(..., nt) bytes for calls with up to nt targets (sums, one list head per cell and anchor,
+ * one record per possible match: nl * 5 * na * nt of them). */
+size_t hdy_det_loss_workspace_bytes(int nl, const int* ny, const int* nx, int B, int na, int nc, int nt);
 int hdy_det_loss(const float* const* logits, int ldl, void* const* gdet, int ldg, int dtype, const int* ny, const int* nx, int nl, int B,
                  int na, int nc, const float* anchors_grid, const float* balance, const float* gts, const float* tcls, int nt,
                  const float* cls_cw, float cls_pw, float obj_pw, float anchor_t, float label_smoothing, float h_box, float h_obj, float h_cls,

@@ -330,6 +330,18 @@ def test_sppf_pool(shape, dtype):
     dx = torch.empty((N, H, W, C), dtype=dtype, device=DEV)
     ops.run([ops.rec_sppf_pool_bwd(gs[0], gs[1], gs[2], gs[3], idx, dx)])
     assert_close(from_dev_nhwc(dx), xr.grad, TOL[dtype], 'sppf backward')
+    # many equal values per window (four levels): the gradient must go to the FIRST maximum in row-major window order, as ATen's does
+    xt = q(torch.round(x * 1.5) / 1.5, dtype).clone().requires_grad_(True)
+    y1 = F.max_pool2d(xt, 5, 1, 2)
+    y2 = F.max_pool2d(y1, 5, 1, 2)
+    y3 = F.max_pool2d(y2, 5, 1, 2)
+    cat = torch.cat([xt, y1, y2, y3], 1)
+    cat.backward(g)
+    sl[0].copy_(xt.detach().permute(0, 2, 3, 1).to(dtype))
+    ops.run([ops.rec_sppf_pool_fwd(sl[0], sl[1], sl[2], sl[3], idx)])
+    assert torch.equal(from_dev_nhwc(buf), cat.detach()), 'sppf forward with ties'
+    ops.run([ops.rec_sppf_pool_bwd(gs[0], gs[1], gs[2], gs[3], idx, dx)])
+    assert_close(from_dev_nhwc(dx), xt.grad, TOL[dtype], 'sppf backward with ties')
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
