@@ -74,6 +74,7 @@ SIGNATURES = {
     'hdy_add_inplace': (_I, [_P, _I, _P, _I, _L, _I, _I, _P]),
     'hdy_colsum': (_I, [_P, _I, _L, _I, _P, _I, _I, _P, _P]),
     'hdy_det_grad_pack': (_I, [_P, _L, _L, _L, _L, _L, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'hdy_det_targets': (_I, [_P, _P, _P, _I, _I, _P, _P, _P]),
     'hdy_det_loss_workspace_bytes': (_Z, [_I, _P, _P, _I, _I, _I, _I]),
     'hdy_det_loss': (_I, [_P, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _F, _F, _F, _F, _F, _F, _F, _P, _P, _Z, _P]),
     'hdy_scale_inplace': (_I, [_P, _L, _P, _I, _P]),

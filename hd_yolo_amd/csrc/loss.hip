@@ -344,6 +344,24 @@ __global__ __launch_bounds__(256) void scale_kernel(T* p, size_t n, const float*
         p[i] = from_f32<T>(to_f32<T>(p[i]) * s);
 }
 
+// Target rows of hdy_det_loss from the batch's concatenated annotation tensors: gts[t] = (img, cx, cy, w, h) of the corner box,
+// tcls[t][c] = 1 if label == c + 1 (labels outside 1..nc select no class: column 0 of the reference's one-hot, dropped by its [:, 1:]).
+__global__ __launch_bounds__(256) void det_targets_kernel(const float* __restrict__ boxes, const float* __restrict__ img,
+                                                          const long long* __restrict__ labels, int nt, int nc, float* __restrict__ gts,
+                                                          float* __restrict__ tcls) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= nt) return;
+    const f32x4 b = *(const f32x4*)(boxes + (size_t)t * 4);
+    float* g = gts + (size_t)t * 5;
+    g[0] = img[t];
+    g[1] = (b[0] + b[2]) / 2;
+    g[2] = (b[1] + b[3]) / 2;
+    g[3] = b[2] - b[0];
+    g[4] = b[3] - b[1];
+    const long long lab = labels[t];
+    for (int c = 0; c < nc; ++c) tcls[(size_t)t * nc + c] = lab == c + 1 ? 1.f : 0.f;
+}
+
 inline size_t a16(size_t v) { return (v + 15) / 16 * 16; }
 
 }  // namespace
@@ -417,6 +435,15 @@ int hdy_det_loss(const float* const* logits, int ldl, void* const* gdet, int ldg
     HDY_LAUNCH_CHECK("det_loss dense");
     hipLaunchKernelGGL(final_kernel, dim3(1), dim3(1), 0, st, a);
     HDY_LAUNCH_CHECK("det_loss final");
+    return HDY_OK;
+}
+
+int hdy_det_targets(const float* boxes, const float* img, const long long* labels, int nt, int nc, float* gts, float* tcls, void* stream) {
+    HDY_ARG(nt >= 0 && nc >= 1 && nc <= MAXC, "det_targets: bad sizes");
+    if (nt == 0) return HDY_OK;
+    HDY_ARG(boxes && img && labels && gts && tcls && ((uintptr_t)boxes & 15) == 0, "det_targets: null / unaligned pointer");
+    hipLaunchKernelGGL(det_targets_kernel, dim3(cdiv(nt, 256)), dim3(256), 0, (hipStream_t)stream, boxes, img, labels, nt, nc, gts, tcls);
+    HDY_LAUNCH_CHECK("det_targets");
     return HDY_OK;
 }
 

@@ -280,8 +280,10 @@ class Detect(nn.Module):
         return (os.environ.get('HDY_FUSED_LOSS', '1') != '0' and not dl.autobalance and dl.hyp['fl_gamma'] == 0 and dl.gr == 1.0
                 and not dl.sort_obj_iou and self.nc <= 128)
 
-    def flatten_targets(self, targets, dev):
-        """Per-image ann dicts -> gts (nt,5) [img, cx, cy, w, h] and one-hot labels (nt, nc+1), built once per batch."""
+    def flatten_targets(self, targets, dev, fused=False):
+        """Per-image ann dicts -> gts (nt,5) [img, cx, cy, w, h] and one-hot labels (nt, nc+1), built once per batch.
+        fused=True (device path, plain integer labels): one kernel, and the second result is tcls (nt, nc) float instead — what
+        hdy_det_loss takes; the (nt, nc+1) table is only built by callers that need it."""
         boxes = [t['boxes'] for t in targets]
         if boxes:
             torch._foreach_clamp_min_(boxes, 0.0)      # the reference's xyxy2xywh(clip=True) clamps the caller's boxes too
@@ -297,21 +299,31 @@ class Detect(nn.Module):
 
         allb = up(torch.cat(boxes)) if boxes else torch.zeros((0, 4), device=dev)
         img = up(torch.repeat_interleave(torch.arange(len(boxes), dtype=allb.dtype), torch.tensor(counts)))       # one small upload
+        labs = [t['labels'] for t in targets]
+        plain = all(l.dim() == 1 for l in labs)
+        if fused and plain and dev.type == 'cuda' and allb.dtype == torch.float32 and len(labs) > 0:
+            from hd_yolo_amd import ops
+            return ops.det_targets(allb.contiguous(), img, up(torch.cat(labs)).long(), self.nc)
         gts = torch.stack([img, (allb[:, 0] + allb[:, 2]) / 2, (allb[:, 1] + allb[:, 3]) / 2, allb[:, 2] - allb[:, 0],
                            allb[:, 3] - allb[:, 1]], 1)
-        labs = [t['labels'] for t in targets]
-        if all(l.dim() == 1 for l in labs):
+        if plain:
             gt_labels = one_hot_labels(up(torch.cat(labs)), self.nc)
         else:
             gt_labels = up(torch.cat([one_hot_labels(l, self.nc) if l.dim() == 1 else l for l in labs]))
+        if fused:
+            return gts.contiguous(), gt_labels[:, 1:].float().contiguous()
         return gts, gt_labels
 
     def fused_losses(self, engine, x, dtype, targets, compute_masks=False):
-        gts, gt_labels = self.flatten_targets(targets, x.device)
-        tcls = gt_labels[:, 1:].float().contiguous()
-        plan, loss, items = engine.forward_fused_loss(x, dtype, self, gts.contiguous(), tcls)
+        want_masks = compute_masks and self.nc_masks > 0
+        if want_masks:
+            gts, gt_labels = self.flatten_targets(targets, x.device)
+            gts, tcls = gts.contiguous(), gt_labels[:, 1:].float().contiguous()
+        else:
+            gts, tcls = self.flatten_targets(targets, x.device, fused=True)
+        plan, loss, items = engine.forward_fused_loss(x, dtype, self, gts, tcls)
         mask_loss = None
-        if compute_masks and self.nc_masks > 0:
+        if want_masks:
             # the mask branch needs WHICH cells were matched: the tensor-expression matcher on the (detached) logits — the same
             # assignment the loss kernel made — and the decoded boxes of those cells
             dets = [d.detach() for d in plan.det_views()]

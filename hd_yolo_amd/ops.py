@@ -695,6 +695,16 @@ class DetLossCall:
                   float(h['obj']), float(h['cls']), self.out.data_ptr(), self.ws.data_ptr(), self.ws.numel() * 4, stream_ptr())
 
 
+def det_targets(boxes, img, labels, nc):
+    """(nt, 4) clamped corner boxes, (nt,) image index, (nt,) int64 labels -> gts (nt, 5) [img, cx, cy, w, h], tcls (nt, nc) one-hot of labels 1..nc"""
+    nt = int(boxes.shape[0])
+    assert boxes.dtype == torch.float32 and boxes.is_contiguous() and img.dtype == torch.float32 and labels.dtype == torch.int64
+    gts = torch.empty((nt, 5), dtype=torch.float32, device=boxes.device)
+    tcls = torch.empty((nt, nc), dtype=torch.float32, device=boxes.device)
+    _lib.call('hdy_det_targets', ptr(boxes), ptr(img), ptr(labels), nt, nc, gts.data_ptr(), tcls.data_ptr(), stream_ptr())
+    return gts, tcls
+
+
 def scale_inplace(t, scale):
     """t *= scale (a 1-element fp32 device tensor), no host sync"""
     assert t.is_contiguous() and scale.dtype == torch.float32 and scale.is_cuda

@@ -264,6 +264,11 @@ int hdy_det_loss(const float* const* logits, int ldl, void* const* gdet, int ldg
                  int na, int nc, const float* anchors_grid, const float* balance, const float* gts, const float* tcls, int nt,
                  const float* cls_cw, float cls_pw, float obj_pw, float anchor_t, float label_smoothing, float h_box, float h_obj, float h_cls,
                  float* out, void* workspace, size_t ws_bytes, void* stream);
+/* gts / tcls of hdy_det_loss from the batch's annotations (replaces the xyxy -> xywh conversion and the one-hot encoding of
+ * Detect.forward's target preparation, metayolo/models/yolo_head.py:217-222: ~15 eager tensor ops per step): boxes device [nt][4] corner boxes
+ * (normalised, already clamped to [0, 1]), img device [nt] image index of each row (fp32), labels device [nt] int64 class labels
+ * 1..nc (anything else: no class) -> gts [nt][5], tcls [nt][nc]. */
+int hdy_det_targets(const float* boxes, const float* img, const long long* labels, int nt, int nc, float* gts, float* tcls, void* stream);
 int hdy_scale_inplace(void* p, long long n, const float* scale_dev, int dtype, void* stream);
 
 /* ---- Semantic-segmentation branch (hnet's PanopticSeg) ---------------------------------------------

@@ -685,3 +685,21 @@ def test_stem_weight_gradient_with_fused_batchnorm_backward_is_bit_identical():
     assert torch.equal(g_fused, g_ref) and g_ref.abs().max().item() > 0
     assert not ops.wgrad_stem_fused_ok(N, H, W, 48, dt) and not ops.wgrad_stem_fused_ok(N, 60, 60, K, dt)
 
+
+
+def test_det_targets_equals_the_tensor_expressions():
+    """hdy_det_targets against the eager form it replaces (yolo_head.py:217-222: xyxy -> xywh rows and the one-hot class table without
+    its column 0), labels outside 1..nc included."""
+    from metayolo.models.utils_torch import one_hot_labels
+    g = torch.Generator().manual_seed(3)
+    nt, nc = 1000, 8
+    xy = torch.rand((nt, 2), generator=g) * 0.8
+    boxes = torch.cat([xy, xy + torch.rand((nt, 2), generator=g) * 0.2], 1).to(DEV)
+    img = torch.randint(0, 64, (nt,), generator=g).float().to(DEV)
+    labels = torch.randint(-1, nc + 3, (nt,), generator=g).to(DEV)
+    gts, tcls = ops.det_targets(boxes, img, labels, nc)
+    want = torch.stack([img, (boxes[:, 0] + boxes[:, 2]) / 2, (boxes[:, 1] + boxes[:, 3]) / 2, boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]], 1)
+    assert torch.equal(gts, want)
+    assert torch.equal(tcls, one_hot_labels(labels, nc)[:, 1:].float())
+    e = ops.det_targets(boxes[:0], img[:0], labels[:0], nc)
+    assert e[0].shape == (0, 5) and e[1].shape == (0, nc)
