@@ -115,16 +115,18 @@ struct BnParams {
 };
 
 // Final stage.  Input is either the fp32 slabs (ST = float) or stage A's fp64 partials (ST = double).
-// grid = ceil(K/32), block = 32 channels x 32 tile-lanes
+// grid = ceil(K/8), block = 8 channels x 32 tile-lanes.  (32 x 32 = 1024-thread workgroups were the first shape: a workgroup that needs 16 wave
+// slots and 17 KB of LDS on ONE CU waits whenever the weight-gradient stream's kernels fill the CUs — 35-47 us for a 5 us kernel.)
+constexpr int FCL = 8, FTL = 32;
 template <typename ST>
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(const ST* __restrict__ stats, int stats_ld, int mtiles, int K, double count,
-                                                           BnParams bn, float eps, float momentum,
-                                                           float* __restrict__ scale, float* __restrict__ shift,
-                                                           float* __restrict__ save_mean, float* __restrict__ save_invstd,
-                                                           const double* __restrict__ count_dev = nullptr) {
-    __shared__ double red[2][32][33];
-    const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
-    const int k = blockIdx.x * 32 + cl;
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const ST* __restrict__ stats, int stats_ld, int mtiles, int K, double count,
+                                                          BnParams bn, float eps, float momentum,
+                                                          float* __restrict__ scale, float* __restrict__ shift,
+                                                          float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                          const double* __restrict__ count_dev = nullptr) {
+    __shared__ double red[2][FTL][FCL + 1];
+    const int cl = threadIdx.x % FCL, tl = threadIdx.x / FCL;
+    const int k = blockIdx.x * FCL + cl;
     if (count_dev) count = *count_dev;                   // SyncBatchNorm: the all-reduced element count
     double s = 0.0, ss = 0.0;
     if (k < K) {
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const ST* __restrict_
     __syncthreads();
     if (tl == 0 && k < K) {
         s = 0.0; ss = 0.0;
-        for (int t = 0; t < 32; ++t) { s += red[0][t][cl]; ss += red[1][t][cl]; }
+        for (int t = 0; t < FTL; ++t) { s += red[0][t][cl]; ss += red[1][t][cl]; }
         const double mean = s / count;
         double var = ss / count - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -311,23 +313,26 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restr
 // (Measured and not adopted: dropping this launch by letting the reduce pass add its sums into fp64 accumulators with
 // global_atomic_add_f64 and deriving c1 / c2 in the apply pass — up to 1024 device-scope atomics per address cost ~100 us per
 // layer: 17.1 -> 22.9 ms per yolov5s bench step.)
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblocks, int K, double count,
+// CL channels x TL slab lanes per workgroup: 8 x 32 for the usual few hundred slabs (small workgroups, see bn_finalize_kernel), 8 x 128 for
+// the slab arrays of the fused 1x1 backward kernel (one slab per workgroup of a 3 000 - 6 000 workgroup launch).
+template <int CL, int TL>
+__global__ __launch_bounds__(CL * TL) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblocks, int K, double count,
                                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                float* __restrict__ dgamma_b, float* __restrict__ dbeta_b, int Ka, int accumulate,
                                                                float* __restrict__ c1, float* __restrict__ c2,
                                                                const float* __restrict__ mean = nullptr, const float* __restrict__ invstd = nullptr) {
-    __shared__ double red[2][32][33];
-    const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
-    const int k = blockIdx.x * 32 + cl;
+    __shared__ double red[2][TL][CL + 1];
+    const int cl = threadIdx.x % CL, tl = threadIdx.x / CL;
+    const int k = blockIdx.x * CL + cl;
     double s1 = 0.0, s2 = 0.0;
     if (k < K) {
         int t = tl;
-        for (; t + 96 < nblocks; t += 128) {              // 8 independent loads in flight per lane (see bn_finalize_kernel)
+        for (; t + 3 * TL < nblocks; t += 4 * TL) {       // 8 independent loads in flight per lane (see bn_finalize_kernel)
             float a[4], b[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                a[u] = partial[((size_t)(t + 32 * u) * 2 + 0) * K + k];
-                b[u] = partial[((size_t)(t + 32 * u) * 2 + 1) * K + k];
+                a[u] = partial[((size_t)(t + TL * u) * 2 + 0) * K + k];
+                b[u] = partial[((size_t)(t + TL * u) * 2 + 1) * K + k];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -335,7 +340,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
                 s2 += (double)b[u];
             }
         }
-        for (; t < nblocks; t += 32) {
+        for (; t < nblocks; t += TL) {
             s1 += (double)partial[((size_t)t * 2 + 0) * K + k];
             s2 += (double)partial[((size_t)t * 2 + 1) * K + k];
         }
@@ -345,7 +350,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
     __syncthreads();
     if (tl == 0 && k < K) {
         s1 = 0.0; s2 = 0.0;
-        for (int t = 0; t < 32; ++t) { s1 += red[0][t][cl]; s2 += red[1][t][cl]; }
+        for (int t = 0; t < TL; ++t) { s1 += red[0][t][cl]; s2 += red[1][t][cl]; }
         if (mean) s2 = (double)invstd[k] * (s2 - (double)mean[k] * s1);      // slabs of (SUM du, SUM du*y) from a producer's epilogue
         float* const db = k < Ka ? dbeta : dbeta_b;      // parameter gradients of the pair's second module
         float* const dg = k < Ka ? dgamma : dgamma_b;
@@ -355,6 +360,17 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
         if (c1) c1[k] = (float)(s1 / count);
         if (c2) c2[k] = (float)(s2 / count);
     }
+}
+
+static void bn_bwd_finalize_launch(hipStream_t st, const float* partial, int nblocks, int K, double count, float* dgamma, float* dbeta, float* dgamma_b,
+                                   float* dbeta_b, int Ka, int accumulate, float* c1, float* c2, const float* mean = nullptr,
+                                   const float* invstd = nullptr) {
+    if (nblocks >= 1024)
+        hipLaunchKernelGGL((bn_bwd_finalize_kernel<8, 128>), dim3(cdiv(K, 8)), dim3(1024), 0, st, partial, nblocks, K, count, dgamma, dbeta, dgamma_b, dbeta_b, Ka,
+                           accumulate, c1, c2, mean, invstd);
+    else
+        hipLaunchKernelGGL((bn_bwd_finalize_kernel<8, 32>), dim3(cdiv(K, 8)), dim3(256), 0, st, partial, nblocks, K, count, dgamma, dbeta, dgamma_b, dbeta_b, Ka,
+                           accumulate, c1, c2, mean, invstd);
 }
 
 // FROZEN: constant scale / shift (FrozenBatchNorm2d): dy = scale * du, no statistics terms (mean / invstd / c1 / c2 unused)
@@ -499,10 +515,10 @@ static int bn_finalize_impl(const float* stats, int stats_ld, int mtiles, int K,
         double* part = (double*)workspace;
         hipLaunchKernelGGL(bn_partial_kernel, dim3(cdiv(K, 32), G), dim3(1024), 0, st, stats, stats_ld, mtiles, K, tpg, part);
         HDY_LAUNCH_CHECK("bn_partial");
-        hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3(cdiv(K, 32)), dim3(1024), 0, st, (const double*)part, K, cdiv(mtiles, tpg), K,
+        hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3(cdiv(K, FCL)), dim3(256), 0, st, (const double*)part, K, cdiv(mtiles, tpg), K,
                            (double)count, bn, eps, momentum, scale, shift, save_mean, save_invstd);
     } else {
-        hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3(cdiv(K, 32)), dim3(1024), 0, st, stats, stats_ld, mtiles, K, (double)count, bn, eps,
+        hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3(cdiv(K, FCL)), dim3(256), 0, st, stats, stats_ld, mtiles, K, (double)count, bn, eps,
                            momentum, scale, shift, save_mean, save_invstd);
     }
     HDY_LAUNCH_CHECK("bn_finalize");
@@ -550,7 +566,7 @@ int hdy_bn_finalize_sums(const double* sums, int sums_ld, const double* count, i
     const BnParams bn = {gamma_a, beta_a, running_mean_a, running_var_a, gamma_b, beta_b, running_mean_b, running_var_b, Ka};
     HDY_ARG(sums && count && gamma_a && beta_a && scale && shift && save_mean && save_invstd && K > 0 && sums_ld >= K, "bn_finalize_sums: bad args");
     HDY_ARG(Ka == K || (Ka > 0 && Ka < K && gamma_b && beta_b), "bn_finalize_sums: second module's parameters missing or split point outside (0, K)");
-    hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3(cdiv(K, 32)), dim3(1024), 0, (hipStream_t)stream, sums, sums_ld, 1, K, 1.0, bn, eps, momentum, scale,
+    hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3(cdiv(K, FCL)), dim3(256), 0, (hipStream_t)stream, sums, sums_ld, 1, K, 1.0, bn, eps, momentum, scale,
                        shift, save_mean, save_invstd, count);
     HDY_LAUNCH_CHECK("bn_finalize_sums");
     return HDY_OK;
@@ -645,8 +661,7 @@ static int bn_act_bwd_impl(const Split& dz, const void* y, int ldy, const float*
     if (dtype == HDY_BF16) bn_bwd_reduce_launch<bf16_t>(grid, st, dz, y, ldy, scale, shift, mean, invstd, (int)M, K, act, rows, partial);
     else bn_bwd_reduce_launch<float>(grid, st, dz, y, ldy, scale, shift, mean, invstd, (int)M, K, act, rows, partial);
     HDY_LAUNCH_CHECK("bn_act_bwd_reduce");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(K, 32)), dim3(1024), 0, st, partial, nb, K, (double)M, dgamma, dbeta, dgamma_b, dbeta_b, dz.Ka,
-                       accumulate, c1, c2);
+    bn_bwd_finalize_launch(st, partial, nb, K, (double)M, dgamma, dbeta, dgamma_b, dbeta_b, dz.Ka, accumulate, c1, c2);
     HDY_LAUNCH_CHECK("bn_bwd_finalize");
     if (!dy) return HDY_OK;                               // statistics only: the consumer applies c1 / c2 itself (conv1x1_bwd.hip)
     if (dtype == HDY_BF16) bn_bwd_apply_launch<bf16_t, false>(g2, st, dz, y, ldy, scale, shift, mean, invstd, c1, c2, dy, lddy, (int)M, K, act);
@@ -658,8 +673,7 @@ static int bn_act_bwd_impl(const Split& dz, const void* y, int ldy, const float*
 int hdy_bn_bwd_finalize_slabs(const float* slabs, int nslabs, int K, long long count, const float* mean, const float* invstd, float* dgamma,
                               float* dbeta, int accumulate, float* c1, float* c2, void* stream) {
     HDY_ARG(slabs && nslabs > 0 && K > 0 && count > 0 && mean && invstd, "bn_bwd_finalize_slabs: bad args");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(K, 32)), dim3(1024), 0, (hipStream_t)stream, slabs, nslabs, K, (double)count, dgamma, dbeta,
-                       (float*)nullptr, (float*)nullptr, K, accumulate, c1, c2, mean, invstd);
+    bn_bwd_finalize_launch((hipStream_t)stream, slabs, nslabs, K, (double)count, dgamma, dbeta, nullptr, nullptr, K, accumulate, c1, c2, mean, invstd);
     HDY_LAUNCH_CHECK("bn_bwd_finalize_slabs");
     return HDY_OK;
 }
@@ -705,8 +719,7 @@ int hdy_colsum(const void* dz, int lddz, long long M, int K, float* out, int acc
     if (dtype == HDY_BF16) bn_bwd_reduce_launch<bf16_t>(grid, st, src, nullptr, 0, nullptr, nullptr, nullptr, nullptr, (int)M, K, 0, rows, workspace);
     else bn_bwd_reduce_launch<float>(grid, st, src, nullptr, 0, nullptr, nullptr, nullptr, nullptr, (int)M, K, 0, rows, workspace);
     HDY_LAUNCH_CHECK("colsum_reduce");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(K, 32)), dim3(1024), 0, st, workspace, nb, K, (double)M, (float*)nullptr, out, (float*)nullptr,
-                       (float*)nullptr, K, accumulate, (float*)nullptr, (float*)nullptr);
+    bn_bwd_finalize_launch(st, workspace, nb, K, (double)M, nullptr, out, nullptr, nullptr, K, accumulate, nullptr, nullptr);
     HDY_LAUNCH_CHECK("colsum_finalize");
     return HDY_OK;
 }
