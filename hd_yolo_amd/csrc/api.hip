@@ -113,6 +113,7 @@ int hdy_conv_pack_describe(const float* w_a, int K_a, const float* w_b, int K_b,
     HDY_ARG((K_b == 0) == (w_b == nullptr), "conv_pack: w_b / K_b mismatch");
     HDY_ARG(stride == 1 || stride == 2, "conv_pack: stride %d unsupported", stride);
     HDY_ARG(dtype == HDY_BF16 || dtype == HDY_F32, "conv_pack: unknown dtype %d", dtype);
+    HDY_ARG(((long long)K + 256) * ((long long)R * S * ((long long)C + 256) + 64) < (1LL << 31), "conv_pack: weight too large for 32-bit packing indices");
     if (kind == KIND_FWD || kind == KIND_STEM) {
         const int stem = kind == KIND_STEM;
         HDY_ARG(!stem || (C == 3 && K_b == 0), "conv_pack: stem expects C == 3 and a single weight");

@@ -462,9 +462,9 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_scalar_kernel(const float* 
 //   transpose == 1: row = c, cdim = k (dgrad geometry)
 //   tap t = (tr, ts) in a TH x TW window reads source (r, s) = (rbase + rstep*tr, sbase + sstep*ts)
 //   stem == 1: forward only, cdim = s*4 + c over a [R][S*4] window (TH = R, TW = 1), c == 3 is zero
-__device__ __forceinline__ float pack_value(const hdy_pack_desc& d, long long idx) {
+__device__ __forceinline__ float pack_value(const hdy_pack_desc& d, unsigned idx) {      // idx < rows_total * Kdp < 2^31 (checked where the job is made)
     // logical weight W[k][c][r][s], k < Kl: rows of w_a, then rows of w_b, then zeros (channel padding)
-    const int row = (int)(idx / d.Kdp), col = (int)(idx - (long long)row * d.Kdp);
+    const int row = (int)(idx / (unsigned)d.Kdp), col = (int)(idx - (unsigned)row * (unsigned)d.Kdp);
     int k = -1, c = 0, r = 0, s = 0;
     if (d.stem) {
         r = col / (d.S * 4);
@@ -491,8 +491,8 @@ __device__ __forceinline__ float pack_value(const hdy_pack_desc& d, long long id
 
 // one job per launch (descriptor by value)
 __global__ __launch_bounds__(256) void pack_weight_kernel(const hdy_pack_desc d) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)d.rows_total * d.Kdp) return;
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (unsigned)d.rows_total * (unsigned)d.Kdp) return;
     const float v = pack_value(d, idx);
     if (d.dtype == HDY_BF16) ((bf16_t*)d.out)[idx] = (bf16_t)v;
     else ((float*)d.out)[idx] = v;
@@ -507,8 +507,8 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const hdy_pack_desc* __
         if (table[mid].first_block <= b) lo = mid; else hi = mid - 1;
     }
     const hdy_pack_desc d = table[lo];
-    const long long idx = (long long)(b - d.first_block) * blockDim.x + threadIdx.x;
-    if (idx >= (long long)d.rows_total * d.Kdp) return;
+    const unsigned idx = (unsigned)(b - d.first_block) * blockDim.x + threadIdx.x;
+    if (idx >= (unsigned)d.rows_total * (unsigned)d.Kdp) return;
     const float v = pack_value(d, idx);
     if (d.dtype == HDY_BF16) ((bf16_t*)d.out)[idx] = (bf16_t)v;
     else ((float*)d.out)[idx] = v;
