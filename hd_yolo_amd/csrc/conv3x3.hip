@@ -40,6 +40,10 @@
 // patch issue" in barrier-closed half-steps (46.7): a lone MFMA wave per SIMD reaches only ~62 % of the pipe rate (1.8-1.9k cycles
 // per half item against 1.15k), which two independently scheduled workgroups hide by overlapping their MFMA phases, and 28 % of
 // the cycles went to waiting at the half-step barriers.
+// Round 2: waves as (pixel half) x (channel half) — 32 output channels and half the rows per wave, so each patch fragment is read by two
+// waves instead of four (LDS reads -40 %, 18 MFMAs per fragment group instead of 9) at 144 filter VGPRs: dgrad 64<-64 33.0 us as before,
+// 32<-32 51.1 against 56.5 us, but the forward with statistics needs more than 256 registers (56 B of scratch, 55.7 us).  The LDS reads
+// are not what holds the 64-channel kernel back; not adopted.
 // Ablation: without the patch fetch 35.1, without the output stores 34.8, without both 32.9 us — the kernel is not memory bound;
 // the MFMA pipe is busy ~45 % of the cycles (1.7 GHz under this load), the rest is per-item work that two waves per SIMD do
 // not overlap completely (patch issue ~2.0k cycles, statistics + staging ~0.6k, row stores ~0.5k, barriers ~0.4k per 8-row item).
