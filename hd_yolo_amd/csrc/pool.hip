@@ -150,8 +150,10 @@ template <typename T>
 __global__ __launch_bounds__(256) void sppf_pool_bwd_kernel(const T* __restrict__ g0, const T* __restrict__ g1, const T* __restrict__ g2,
                                                             const T* __restrict__ g3, int ldg, const unsigned char* __restrict__ i1,
                                                             const unsigned char* __restrict__ i2, const unsigned char* __restrict__ i3,
-                                                            T* __restrict__ dx, int lddx, int H, int W, int C) {
-    extern __shared__ __attribute__((aligned(16))) float pl[];          // [2][(H+4)*(W+4)][CG] floats + [2][(H+4)*(W+4)][CG] bytes
+                                                            T* __restrict__ dx, int lddx, int H, int W, int C, int two_ix) {
+    // two_ix: a second position plane, so that the next level's positions are fetched during the row stage instead of between two extra
+    // barriers (planes up to 38 x 38; a 40 x 40 plane — 1280 x 1280 tiles at stride 32 — only fits with one)
+    extern __shared__ __attribute__((aligned(16))) float pl[];          // [2][(H+4)*(W+4)][CG] floats + [1 or 2][(H+4)*(W+4)][CG] bytes
     const int HW = H * W, WP = W + 2 * PB, PP = (H + 2 * PB) * WP;
     float* a = pl;
     float* b = pl + PP * CG;
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(256) void sppf_pool_bwd_kernel(const T* __restrict_
     const size_t base = (size_t)n * HW;
     const T* gs[3] = {g2, g1, g0};
     const unsigned char* idxs[3] = {i3, i2, i1};
-    for (int e = threadIdx.x; e < 2 * PP * CG / 4; e += 256) ((unsigned*)ixb)[e] = 0xffffffffu;   // border: positions that never match
+    for (int e = threadIdx.x; e < (two_ix ? 2 : 1) * PP * CG / 4; e += 256) ((unsigned*)ixb)[e] = 0xffffffffu;   // border: positions that never match
     for (int e = threadIdx.x; e < 2 * PP * CG; e += 256) pl[e] = 0.f;              // border sources are read (and discarded) below
     __syncthreads();
     for (PlaneWalk q(W); q.pix < HW; q.next(W)) {
@@ -173,8 +175,8 @@ __global__ __launch_bounds__(256) void sppf_pool_bwd_kernel(const T* __restrict_
     __syncthreads();
 #pragma unroll
     for (int pass = 0; pass < 3; ++pass) {
-        const unsigned char* ix = ixb + (pass & 1) * PP * CG;
-        unsigned char* ixn = ixb + ((pass + 1) & 1) * PP * CG;
+        const unsigned char* ix = ixb + (two_ix ? (pass & 1) * PP * CG : 0);
+        unsigned char* ixn = ixb + (two_ix ? ((pass + 1) & 1) * PP * CG : 0);
         for (PlaneWalk q(W); q.pix < HW; q.next(W)) {              // columns: a -> b.  All candidate reads are unconditional and independent
             const int o = ((q.h + PB) * WP + q.w + PB) * CG + cl;
             f32x4 s = {0.f, 0.f, 0.f, 0.f};
@@ -204,10 +206,17 @@ __global__ __launch_bounds__(256) void sppf_pool_bwd_kernel(const T* __restrict_
                 store4<T>(dx + (base + q.pix) * lddx + c0, s);
             } else {
                 *(f32x4*)(a + o) = s;
-                *(unsigned*)(ixn + o) = *(const unsigned*)(idxs[pass + 1] + (base + q.pix) * C + c0);
+                if (two_ix) *(unsigned*)(ixn + o) = *(const unsigned*)(idxs[pass + 1] + (base + q.pix) * C + c0);
             }
         }
-        if (pass < 2) __syncthreads();
+        if (pass < 2) {
+            __syncthreads();
+            if (!two_ix) {                                         // the one position plane is free only now
+                for (PlaneWalk q(W); q.pix < HW; q.next(W))
+                    *(unsigned*)(ixn + ((q.h + PB) * WP + q.w + PB) * CG + cl) = *(const unsigned*)(idxs[pass + 1] + (base + q.pix) * C + c0);
+                __syncthreads();
+            }
+        }
     }
 }
 
@@ -348,17 +357,19 @@ int hdy_sppf_pool_bwd(const void* g0, const void* g1, const void* g2, const void
                       void* stream) {
     HDY_ARG(g0 && g1 && g2 && g3 && idx1 && idx2 && idx3 && dx && N > 0 && H > 0 && W > 0, "sppf_pool_bwd: bad args");
     HDY_ARG(C % CG == 0 && ldg >= C && lddx >= C && ldg % 4 == 0 && lddx % 4 == 0, "sppf_pool_bwd: bad channel count / pitch");
-    const size_t smem = (size_t)(H + 2 * PB) * (W + 2 * PB) * CG * (2 * sizeof(float) + 2);
+    const size_t plane = (size_t)(H + 2 * PB) * (W + 2 * PB) * CG;
+    const int two_ix = plane * (2 * sizeof(float) + 2) <= 150 * 1024;
+    const size_t smem = plane * (2 * sizeof(float) + (two_ix ? 2 : 1));
     HDY_ARG(smem <= 150 * 1024, "sppf_pool_bwd: plane %dx%d does not fit LDS", H, W);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == HDY_BF16) {
         (void)hipFuncSetAttribute((const void*)sppf_pool_bwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         hipLaunchKernelGGL(sppf_pool_bwd_kernel<bf16_t>, dim3(N * (C / CG)), dim3(256), smem, st, (const bf16_t*)g0, (const bf16_t*)g1,
-                           (const bf16_t*)g2, (const bf16_t*)g3, ldg, idx1, idx2, idx3, (bf16_t*)dx, lddx, H, W, C);
+                           (const bf16_t*)g2, (const bf16_t*)g3, ldg, idx1, idx2, idx3, (bf16_t*)dx, lddx, H, W, C, two_ix);
     } else {
         (void)hipFuncSetAttribute((const void*)sppf_pool_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         hipLaunchKernelGGL(sppf_pool_bwd_kernel<float>, dim3(N * (C / CG)), dim3(256), smem, st, (const float*)g0, (const float*)g1,
-                           (const float*)g2, (const float*)g3, ldg, idx1, idx2, idx3, (float*)dx, lddx, H, W, C);
+                           (const float*)g2, (const float*)g3, ldg, idx1, idx2, idx3, (float*)dx, lddx, H, W, C, two_ix);
     }
     HDY_LAUNCH_CHECK("sppf_pool_bwd");
     return HDY_OK;
