@@ -42,7 +42,10 @@ constexpr int W3_MAXPP = 352;        // patch pixels per tile
 constexpr int W3_PROWS = 384;                           // patch rows an LDS buffer holds (48 DMA instructions: 6 for each of 8 waves)
 constexpr int W3_DY_Q = W3_MAXTP / 8 / 4;               // DMA instructions per tile of each dy-loading wave (waves 0-3)
 constexpr int W3_P_Q = W3_PROWS / 8 / 8;                // ... of each patch-loading wave (waves 4-11)
-constexpr int W3_BUF = (W3_MAXTP + W3_PROWS) * 128;     // bytes of one (dy tile | patch) buffer: 80 KB, two of them = the CU's 160 KB
+constexpr int W3_BUF = (W3_MAXTP + W3_MAXPP) * 128;     // bytes of one (dy tile | patch) buffer: 76 KB.  Two of them leave 8 KB of the CU's 160 KB:
+                                                        // with all of it taken (buffers of W3_PROWS rows) even a 5 KB main-stream workgroup — a BatchNorm
+                                                        // finalize — waited a whole weight-gradient kernel (~42 us) for LDS.  The four DMA instructions
+                                                        // that would fill patch rows 352-383 (waves 8-11, i = 5) are skipped instead
 static_assert(W3_MAXPP <= W3_PROWS, "patch buffer");
 
 // One 12-wave workgroup per CU with two LDS buffers: the next tile's dy / patch stream in by LDS-DMA while the current tile's nine
@@ -116,6 +119,7 @@ __global__ __launch_bounds__(768) void wgrad3x3_kernel(const W3Args p) {
             const bf16_t* org = x + ((size_t)(n * p.Hin + ih0) * p.Win + iw0) * p.ldx;   // patch pixel (1, 1); offsets may be negative
 #pragma unroll
             for (int i = 0; i < W3_P_Q; ++i) {
+                if ((wave - 4 + 8 * i) * 8 >= W3_MAXPP) continue;                        // wave-uniform: rows the buffer does not hold
                 const int py = l_yx[i] >> 16, px = l_yx[i] & 0xFFFF;                     // image pixel (ih0 + py - 1, iw0 + px - 1)
                 const bool ok = (unsigned)(ih0 + py - 1) < (unsigned)p.Hin && (unsigned)(iw0 + px - 1) < (unsigned)p.Win && py < 0x7FFF;
                 const void* src = ok ? (const void*)(org + l_off[i]) : (const void*)zero;
@@ -165,7 +169,9 @@ __global__ __launch_bounds__(768) void wgrad3x3_kernel(const W3Args p) {
         const bool more = t + p.nsplit < tiles;
         if (more) {
             issue(t + p.nsplit, cur ^ 1);                // the buffer tile t - nsplit used: everyone left it at the barrier below
+            // everything but the next tile's requests of this wave must have landed (waves 8-11 skip one patch request, see W3_BUF)
             if (dy_loader) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W3_DY_Q) : "memory");
+            else if ((wave - 4 + 8 * (W3_P_Q - 1)) * 8 >= W3_MAXPP) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W3_P_Q - 1) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W3_P_Q) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
