@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restr
                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                 int M, int K, int act, int rows_per_block, float* __restrict__ partial) {
     constexpr int VE = VT<T>::VE;
-    __shared__ float red[2][256 * VE];
+    __shared__ float red[256 * VE];                      // one sum at a time (8 KB, not 16: the weight-gradient stream's kernels leave 32 KB or less per CU)
     const int VCt = K / VE;
     const Lane L = lane_map(VCt, blockIdx.y);
     const int VC = min(256, VCt - blockIdx.y * 256);
@@ -291,21 +291,20 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restr
             const i32x4 vq = MODE != 0 ? *(const i32x4*)(y + (size_t)m * ldy + c) : i32x4{0, 0, 0, 0};
             accumulate(gq, vq);
         }
-#pragma unroll
-        for (int i = 0; i < VE; ++i) {
-            red[0][(L.rl * VC + (L.vc - blockIdx.y * 256)) * VE + i] = a1[i];
-            red[1][(L.rl * VC + (L.vc - blockIdx.y * 256)) * VE + i] = a2[i];
-        }
     }
-    __syncthreads();
-    for (int j = threadIdx.x; j < VC * VE; j += 256) {
-        float s1 = 0.f, s2 = 0.f;
-        for (int r = 0; r < L.RL; ++r) {
-            s1 += red[0][r * VC * VE + j];
-            s2 += red[1][r * VC * VE + j];
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        if (L.live) {
+#pragma unroll
+            for (int i = 0; i < VE; ++i) red[(L.rl * VC + (L.vc - blockIdx.y * 256)) * VE + i] = which ? a2[i] : a1[i];
         }
-        partial[((size_t)blockIdx.x * 2 + 0) * K + blockIdx.y * 256 * VE + j] = s1;
-        partial[((size_t)blockIdx.x * 2 + 1) * K + blockIdx.y * 256 * VE + j] = s2;
+        __syncthreads();
+        for (int j = threadIdx.x; j < VC * VE; j += 256) {
+            float s = 0.f;
+            for (int r = 0; r < L.RL; ++r) s += red[r * VC * VE + j];
+            partial[((size_t)blockIdx.x * 2 + which) * K + blockIdx.y * 256 * VE + j] = s;
+        }
+        __syncthreads();
     }
 }
 
