@@ -101,7 +101,7 @@ static hdy_pack_desc make_desc(const float* w_a, int K_a, const float* w_b, int 
     d.w_a = w_a; d.w_b = w_b; d.out = out; d.K_a = K_a; d.K_b = K_b; d.Kl = Kl; d.C = C; d.R = R; d.S = S; d.transpose = transpose;
     d.TH = TH; d.TW = TW; d.rbase = rbase; d.rstep = rstep; d.sbase = sbase; d.sstep = sstep; d.stem = stem; d.rows_total = rows_total;
     d.Kdp = Kdp; d.dtype = dtype; d.first_block = first_block;
-    d.nblocks = cdiv((long long)rows_total * Kdp, 256);
+    d.nblocks = cdiv((long long)rows_total * Kdp, 2048);      // 256 threads x 8 outputs (conv_wgrad.hip PACK_PER_BLOCK)
     return d;
 }
 

@@ -489,13 +489,53 @@ __device__ __forceinline__ float pack_value(const hdy_pack_desc& d, unsigned idx
     return v;
 }
 
+// Eight consecutive outputs (one 16-byte bf16 store) per thread: inside one tap the source row / column and the bounds are shared, only the
+// channel moves (stride R*S or C*R*S floats in the source).  Kdp is a multiple of 8, so a vector never crosses a packed row.
+__device__ __forceinline__ void pack8(const hdy_pack_desc& d, unsigned idx0) {
+    const int row = (int)(idx0 / (unsigned)d.Kdp), col0 = (int)(idx0 - (unsigned)row * (unsigned)d.Kdp);
+    float v[8];
+    const int cd = d.transpose ? d.Kl : d.C;
+    const int t = d.stem ? 0 : col0 / cd, ci0 = col0 - t * cd;
+    if (!d.stem && ci0 + 8 <= cd) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+        if (t < d.TH * d.TW) {
+            const int tr = t / d.TW, ts = t - tr * d.TW;
+            const int r = d.rbase + d.rstep * tr, sx = d.sbase + d.sstep * ts;
+            if (r >= 0 && r < d.R && sx >= 0 && sx < d.S) {
+                const size_t rs = (size_t)r * d.S + sx, RS = (size_t)d.R * d.S;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int c = d.transpose ? row : ci0 + j, k = d.transpose ? ci0 + j : row;
+                    if (c < d.C) {
+                        if (k < d.K_a) v[j] = d.w_a[((size_t)k * d.C + c) * RS + rs];
+                        else if (k < d.K_a + d.K_b) v[j] = d.w_b[((size_t)(k - d.K_a) * d.C + c) * RS + rs];
+                    }
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = pack_value(d, idx0 + j);
+    }
+    if (d.dtype == HDY_BF16) {
+        V16 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.h[j] = (bf16_t)v[j];
+        *(i32x4*)((bf16_t*)d.out + idx0) = o.i;
+    } else {
+        *(f32x4*)((float*)d.out + idx0) = f32x4{v[0], v[1], v[2], v[3]};
+        *(f32x4*)((float*)d.out + idx0 + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    }
+}
+
+// a workgroup packs 256 x 8 = 2048 outputs: hdy_pack_desc.nblocks (api.hip make_desc) counts those
+
 // one job per launch (descriptor by value)
 __global__ __launch_bounds__(256) void pack_weight_kernel(const hdy_pack_desc d) {
-    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned idx = (blockIdx.x * blockDim.x + threadIdx.x) * 8;
     if (idx >= (unsigned)d.rows_total * (unsigned)d.Kdp) return;
-    const float v = pack_value(d, idx);
-    if (d.dtype == HDY_BF16) ((bf16_t*)d.out)[idx] = (bf16_t)v;
-    else ((float*)d.out)[idx] = v;
+    pack8(d, idx);
 }
 
 // every job of a plan in one launch: block -> descriptor by binary search over first_block
@@ -507,11 +547,9 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const hdy_pack_desc* __
         if (table[mid].first_block <= b) lo = mid; else hi = mid - 1;
     }
     const hdy_pack_desc d = table[lo];
-    const unsigned idx = (unsigned)(b - d.first_block) * blockDim.x + threadIdx.x;
+    const unsigned idx = ((unsigned)(b - d.first_block) * blockDim.x + threadIdx.x) * 8;
     if (idx >= (unsigned)d.rows_total * (unsigned)d.Kdp) return;
-    const float v = pack_value(d, idx);
-    if (d.dtype == HDY_BF16) ((bf16_t*)d.out)[idx] = (bf16_t)v;
-    else ((float*)d.out)[idx] = v;
+    pack8(d, idx);
 }
 
 }  // namespace
