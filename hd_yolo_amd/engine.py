@@ -32,6 +32,8 @@ class GradStore:
         self.cur = torch.zeros(n, dtype=torch.float32, device=device)
         self.acc = torch.zeros(n, dtype=torch.float32, device=device)
         self._acc_views = {id(p): self._view(self.acc, p) for p in self.params}
+        self._cur_views = {id(p): self._view(self.cur, p) for p in self.params}
+        self.aliased = False          # parameters' .grad are views of `cur` itself (no copy was made for them yet)
 
     def _view(self, flat, p):
         o = self.offsets[id(p)]
@@ -44,9 +46,12 @@ class GradStore:
         live = [p for p in self.params if p.requires_grad]
         fresh = all(p.grad is None for p in live)
         if fresh:
-            self.acc.copy_(self.cur)
+            # hand out views of the buffer the backward wrote — no 29 MB copy per step.  They stay valid until the next backward pass
+            # starts; if the caller still holds them then (gradient accumulation, zero_grad(set_to_none=False)), before_backward()
+            # moves them into `acc` first
             for p in live:
-                p.grad = self._acc_views[id(p)]
+                p.grad = self._cur_views[id(p)]
+            self.aliased = True
             return
         mine = all(p.grad is not None and p.grad.data_ptr() == self._acc_views[id(p)].data_ptr() for p in live)
         if mine:
@@ -58,6 +63,17 @@ class GradStore:
                 p.grad = g.clone()
             else:
                 p.grad.add_(g)
+
+    def before_backward(self):
+        """Called before anything of a backward pass writes `cur`: gradients that are still views of it move to `acc`."""
+        if not self.aliased:
+            return
+        self.aliased = False
+        held = [p for p in self.params if p.grad is not None and p.grad.data_ptr() == self._cur_views[id(p)].data_ptr()]
+        if held:
+            self.acc.copy_(self.cur)
+            for p in held:
+                p.grad = self._acc_views[id(p)]
 
 
 class _PlanFn(torch.autograd.Function):
@@ -125,6 +141,7 @@ class MaskBranchFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits):
         store, plan, head = ctx.engine.store, ctx.plan, ctx.head
+        store.before_backward()
         dx = ctx.run.backward(dlogits.permute(0, 2, 3, 1).contiguous().float(), store.view_of)
         inv = torch.empty_like(ctx.order)
         inv[ctx.order] = torch.arange(len(ctx.order), device=ctx.order.device)
@@ -331,6 +348,7 @@ class Engine:
     def tap_grad_sink(self, plan):
         """`grad_of(param)` for an outside module's backward: the flat store's view; the first call marks the gradients as written"""
         def grad_of(p):
+            self.store.before_backward()
             plan.tap_grads_ready = True
             return self.store.view_of(p)
         return grad_of

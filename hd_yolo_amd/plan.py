@@ -869,6 +869,8 @@ class Plan:
         """gdets: autograd's logits gradients (unfused loss), or None when the fused loss kernel already filled the plan's
         gradient buffers; then `scale` is the upstream gradient of the loss (1-element device tensor).  gtaps: gradients of the
         tapped feature maps (NCHW-shaped, or None = no outside consumer contributed in this step)."""
+        if self.grad_store is not None:
+            self.grad_store.before_backward()
         for i, k in enumerate(self.tap_keys):
             g = None if gtaps is None else gtaps[i]
             if g is None:

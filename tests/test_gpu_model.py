@@ -581,3 +581,34 @@ def test_bf16_plan_layer_by_layer_with_producer_side_statistics():
         p = subprocess.run([sys.executable, '-m', 'pytest', 'tests/test_gpu_model.py', '-q', '-x', '-k', 'test_bf16_plan_layer_by_layer_against_fp32_torch'],
                            cwd=root, env=env, capture_output=True, text=True, timeout=600)
         assert p.returncode == 0 and ' passed' in p.stdout, (mode, p.stdout[-3000:])
+
+
+def test_gradients_under_every_zero_grad_style():
+    """The parameters' .grad are views of the flat buffer the backward pass writes (no copy per step); a caller that keeps them across a
+    backward pass — gradient accumulation, zero_grad(set_to_none=False) — must still see torch's semantics."""
+    nc, B, S = 2, 2, 64
+    model = build('n', nc).train()
+    x = synth.synth_images(B, S, seed=11).to(DEV)
+    params = [p for p in model.parameters() if p.requires_grad]
+
+    def backward():
+        losses, _ = model(x, synth.synth_targets(B, S, nc, nmin=3, nmax=8, seed=5))
+        losses['det']['det_loss'].backward()
+
+    backward()
+    g1 = [p.grad.clone() for p in params]
+    held = [p.grad for p in params]                       # the tensors a caller may keep
+    for p in params:                                      # zero_grad(set_to_none=False)
+        p.grad.zero_()
+    backward()                                            # same batch statistics, same weights: the same gradient, added to zeros
+    for p, g in zip(params, g1):
+        assert relmax(p.grad, g) < 1e-4
+    backward()                                            # no zeroing: accumulates
+    for p, g in zip(params, g1):
+        assert relmax(p.grad, 2 * g) < 1e-4
+    for p in params:                                      # zero_grad(set_to_none=True)
+        p.grad = None
+    backward()
+    for p, g in zip(params, g1):
+        assert relmax(p.grad, g) < 1e-4
+    assert all(h.shape == p.shape for h, p in zip(held, params))
