@@ -281,7 +281,12 @@ __global__ __launch_bounds__(2 * BM, (BM == 256 || BN == 128 || STAT) ? 2 : (BN 
     // BatchNorm sums: with a single column tile (K <= 128, every large layer) they stay in registers for all of the workgroup's
     // tiles and are written as ONE slab per workgroup at the end; otherwise each tile reduces its 16 pixel lanes and writes the
     // slab rows of its 128-row groups.  (Per tile the single-tap layers spent more cycles here than in their MFMAs.)
-    const bool wg_stats = p.stats != nullptr && ntiles == 1;
+    // BatchNorm sums stay in registers across ALL of a workgroup's tiles when every one of them is the same column tile: a single column
+    // tile, or the interleaved order with grid % ntiles == 0 (tile index = m-tile * ntiles + n-tile, step = grid).  One slab row per
+    // workgroup position then (wg_id / ntiles), each of the ntiles workgroups that share it filling its BN columns.  Otherwise one slab per
+    // 128 output rows from every tile's epilogue: 32 values x 4 shuffle steps, two barriers and a slab write per tile — on the 1x1 layers
+    // with 4-8 k-blocks per tile that was a third of the kernel (256->256 @40x40: 45.7 -> 30.5 us without it).
+    const bool wg_stats = p.stats != nullptr && (ntiles == 1 || (interleave && !walk && (int)gridDim.x % ntiles == 0));
     // epilogue scale / shift of the current column tile: [2][BN] floats behind the ring — except for the 32-wide tile (always a single
     // column tile, and 4 workgroups fill the LDS exactly), whose 4 + 4 values per lane are loaded once into registers
     constexpr bool COEF_LDS = BN > 32;
@@ -670,17 +675,24 @@ __global__ __launch_bounds__(2 * BM, (BM == 256 || BN == 128 || STAT) ? 2 : (BN 
         __syncthreads();
         stats_to_lds(red, s1, s2);
         __syncthreads();
-        const size_t slab = (size_t)wg_id;               // wg_stats implies one column tile: contiguous ranges, wg_id = tile_begin / tpb
+        // one column tile: contiguous ranges, wg_id = tile_begin / tpb; interleaved: this workgroup's column tile is wg_id % ntiles
+        const size_t slab = (size_t)(wg_id / ntiles);
+        const int n0 = (wg_id % ntiles) * BN;
         for (int j = tid; j < 2 * BN; j += NTHR) {
             const int which = j / BN, c = j - which * BN;
-            if (c < p.K) {
+            if (n0 + c < p.K) {
                 float v = 0.f;
 #pragma unroll
                 for (int g = 0; g < BM / 64; ++g) v += red[(g * BN + c) * 2 + which];
-                p.stats[(slab * 2 + which) * p.K + c] = v;
+                p.stats[(slab * 2 + which) * p.K + n0 + c] = v;
             }
         }
     }
+}
+
+inline int igemm_interleave_mode() {      // bit 0: column tiles of one m-tile on neighbouring workgroups, bit 1: parity classes of the stride-2 dgrad too
+    static const int mode = getenv("HDY_TILE_INTERLEAVE") ? atoi(getenv("HDY_TILE_INTERLEAVE")) : 1;
+    return mode;
 }
 
 // Persistent grid of a tile configuration: as many workgroups as stay resident (LDS-limited), never more than tiles.
@@ -736,14 +748,15 @@ int launch_bn(const ConvArgs& a, hipStream_t st) {
 
 int hdy_conv_bn_tile(int K) { return K <= 32 ? 32 : (K <= 64 ? 64 : 128); }
 
-// Statistic slabs the generic kernel writes for M output pixels, K channels, `taps` filter taps: one per workgroup when the layer
-// has a single column tile (sums stay in registers across the workgroup's tiles), else one per 128 output rows.
+// Statistic slabs the generic kernel writes for M output pixels, K channels, `taps` filter taps: one per workgroup position when the
+// sums stay in registers across the workgroup's tiles (a single column tile, or interleaved column tiles with grid % ntiles == 0: the
+// kernel's wg_stats), else one per 128 output rows.
 int hdy_conv_igemm_slabs(long long M, int K, int taps) {
     const int bn = hdy_conv_bn_tile(K), ntiles = cdiv(K, bn);
-    if (ntiles > 1) return (int)((M + 127) / 128);
     const bool big = igemm_big(M, bn, ntiles, taps);
     const int BM = big ? 256 : 128;
     const int grid = igemm_grid(M, ntiles, BM, bn, big ? 3 : 2);
+    if (ntiles > 1) return ((igemm_interleave_mode() & 1) && grid % ntiles == 0) ? grid / ntiles : (int)((M + 127) / 128);
     const long long tiles = (M + BM - 1) / BM;
     const long long tpb = (tiles + grid - 1) / grid;
     return (int)((tiles + tpb - 1) / tpb);
@@ -807,8 +820,7 @@ int hdy_conv_igemm_launch(ConvArgs a, int dtype, int out_f32, hipStream_t st) {
     HDY_ARG(a.UH * a.UW <= 31, "conv: %d x %d tap window beyond the loader's 31 tap bits", a.UH, a.UW);
     HDY_ARG(((long long)(a.UH + 1) * a.Win + a.UW) * a.ldx * (dtype == HDY_BF16 ? 2 : 4) < (1LL << 28), "conv: tap window spans too many bytes");
     a.utap = a.C % BKE == 0 ? 1 : 0;
-    static const int interleave_mode = getenv("HDY_TILE_INTERLEAVE") ? atoi(getenv("HDY_TILE_INTERLEAVE")) : 1;      // bit 0: column tiles, bit 1: parity classes
-    a.tile_interleave = interleave_mode;
+    a.tile_interleave = igemm_interleave_mode();
     hdy_magic((unsigned)(a.Ho * a.Wo), &a.mg_howo, &a.sh_howo);
     hdy_magic((unsigned)a.Wo, &a.mg_wo, &a.sh_wo);
     hdy_magic((unsigned)a.C, &a.mg_c, &a.sh_c);
