@@ -612,3 +612,33 @@ def test_gradients_under_every_zero_grad_style():
     for p, g in zip(params, g1):
         assert relmax(p.grad, g) < 1e-4
     assert all(h.shape == p.shape for h, p in zip(held, params))
+
+
+@pytest.mark.parametrize('fused', ['1', '0'])
+@pytest.mark.parametrize('nc', [1, 5])
+def test_class_counts_other_than_the_fixtures_match_oracle(nc, fused, monkeypatch):
+    """nc = 1 (a single nucleus class: 6 outputs per anchor, 18 logits padded to 20, no class loss — loss.py:222 `if self.nc > 1`) and an
+    odd class count (10 outputs per anchor, 30 -> 32): logits pitch, objectness positions inside the 4-channel groups of the loss
+    kernel and the class-gradient slots differ from the 2- and 8-class fixtures."""
+    from oracle.ref_net import RefNet
+    monkeypatch.setenv('HDY_FUSED_LOSS', fused)
+    B, S = 2, 64
+    cfg, hyp = synth.make_cfg('n', nc), synth.make_hyp()
+    model = build('n', nc).train()
+    net = RefNet(cfg, hyp)
+    sd = net.init_state()
+    for k in sd:
+        if 'running' not in k:
+            sd[k].requires_grad_(True)
+    x = synth.synth_images(B, S, seed=11)
+    lg, _ = model(x.to(DEV), synth.synth_targets(B, S, nc, nmin=20, nmax=40, seed=5))       # dense: several matches share a cell
+    lg['det']['det_loss'].backward()
+    lc, items, _ = net.train_forward(sd, x, synth.synth_targets(B, S, nc, nmin=20, nmax=40, seed=5))
+    lc.backward()
+    a, b = float(lg['det']['det_loss'].detach()), float(lc.detach())
+    assert a == a and abs(a - b) <= 2e-4 * abs(b), (a, b)
+    for k in ('box', 'obj', 'cls'):
+        assert abs(float(lg['det']['loss_items'][k]) - float(items[k])) <= 2e-4 * abs(float(items[k])) + 1e-7, k
+    params = dict(model.named_parameters())
+    for k in ('backbone.0.conv.weight', 'neck.13.cv3.conv.weight', 'headers.det.m.0.bias', 'headers.det.m.0.weight', 'headers.det.m.2.weight'):
+        assert relmax(params[k].grad, sd[k].grad) < 2e-3, k
