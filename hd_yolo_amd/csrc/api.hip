@@ -265,6 +265,8 @@ static int dgrad_impl(const void* dy, int lddy, const void* w_packed_dgrad, void
             c.w = w_packed_dgrad;
             c.dh0 = c.c_dh[0]; c.dw0 = c.c_dw[0]; c.TH = c.c_TH[0]; c.TW = c.c_TW[0]; c.oh_off = c.ow_off = 0;
             c.Kdp = c.c_nkb[0] * bke(dtype);
+            int rc2 = HDY_OK;
+            if (hdy_dgrad3x3s2_try(c, dtype, (hipStream_t)stream, &rc2)) return rc2;     // patch-resident kernel for the 32<-64 layer
             return hdy_conv_igemm_launch(c, dtype, 0, (hipStream_t)stream);
         }
         off = 0;

@@ -89,3 +89,4 @@ size_t hdy_wgrad3x3_workspace_bytes(int N, int Ho, int Wo, int C, int K, int str
 int hdy_wgrad3x3_try(const void* x, int ldx, const void* dy, int lddy, int N, int Hin, int Win, int Ho, int Wo, int C, int K, int stride, float* partial,
                      int dtype, hipStream_t st, int* splits, int* rc);
 int hdy_conv_igemm_stat_grid(long long M, int K, int taps, int ncls);
+int hdy_dgrad3x3s2_try(const ConvArgs& a, int dtype, hipStream_t st, int* rc);

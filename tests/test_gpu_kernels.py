@@ -65,6 +65,7 @@ CONV_CASES = [
     (3, 64, 96, 64, 128, 3, 2, 1),       # class walk over many tiles: workgroup ranges start mid-group
     (2, 48, 48, 128, 256, 3, 2, 1),      # two column tiles per class
     (3, 40, 40, 256, 512, 1, 1, 0),
+    (2, 32, 64, 32, 64, 3, 2, 1),        # the patch-resident stride-2 data gradient (dx 32 <- dy 64 channels, dy grid 16 x 32 = 2 x 2 tiles)
     (2, 24, 24, 16, 32, 3, 2, 1),        # stride-2 dgrad over 32 gradient channels: class walk with k-blocks that straddle taps
     (1, 20, 28, 32, 48, 3, 2, 1),        # ... over 48
     (2, 20, 20, 128, 128, 3, 1, 1),      # wide 3x3 / stride 1: one column tile
