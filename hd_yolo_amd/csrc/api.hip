@@ -72,6 +72,8 @@ int hdy_conv_mtiles(long long M) { return (int)((M + 127) / 128); }
 int hdy_conv_stat_slabs(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dtype) {
     int own = hdy_conv3x3_c64_slabs(N, H, W, C, K, R, S, stride, pad, dtype);
     if (own > 0) return own;
+    own = hdy_conv3x3s2_c32_slabs(N, H, W, C, K, R, S, stride, pad, dtype);
+    if (own > 0) return own;
     const bool stem = C == 3 && R == 6 && S == 6 && stride == 2 && pad == 2;
     if (stem) {
         own = hdy_conv_stem_slabs(N, H, W, K, dtype);

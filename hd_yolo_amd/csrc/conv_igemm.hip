@@ -829,6 +829,7 @@ int hdy_conv_igemm_launch(ConvArgs a, int dtype, int out_f32, hipStream_t st) {
     if (a.ncls <= 1 && a.nstat == 0) {
         if (hdy_conv_stem_try(a, dtype, out_f32, st, &rc)) return rc;         // patch-resident 6x6/s2 stem
         if (hdy_conv3x3_c64_try(a, dtype, out_f32, st, &rc)) return rc;      // filter-resident 3x3 kernel when the shape qualifies
+        if (hdy_conv3x3s2_c32_try(a, dtype, out_f32, st, &rc)) return rc;    // patch-resident 3x3 / stride 2 kernel (32 input channels)
     }
     if (dtype == HDY_BF16) return out_f32 ? launch_bn<bf16_t, float>(a, st) : launch_bn<bf16_t, bf16_t>(a, st);
     return launch_bn<float, float>(a, st);

@@ -90,3 +90,5 @@ int hdy_wgrad3x3_try(const void* x, int ldx, const void* dy, int lddy, int N, in
                      int dtype, hipStream_t st, int* splits, int* rc);
 int hdy_conv_igemm_stat_grid(long long M, int K, int taps, int ncls);
 int hdy_dgrad3x3s2_try(const ConvArgs& a, int dtype, hipStream_t st, int* rc);
+int hdy_conv3x3s2_c32_try(const ConvArgs& a, int dtype, int out_f32, hipStream_t st, int* rc);
+int hdy_conv3x3s2_c32_slabs(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dtype);
