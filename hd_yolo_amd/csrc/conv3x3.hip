@@ -101,7 +101,7 @@ template <int C> struct Geo {
 // EPI: 0 = raw convolution out (train-mode forward, dgrad), 1 = scale/shift, 2 = scale/shift + SiLU
 // STATS: accumulate BatchNorm partial sums (one slab per workgroup)
 template <int C, int EPI, bool STATS>
-__global__ __launch_bounds__(NTHR, 2) void conv3x3_c64_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(NTHR, C == 32 ? 3 : 2) void conv3x3_c64_kernel(const ConvArgs p) {      // C = 32: 39 KB of LDS, 36 filter VGPRs: three workgroups per CU
     constexpr int CB = Geo<C>::CB, CPP = Geo<C>::CPP, KS = Geo<C>::KS, PATCH_B = Geo<C>::PATCH_B, NPASS = Geo<C>::NPASS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sP = smem;                    // [2][180][C*2 B]
@@ -405,15 +405,16 @@ static bool conv3x3_shape_ok(int C, int K, int R, int S, int stride, int pad, in
            W % TW == 0;
 }
 
-static int conv3x3_grid(int tiles) {
-    static const int g = getenv("HDY_C3_GRID") ? atoi(getenv("HDY_C3_GRID")) : 512;
-    return tiles < g ? tiles : g;
-}     // two 61 KB, 4-wave workgroups per CU
+static int conv3x3_grid(int tiles, int C) {
+    static const int g = getenv("HDY_C3_GRID") ? atoi(getenv("HDY_C3_GRID")) : 0;
+    const int cap = g ? g : (C == 32 ? 768 : 512);       // two 61 KB (C = 64) or three 39 KB (C = 32) 4-wave workgroups per CU
+    return tiles < cap ? tiles : cap;
+}
 
 // Number of statistic slabs the filter-resident kernel writes for this shape (one per workgroup), 0 = not eligible.
 int hdy_conv3x3_c64_slabs(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dtype) {
     if (!conv3x3_shape_ok(C, K, R, S, stride, pad, H, W, dtype)) return 0;
-    return conv3x3_grid(N * (H / TH) * (W / TW));
+    return conv3x3_grid(N * (H / TH) * (W / TW), C);
 }
 
 // Returns 1 and launches when the shape qualifies; 0 = not eligible (caller falls back to the generic kernel); <0 / >0 = error.
@@ -430,7 +431,7 @@ int hdy_conv3x3_c64_try(const ConvArgs& a, int dtype, int out_f32, hipStream_t s
         *rc = HDY_EINVAL;
         return 1;
     }
-    const int grid = conv3x3_grid(a.N * (a.Ho / TH) * (a.Wo / TW));
+    const int grid = conv3x3_grid(a.N * (a.Ho / TH) * (a.Wo / TW), a.C);
     const int epi = a.act == 1 ? 2 : ((a.scale || a.shift) ? 1 : 0);
     if (a.C == 32) launch_c3_c<32>(a, grid, epi, st);
     else launch_c3_c<64>(a, grid, epi, st);
