@@ -44,6 +44,8 @@
 // waves instead of four (LDS reads -40 %, 18 MFMAs per fragment group instead of 9) at 144 filter VGPRs: dgrad 64<-64 33.0 us as before,
 // 32<-32 51.1 against 56.5 us, but the forward with statistics needs more than 256 registers (56 B of scratch, 55.7 us).  The LDS reads
 // are not what holds the 64-channel kernel back; not adopted.
+// 4-row tiles with three workgroups per CU (36 KB of LDS, 168 VGPRs, no spills): forward 64->64 34.6-35.6 against 32.5-33 us, data gradient
+// unchanged, 32->32 71 against 60 us — a third wave per SIMD does not pay for the halved MFMA work per item; not adopted.
 // Ablation: without the patch fetch 35.1, without the output stores 34.8, without both 32.9 us — the kernel is not memory bound;
 // the MFMA pipe is busy ~45 % of the cycles (1.7 GHz under this load), the rest is per-item work that two waves per SIMD do
 // not overlap completely (patch issue ~2.0k cycles, statistics + staging ~0.6k, row stores ~0.5k, barriers ~0.4k per 8-row item).
