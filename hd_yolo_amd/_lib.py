@@ -22,6 +22,11 @@ _P, _I, _L, _F, _Z = c_void_p, c_int, c_longlong, c_float, c_size_t
 # name -> (restype, argtypes); must list every symbol include/hdyolo.h declares (tests check this)
 SIGNATURES = {
     'hdy_last_error': (c_char_p, []),
+    'hdy_last_dispatch': (c_char_p, []),
+    'hdy_dispatch_log': (c_char_p, []),
+    'hdy_dispatch_log_reset': (None, []),
+    'hdy_set_option': (_I, [c_char_p, _I]),
+    'hdy_get_option': (_I, [c_char_p]),
     'hdy_conv_wgrad_stem_fused_ok': (_I, [_I, _I, _I, _I]),
     'hdy_conv_wgrad_stem_fused': (_I, [_P, _P, _I, _P, _I] + [_P] * 6 + [_I, _I, _I, _I, _P, _I, _P, _I, _I, _P, _Z, _P]),
     'hdy_bn_slab_sums': (_I, [_P, _I, _I, _I, _L, _P, _P]),
@@ -152,3 +157,31 @@ def call(name, *args):
 
 def query(name, *args):
     return getattr(load(), name)(*args)
+
+
+# ---- kernel selection: switches and the dispatch log (include/hdyolo.h) -----------------------------------------------------------
+class option:
+    """`with _lib.option('HDY_NO_CONV3X3', 1): ...` — a process-wide switch for the duration of the block (set it BEFORE sizing buffers or
+    building plans: the switches also steer the slab / workspace queries)."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name.encode(), int(value)
+
+    def __enter__(self):
+        self.prev = load().hdy_set_option(self.name, self.value)
+        if self.prev < 0 and load().hdy_get_option(self.name) != self.value:
+            raise HdyError(f'unknown option {self.name.decode()}')
+        return self
+
+    def __exit__(self, *exc):
+        load().hdy_set_option(self.name, self.prev)
+        return False
+
+
+def dispatch_log(reset=False):
+    """kernel families picked on this thread since the last reset, in launch order"""
+    lib = load()
+    names = [n for n in lib.hdy_dispatch_log().decode().split(';') if n]
+    if reset:
+        lib.hdy_dispatch_log_reset()
+    return names

@@ -1,9 +1,13 @@
 // C-ABI entry points for the convolution family (see include/hdyolo.h).  Everything here is host code that
 // validates shapes, derives the tap-window geometry and launches the kernels in conv_igemm.hip / conv_wgrad.hip
-// on the caller's stream.  No allocation, no synchronisation, no global state besides the thread-local error text.
+// on the caller's stream.  No allocation, no synchronisation; process state = the option table below (atomics, initialised once from the
+// environment), the per-kernel "LDS size attribute set" once-flags, and the thread-local error text / dispatch log.
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
+
+#include <atomic>
 
 #include "common.h"
 #include "hdyolo_internal.h"
@@ -21,6 +25,50 @@ void hdy_set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+namespace {
+struct OptDef { const char* name; int def; bool flag; };       // flag: the variable's presence means 1 (its value is not parsed)
+const OptDef g_opt_def[HDY_OPT_COUNT] = {
+    {"HDY_NO_CLASS_WALK", 0, true}, {"HDY_NO_CONV3X3", 0, true}, {"HDY_C3_GRID", 0, false}, {"HDY_NO_CONV3X3S2", 0, true},
+    {"HDY_NO_DGRAD_S2", 0, true}, {"HDY_TILE_INTERLEAVE", 1, false}, {"HDY_NO_BIG_TILES", 0, true}, {"HDY_NO_STEM_KERNEL", 0, true},
+    {"HDY_WGRAD_BLOCKS", 512, false}, {"HDY_NO_STEM_WGRAD", 0, true}, {"HDY_NO_WGRAD3X3", 0, true}, {"HDY_WGRAD3X3_S2", 0, true},
+    {"HDY_LOSS_GRID", 2048, false}, {"HDY_NO_DEEP", 0, true}, {"HDY_NO_WGRAD_S2", 0, true},
+};
+std::atomic<int> g_opt[HDY_OPT_COUNT];
+std::once_flag g_opt_once;
+void opt_init() {
+    std::call_once(g_opt_once, [] {
+        for (int i = 0; i < HDY_OPT_COUNT; ++i) {
+            const char* v = getenv(g_opt_def[i].name);
+            g_opt[i].store(v ? (g_opt_def[i].flag ? 1 : atoi(v)) : g_opt_def[i].def, std::memory_order_relaxed);
+        }
+    });
+}
+int opt_index(const char* name) {
+    for (int i = 0; name && i < HDY_OPT_COUNT; ++i)
+        if (!strcmp(name, g_opt_def[i].name)) return i;
+    return -1;
+}
+thread_local char g_disp_last[64] = "";
+thread_local char g_disp_log[2048] = "";
+thread_local size_t g_disp_len = 0;
+}  // namespace
+
+int hdy_opt(int id) {
+    opt_init();
+    return g_opt[id].load(std::memory_order_relaxed);
+}
+
+void hdy_note_dispatch(const char* what) {
+    snprintf(g_disp_last, sizeof(g_disp_last), "%s", what);
+    const size_t n = strlen(g_disp_last);
+    if (g_disp_len + n + 2 < sizeof(g_disp_log)) {
+        memcpy(g_disp_log + g_disp_len, g_disp_last, n);
+        g_disp_log[g_disp_len + n] = ';';
+        g_disp_log[g_disp_len + n + 1] = 0;
+        g_disp_len += n + 1;
+    }
 }
 
 namespace {
@@ -55,6 +103,32 @@ inline size_t block_elems(int rows, int kd, int dtype) {
 extern "C" {
 
 const char* hdy_last_error(void) { return g_err; }
+
+// name of the kernel family the last launcher call on this thread picked ("" before the first)
+const char* hdy_last_dispatch(void) { return g_disp_last; }
+
+// every pick since the last hdy_dispatch_log_reset() on this thread, ';'-separated (first 2 KB)
+const char* hdy_dispatch_log(void) { return g_disp_log; }
+
+void hdy_dispatch_log_reset(void) {
+    g_disp_log[0] = 0;
+    g_disp_len = 0;
+    g_disp_last[0] = 0;
+}
+
+// process-wide switch by the name of its environment variable (common.h HdyOption); returns the previous value, HDY_EINVAL for an unknown name
+int hdy_set_option(const char* name, int value) {
+    const int i = opt_index(name);
+    HDY_ARG(i >= 0, "set_option: unknown option %s", name ? name : "(null)");
+    opt_init();
+    return g_opt[i].exchange(value, std::memory_order_relaxed);
+}
+
+int hdy_get_option(const char* name) {
+    const int i = opt_index(name);
+    HDY_ARG(i >= 0, "get_option: unknown option %s", name ? name : "(null)");
+    return hdy_opt(i);
+}
 
 int hdy_version(void) { return 1; }
 
@@ -215,7 +289,7 @@ int hdy_conv_dgrad_stats(const void* dy, int lddy, const void* w_packed_dgrad, v
 int hdy_conv_dgrad_stat_slabs(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dtype) {
     if (dtype != HDY_BF16 || C % 8 || (stride != 1 && stride != 2)) return 0;
     if (stride == 1) return hdy_conv_igemm_stat_grid((long long)N * H * W, C, R * S, 1);
-    if (H % 2 || W % 2 || getenv("HDY_NO_CLASS_WALK")) return 0;
+    if (H % 2 || W % 2 || hdy_opt(HDY_OPT_NO_CLASS_WALK)) return 0;
     for (int a = 0; a < 2; ++a)
         if (!class_axis(R, pad, a).taps || !class_axis(S, pad, a).taps) return 0;
     return hdy_conv_igemm_stat_grid((long long)N * (H / 2) * (W / 2), C, 1, 4);
@@ -246,7 +320,7 @@ static int dgrad_impl(const void* dy, int lddy, const void* w_packed_dgrad, void
     // One launch walking the four parity classes per spatial tile (conv_igemm.hip, `walk`): every class has the same Ho x Wo when H and W
     // are even.  As four launches each class wrote every other pixel of every other row (half cache lines, each line written by two
     // launches) and read dy from HBM again: 32<-64 @320x320 B=64 took 353 us against a 100 us bound.
-    static const bool no_walk = getenv("HDY_NO_CLASS_WALK") != nullptr;
+    const bool no_walk = hdy_opt(HDY_OPT_NO_CLASS_WALK) != 0;
     if (H % 2 == 0 && W % 2 == 0 && !no_walk) {
         ConvArgs c = a;
         c.ncls = 4;

@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stddef.h>
 
+#include <mutex>
+
 #define HDY_OK 0
 #define HDY_EINVAL (-1)
 #define HDY_EUNSUPPORTED (-2)
@@ -12,6 +14,32 @@ enum { HDY_F32 = 0, HDY_BF16 = 1 };
 
 // thread-local error text, returned by hdy_last_error()
 void hdy_set_error(const char* fmt, ...);
+
+// Process-wide switches (tests, A/B measurements): kernel selection and launch geometry knobs.  Each has an environment variable that
+// sets its initial value (read once, under std::call_once) and can be changed at run time through hdy_set_option(); values are atomics.
+// Switches also steer the sizing queries (statistic slabs, workspaces), so change them BEFORE building a plan, never under a live one.
+enum HdyOption {
+    HDY_OPT_NO_CLASS_WALK,     // HDY_NO_CLASS_WALK: stride-2 dgrad as four launches instead of one class-walking launch
+    HDY_OPT_NO_CONV3X3,        // HDY_NO_CONV3X3: filter-resident 3x3 kernel off (generic implicit GEMM instead)
+    HDY_OPT_C3_GRID,           // HDY_C3_GRID: workgroups of the filter-resident 3x3 kernel (0 = default)
+    HDY_OPT_NO_CONV3X3S2,      // HDY_NO_CONV3X3S2: patch-resident 3x3 / stride-2 forward off
+    HDY_OPT_NO_DGRAD_S2,       // HDY_NO_DGRAD_S2: patch-resident stride-2 data gradient off
+    HDY_OPT_TILE_INTERLEAVE,   // HDY_TILE_INTERLEAVE: tile order of the generic kernel (bit 0: column tiles, bit 1: parity classes)
+    HDY_OPT_NO_BIG_TILES,      // HDY_NO_BIG_TILES: never the 256-row tile of the generic kernel
+    HDY_OPT_NO_STEM_KERNEL,    // HDY_NO_STEM_KERNEL: patch-resident stem forward off
+    HDY_OPT_WGRAD_BLOCKS,      // HDY_WGRAD_BLOCKS: workgroups of the generic weight-gradient kernel (default 512)
+    HDY_OPT_NO_STEM_WGRAD,     // HDY_NO_STEM_WGRAD: patch-resident stem weight gradient off
+    HDY_OPT_NO_WGRAD3X3,       // HDY_NO_WGRAD3X3: patch-resident 3x3 weight gradient off
+    HDY_OPT_WGRAD3X3_S2,       // HDY_WGRAD3X3_S2: patch-resident 3x3 weight gradient also at stride 2 (measured: no gain)
+    HDY_OPT_LOSS_GRID,         // HDY_LOSS_GRID: workgroups of the detection loss' dense pass (default 2048)
+    HDY_OPT_NO_DEEP,           // HDY_NO_DEEP: deep-pipelined 256-row implicit GEMM off (generic kernel instead)
+    HDY_OPT_NO_WGRAD_S2,       // HDY_NO_WGRAD_S2: tap-walking stride-2 3x3 weight gradient off
+    HDY_OPT_COUNT
+};
+int hdy_opt(int id);
+
+// thread-local dispatch log: every host-side launcher names the kernel family it picked (hdy_last_dispatch / hdy_dispatch_log)
+void hdy_note_dispatch(const char* what);
 
 #define HDY_ARG(cond, ...)                 \
     do {                                   \

@@ -376,11 +376,11 @@ template <int KT, int CT, int BM, int NXB>
 int fused_launch(const FusedArgs& a, int grid, hipStream_t st) {
     constexpr size_t smem = fused_smem<KT, CT, BM, NXB>();
     static_assert(2 * smem <= 160 * 1024, "two workgroups per CU");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_once;           // first launch of this instance on any thread
+    std::call_once(attr_once, [&] {
         (void)hipFuncSetAttribute((const void*)conv1x1_bwd_kernel<KT, CT, BM, NXB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_set = true;
-    }
+    });
+    hdy_note_dispatch(KT == 32 ? "conv1x1_bwd_32" : (KT == 64 ? "conv1x1_bwd_64" : "conv1x1_bwd_128"));
     hipLaunchKernelGGL((conv1x1_bwd_kernel<KT, CT, BM, NXB>), dim3(grid), dim3(256), smem, st, a);
     HDY_LAUNCH_CHECK("conv1x1_bwd");
     return HDY_OK;

@@ -376,11 +376,11 @@ __global__ __launch_bounds__(NTHR, C == 32 ? 3 : 2) void conv3x3_c64_kernel(cons
 
 template <int C, int EPI, bool STATS>
 static void launch_c3(const ConvArgs& a, int grid, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_once;           // first launch of this instance on any thread
+    std::call_once(attr_once, [&] {
         (void)hipFuncSetAttribute((const void*)conv3x3_c64_kernel<C, EPI, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<C>::SMEM_B);
-        attr_set = true;
-    }
+    });
+    hdy_note_dispatch(C == 64 ? "conv3x3_c64" : "conv3x3_c32");
     hipLaunchKernelGGL((conv3x3_c64_kernel<C, EPI, STATS>), dim3(grid), dim3(NTHR), Geo<C>::SMEM_B, st, a);
 }
 
@@ -402,13 +402,13 @@ static void launch_c3_c(const ConvArgs& a, int grid, int epi, hipStream_t st) {
 
 // Shape test shared by the launcher and the statistics-slab query (the two must agree on who writes the slabs).
 static bool conv3x3_shape_ok(int C, int K, int R, int S, int stride, int pad, int H, int W, int dtype) {
-    static const bool disabled = getenv("HDY_NO_CONV3X3") != nullptr;      // tests: force the generic kernel for A/B comparison
+    const bool disabled = hdy_opt(HDY_OPT_NO_CONV3X3) != 0;      // tests: force the generic kernel for A/B comparison
     return !disabled && dtype == HDY_BF16 && R == 3 && S == 3 && stride == 1 && pad == 1 && (C == 64 || C == 32) && K <= 64 && K % 8 == 0 && H % TH == 0 &&
            W % TW == 0;
 }
 
 static int conv3x3_grid(int tiles, int C) {
-    static const int g = getenv("HDY_C3_GRID") ? atoi(getenv("HDY_C3_GRID")) : 0;
+    const int g = hdy_opt(HDY_OPT_C3_GRID);
     const int cap = g ? g : (C == 32 ? 768 : 512);       // two 61 KB (C = 64) or three 39 KB (C = 32) 4-wave workgroups per CU
     return tiles < cap ? tiles : cap;
 }

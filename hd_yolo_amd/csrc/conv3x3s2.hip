@@ -229,18 +229,18 @@ __global__ __launch_bounds__(NTHR, 3) void conv3x3s2_c32_kernel(const ConvArgs p
 
 template <int EPI, bool STATS>
 static void launch_s2(const ConvArgs& a, int grid, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_once;           // first launch of this instance on any thread
+    std::call_once(attr_once, [&] {
         (void)hipFuncSetAttribute((const void*)conv3x3s2_c32_kernel<EPI, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B);
-        attr_set = true;
-    }
+    });
+    hdy_note_dispatch("conv3x3s2_c32");
     hipLaunchKernelGGL((conv3x3s2_c32_kernel<EPI, STATS>), dim3(grid), dim3(NTHR), SMEM_B, st, a);
 }
 
 }  // namespace
 
 static bool conv3x3s2_shape_ok(int Cin, int K, int R, int S, int stride, int pad, int H, int W, int dtype) {
-    static const bool disabled = getenv("HDY_NO_CONV3X3S2") != nullptr;     // tests: force the generic kernel for A/B comparison
+    const bool disabled = hdy_opt(HDY_OPT_NO_CONV3X3S2) != 0;     // tests: force the generic kernel for A/B comparison
     return !disabled && dtype == HDY_BF16 && R == 3 && S == 3 && stride == 2 && pad == 1 && Cin == C && K <= 64 && K % 8 == 0 && H % 2 == 0 && W % 2 == 0 &&
            (H / 2) % TH == 0 && (W / 2) % TW == 0;
 }

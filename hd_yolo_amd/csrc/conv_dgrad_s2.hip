@@ -182,7 +182,7 @@ __global__ __launch_bounds__(NTHR, 2) void dgrad3x3s2_k64c32_kernel(const ConvAr
 
 // Returns 1 and launches when the class-walk arguments describe this layer; 0 = not eligible (the generic kernel runs).
 int hdy_dgrad3x3s2_try(const ConvArgs& a, int dtype, hipStream_t st, int* rc) {
-    static const bool disabled = getenv("HDY_NO_DGRAD_S2") != nullptr;        // tests: force the class walk for A/B comparison
+    const bool disabled = hdy_opt(HDY_OPT_NO_DGRAD_S2) != 0;        // tests: force the class walk for A/B comparison
     if (disabled || dtype != HDY_BF16 || a.ncls != 4 || a.nstat != 0 || a.res || a.scale || a.shift || a.act != 0 || a.stats) return 0;
     if (a.C != 64 || a.K != 32 || a.Ho % TH || a.Wo % TW || a.Hin != a.Ho || a.Win != a.Wo || a.Hout != 2 * a.Ho || a.Wout != 2 * a.Wo) return 0;
     static const int dh[4] = {0, 0, 0, 0}, dw[4] = {0, 0, 0, 0}, nth[4] = {1, 1, 2, 2}, ntw[4] = {1, 2, 1, 2}, oh[4] = {0, 0, 1, 1}, ow[4] = {0, 1, 0, 1};
@@ -192,12 +192,12 @@ int hdy_dgrad3x3s2_try(const ConvArgs& a, int dtype, hipStream_t st, int* rc) {
             return 0;
     if (a.ldx % 8 || a.ldy % 8 || ((uintptr_t)a.x & 15) || ((uintptr_t)a.y & 15) || ((uintptr_t)a.w & 15)) return 0;
     const int tiles = a.N * (a.Ho / TH) * (a.Wo / TW);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_once;           // first launch of this instance on any thread
+    std::call_once(attr_once, [&] {
         (void)hipFuncSetAttribute((const void*)dgrad3x3s2_k64c32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B);
-        attr_set = true;
-    }
+    });
     const int grid = tiles < 512 ? tiles : 512;        // two 70 KB, 4-wave workgroups per CU
+    hdy_note_dispatch("dgrad3x3s2_k64c32");
     hipLaunchKernelGGL(dgrad3x3s2_k64c32_kernel, dim3(grid), dim3(NTHR), SMEM_B, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -32,6 +32,7 @@
 //
 // Reference semantics replaced: nn.Conv2d inside metayolo/models/layers.py:31 (Conv), :92-93 (Bottleneck),
 // :124-126 (C3), :179-180 (SPPF), yolo_head.py:112 (det conv), and autograd's conv backward-data.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <type_traits>
@@ -691,8 +692,7 @@ __global__ __launch_bounds__(2 * BM, (BM == 256 || BN == 128 || STAT) ? 2 : (BN 
 }
 
 inline int igemm_interleave_mode() {      // bit 0: column tiles of one m-tile on neighbouring workgroups, bit 1: parity classes of the stride-2 dgrad too
-    static const int mode = getenv("HDY_TILE_INTERLEAVE") ? atoi(getenv("HDY_TILE_INTERLEAVE")) : 1;
-    return mode;
+    return hdy_opt(HDY_OPT_TILE_INTERLEAVE);
 }
 
 // Persistent grid of a tile configuration: as many workgroups as stay resident (LDS-limited), never more than tiles.
@@ -710,19 +710,23 @@ inline int igemm_grid(long long M, int ntiles, int BM, int BN, int NS) {
 // every 3x3 layer of yolov5s at B=64 (400-1600) 4-13 % against it; the yolov5s train step 14.93 -> 14.80 ms and the yolov5l
 // inference network 64.2 -> 63.3 ms with the threshold at 4096.  The single-tap layers prefer many small workgroups in flight.
 inline bool igemm_big(long long M, int bn, int ntiles, int taps) {
-    static const bool no_big = getenv("HDY_NO_BIG_TILES") != nullptr;
+    const bool no_big = hdy_opt(HDY_OPT_NO_BIG_TILES) != 0;
     return bn == 128 && taps > 1 && (M + 255) / 256 * ntiles >= 4096 && !no_big;
 }
 
 template <typename T, typename OT, int BM, int BN, int NS, bool STAT = false>
 int launch(const ConvArgs& a, hipStream_t st) {
     const size_t smem = (size_t)NS * (BM * 128 + BN * 128) + (BN > 32 ? 2 * BN * sizeof(float) : 0);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_once;           // first launch of this instance on any thread
+    std::call_once(attr_once, [&] {
         (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, OT, BM, BN, NS, STAT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_set = true;
-    }
+    });
     const int grid = igemm_grid(a.M, a.ntiles * (a.ncls > 1 ? 4 : 1), BM, BN, NS);
+    {
+        char what[48];
+        snprintf(what, sizeof(what), "igemm_%dx%dx%d%s%s", BM, BN, NS, a.ncls > 1 ? "_walk" : "", STAT ? "_stat" : "");
+        hdy_note_dispatch(what);
+    }
     hipLaunchKernelGGL((conv_igemm_kernel<T, OT, BM, BN, NS, STAT>), dim3(grid), dim3(2 * BM), smem, st, a);
     HDY_LAUNCH_CHECK("conv_igemm");
     return HDY_OK;

@@ -219,13 +219,13 @@ template <int NT>
 int launch_nt(const ConvArgs& a, int grid, hipStream_t st) {
     const size_t smem = 2 * PATCH_B + (size_t)TOH * TOW * NT * 32 + (size_t)NT * 16 * 400;
     const int epi = a.act == 1 ? 2 : ((a.scale || a.shift) ? 1 : 0);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_once;           // first launch of this instance on any thread
+    std::call_once(attr_once, [&] {
         (void)hipFuncSetAttribute((const void*)conv_stem_kernel<NT, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         (void)hipFuncSetAttribute((const void*)conv_stem_kernel<NT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         (void)hipFuncSetAttribute((const void*)conv_stem_kernel<NT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_set = true;
-    }
+    });
+    hdy_note_dispatch("conv_stem");
     if (epi == 2) hipLaunchKernelGGL((conv_stem_kernel<NT, 2>), dim3(grid), dim3(NTHR), smem, st, a);
     else if (epi == 1) hipLaunchKernelGGL((conv_stem_kernel<NT, 1>), dim3(grid), dim3(NTHR), smem, st, a);
     else hipLaunchKernelGGL((conv_stem_kernel<NT, 0>), dim3(grid), dim3(NTHR), smem, st, a);
@@ -235,7 +235,7 @@ int launch_nt(const ConvArgs& a, int grid, hipStream_t st) {
 }  // namespace
 
 static bool stem_shape_ok(int K, int Ho, int Wo, int dtype) {
-    static const bool disabled = getenv("HDY_NO_STEM_KERNEL") != nullptr;   // tests: force the generic kernel for A/B comparison
+    const bool disabled = hdy_opt(HDY_OPT_NO_STEM_KERNEL) != 0;   // tests: force the generic kernel for A/B comparison
     return !disabled && dtype == HDY_BF16 && K % 16 == 0 && K >= 16 && K <= 64 && Ho % TOH == 0 && Wo % TOW == 0;
 }
 

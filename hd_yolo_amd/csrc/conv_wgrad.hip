@@ -565,7 +565,7 @@ int hdy_wgrad_plan(int K, int Q, long long P, int dtype, int* splits, int* pix_p
     int sd, sx;
     wgrad_tile(K, Q, dtype, &sd, &sx);
     const int tiles = cdiv(K, TK * sd) * cdiv(Q, TK * sx);
-    static const int target = getenv("HDY_WGRAD_BLOCKS") ? atoi(getenv("HDY_WGRAD_BLOCKS")) : 512;     // = resident workgroups (2 per CU): one wave of blocks, half the slab traffic of 1024
+    const int target = hdy_opt(HDY_OPT_WGRAD_BLOCKS);     // = resident workgroups (2 per CU): one wave of blocks, half the slab traffic of 1024
     int s = cdiv(target, tiles);
     if (s > 512) s = 512;
     const int maxs = cdiv(P, 256);
@@ -580,6 +580,7 @@ int hdy_wgrad_plan(int K, int Q, long long P, int dtype, int* splits, int* pix_p
 
 template <typename T>
 static void wgrad_dispatch(const WgradArgs& a, int sd, int sx, int grid, hipStream_t st) {
+    hdy_note_dispatch("wgrad_generic");
     if (sd == 2 && sx == 2) hipLaunchKernelGGL((wgrad_kernel<T, 2, 2>), dim3(grid), dim3(256), 0, st, a);
     else if (sd == 2) hipLaunchKernelGGL((wgrad_kernel<T, 2, 1>), dim3(grid), dim3(256), 0, st, a);
     else if (sx == 2) hipLaunchKernelGGL((wgrad_kernel<T, 1, 2>), dim3(grid), dim3(256), 0, st, a);
@@ -609,7 +610,7 @@ int hdy_wgrad_launch(WgradArgs a, int dtype, hipStream_t st) {
 
 // Workgroups (= fp32 slabs) of the patch-resident stem weight gradient, 0 = shape not eligible (generic kernel).
 int hdy_wgrad_stem_grid(int N, int Ho, int Wo, int K, int dtype) {
-    static const bool disabled = getenv("HDY_NO_STEM_WGRAD") != nullptr;
+    const bool disabled = hdy_opt(HDY_OPT_NO_STEM_WGRAD) != 0;
     if (disabled || dtype != HDY_BF16 || K % 16 != 0 || K > 64 || Ho % stemw::TOH != 0 || Wo % stemw::TOW != 0) return 0;
     const long long tiles = (long long)N * (Ho / stemw::TOH) * (Wo / stemw::TOW);
     const int cap = K <= 32 ? 768 : 256;                 // 52 KB of LDS per workgroup at K = 32: three per CU
@@ -620,6 +621,7 @@ int hdy_wgrad_stem_launch(const WgradArgs& a, int grid, hipStream_t st) {
     HDY_ARG(((uintptr_t)a.x & 15) == 0 && ((uintptr_t)a.dy & 15) == 0 && a.lddy % 8 == 0 && a.Win % 2 == 0, "wgrad(stem): x/dy alignment");
     const size_t smem = stemw::PATCH_B + 64 + (size_t)stemw::TOH * stemw::TOW * a.K * 2;
     const int mt = a.K / 16;
+    hdy_note_dispatch(a.y ? "wgrad_stem_fused" : "wgrad_stem");
 #define STEMW_LAUNCH(MT, FU)                                                                                                         \
     {                                                                                                                              \
         (void)hipFuncSetAttribute((const void*)stemw::wgrad_stem_kernel<MT, FU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \

@@ -233,11 +233,11 @@ struct W3Plan { int KB, CB, TOH, TOW, tiles_h, tiles_w, nkb, ncb, nsplit; };
 // tile shape (output pixels).  stride 1: whole image rows when they are short (W <= 40), 16x16 blocks when W divides by 16, else 8x32;
 // stride 2 (the patch is (2*TOH+1) x (2*TOW+1) input pixels): 8x8 blocks, or whole / half rows of narrow maps
 bool w3_plan(int N, int Ho, int Wo, int C, int K, int stride, W3Plan* pl) {
-    static const bool off = getenv("HDY_NO_WGRAD3X3") != nullptr;
+    const bool off = hdy_opt(HDY_OPT_NO_WGRAD3X3) != 0;
     // Stride 2 is implemented and tested (HDY_WGRAD3X3_S2=1) but not the default: its patch is 4x the output tile, so a tile is 45 KB of
     // LDS-DMA for two MFMA steps and the kernel is load bound — measured against the generic kernel on yolov5s B=64: 101 vs 100,
     // 86 vs 75, 177 vs 180, 166 vs 172, 166 vs 152, 238 vs 233 us.  Stride 1: 57 vs 82, 57 vs 75, 67 vs 95, 84 vs 168 us.
-    static const bool s2 = getenv("HDY_WGRAD3X3_S2") != nullptr;
+    const bool s2 = hdy_opt(HDY_OPT_WGRAD3X3_S2) != 0;
     if (off || C % 32 || K % 32 || (stride != 1 && !(stride == 2 && s2))) return false;
     pl->KB = K % 64 == 0 ? 64 : 32;
     pl->CB = C % 64 == 0 ? 64 : 32;
@@ -300,14 +300,14 @@ int hdy_wgrad3x3_try(const void* x, int ldx, const void* dy, int lddy, int N, in
     a.nkb = pl.nkb; a.ncb = pl.ncb; a.nsplit = pl.nsplit;
     const int grid = pl.nkb * pl.ncb * pl.nsplit;
     constexpr int smem = 2 * W3_BUF;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_once;           // first launch of this instance on any thread
+    std::call_once(attr_once, [&] {
         (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<64, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<64, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<32, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<32, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr_set = true;
-    }
+    });
+    hdy_note_dispatch("wgrad3x3");
     if (pl.KB == 64 && pl.CB == 64) hipLaunchKernelGGL((wgrad3x3_kernel<64, 64>), dim3(grid), dim3(768), smem, st, a);
     else if (pl.KB == 64) hipLaunchKernelGGL((wgrad3x3_kernel<64, 32>), dim3(grid), dim3(768), smem, st, a);
     else if (pl.CB == 64) hipLaunchKernelGGL((wgrad3x3_kernel<32, 64>), dim3(grid), dim3(768), smem, st, a);

@@ -428,7 +428,7 @@ int hdy_det_loss(const float* const* logits, int ldl, void* const* gdet, int ldg
     // the largest level sets grid.x, the others stride less.  Every workgroup ends with one fp64 atomic and atomics on one address
     // serialise (~50-100 ns each): with one sum per level, 4096 workgroups made that tail longer than the pass itself (140 us; 71 us
     // with 1024 workgroups) — hence the OSL slots per level
-    static const int dense_grid = getenv("HDY_LOSS_GRID") ? atoi(getenv("HDY_LOSS_GRID")) : 2048;
+    const int dense_grid = hdy_opt(HDY_OPT_LOSS_GRID);
     const int grid = (int)((most + 255) / 256 < dense_grid ? (most + 255) / 256 : dense_grid);
     if (dtype == HDY_BF16) hipLaunchKernelGGL(dense_kernel<bf16_t>, dim3(grid, nl), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(dense_kernel<float>, dim3(grid, nl), dim3(256), 0, st, a);

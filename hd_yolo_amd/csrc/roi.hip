@@ -272,12 +272,11 @@ int hdy_roi_align_bwd(const void* dout, float* dfeat_f32, int B, int H, int W, i
     const dim3 grid(R, (C + CB - 1) / CB);
     const int pp = P <= PM ? P : 1;
     const size_t smem = (size_t)(2 * PM * FT + PM * PM * CB + pp * FT * CB) * sizeof(float);        // Wy, Wx, D, Tm: 70 KB at P = 14
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_once;           // first launch of this instance on any thread
+    std::call_once(attr_once, [&] {
         (void)hipFuncSetAttribute((const void*)roi_align_bwd_tiled_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * PM * FT + PM * PM * CB + PM * FT * CB) * 4);
         (void)hipFuncSetAttribute((const void*)roi_align_bwd_tiled_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * PM * FT + PM * PM * CB + PM * FT * CB) * 4);
-        attr_set = true;
-    }
+    });
     if (dtype == HDY_BF16)
         hipLaunchKernelGGL(roi_align_bwd_tiled_kernel<bf16_t>, grid, dim3(256), smem, (hipStream_t)stream, dfeat_f32, B, H, W, C, rois, spatial_scale, P,
                            sampling_ratio, aligned, (const bf16_t*)dout);

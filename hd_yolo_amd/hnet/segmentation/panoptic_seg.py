@@ -116,6 +116,12 @@ class PanopticSeg(torch.nn.Module):
                     if 'roi' in a and [float(v) for v in a['roi']] != [0.0, 0.0, float(W), float(H)]:
                         raise _lib.HdyError('PanopticSeg on this path takes whole-tile rois only (roi == [0, 0, W, H])')
             masks = torch.stack([a['masks'] for a in anns]).float().contiguous()
+            if tuple(masks.shape[-2:]) != out_size:
+                # reference (panoptic_seg.py:13-19, :37-39): Upsample(scale_factor) -> conv -> Softmax2d, THEN the probabilities are
+                # interpolated to the mask size.  This path resizes the logits once and applies the softmax last, which is the same
+                # function only when feature size x scale_factor == mask size (softmax and interpolation do not commute).
+                raise _lib.HdyError(f'PanopticSeg: masks of {tuple(masks.shape[-2:])} do not match feature size x scale_factor = {out_size}; '
+                                    'the HIP path covers the case where they agree (set scale_factor accordingly)')
             if torch.is_grad_enabled() and self.training:
                 loss = _SegFn.apply(self, run, grad_of or self._param_grad, masks, *feats)
             else:

@@ -72,4 +72,7 @@ class SGD(torch.optim.Optimizer):
                               n, int(nesterov.pop()), torch.cuda.current_stream(dev).cuda_stream)
         if rc:
             raise _lib.HdyError(f'hdy_sgd_step failed (status {rc}): {lib.hdy_last_error().decode()}')
+        # the kernel wrote the parameters through raw pointers: tell autograd / every `_version`-keyed cache (segrun.PackCache, ops.PackTable,
+        # ops.BnEvalTable) that they changed, as an in-place torch update would have
+        torch._C._increment_version([p for p, _, _, _, _ in rows] + [buf for _, _, buf, _, _ in rows if buf is not None])
         return loss

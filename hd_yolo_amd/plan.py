@@ -519,6 +519,13 @@ class Plan:
     def bn_counters(self):
         return [m.bn.num_batches_tracked for u in self.units if isinstance(u, ConvUnit) and u.has_bn and not u.frozen for m in u.mods]
 
+    def bn_running(self):
+        """running_mean / running_var of every live BatchNorm: the training forward writes them through raw pointers"""
+        if getattr(self, '_bn_running', None) is None:
+            self._bn_running = [t for u in self.units if isinstance(u, ConvUnit) and u.has_bn and not u.frozen for m in u.mods
+                                for t in (m.bn.running_mean, m.bn.running_var)]
+        return self._bn_running
+
     def run_forward_features(self, feats):
         """Feature-input plan: feats {layer index: NCHW tensor} -> det logits views (empty without a head)."""
         for k, v in self.ext.items():
@@ -546,6 +553,9 @@ class Plan:
         self._replay('fwd', self.fwd)
         if self.training:
             torch._foreach_add_(self.bn_counters(), 1)
+            # the kernels updated the running statistics in place: move their version counters as torch's own BatchNorm would, so that
+            # `_version`-keyed caches (ops.BnEvalTable of an eval plan on the same live model) see the change
+            torch._C._increment_version(self.bn_running())
         return self.det_views()
 
     def det_views(self):

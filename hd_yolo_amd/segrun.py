@@ -22,16 +22,24 @@ class PackCache:
     def __init__(self):
         self.slots = {}
 
+    def _drop(self, wid):
+        for key in [k for k in self.slots if k[0] == wid]:
+            del self.slots[key]
+
     def get(self, weight, stride, pad, kind, dtype, K=None):
         key = (id(weight), kind, dtype, K)
         tag = (weight._version, weight.data_ptr())
         hit = self.slots.get(key)
-        if hit is not None and hit[0] == tag:
+        # a slot belongs to ONE live parameter object: the weak reference both frees the packed buffer when the parameter dies and keeps a
+        # new parameter that happens to reuse the id (and storage address, and version 0) from inheriting another model's packing
+        if hit is not None and hit[0] == tag and hit[2]() is weight:
             return hit[1]
         Kw, C, R, S = weight.shape
         wp = ops.pack_alloc(Kw if K is None else K, C, R, S, stride, pad, kind, dtype, weight.device)
         ops.run([ops.rec_pack(weight.detach().float().contiguous(), None, stride, pad, kind, wp, K=K)])
-        self.slots[key] = (tag, wp)
+        import weakref
+        wid = id(weight)
+        self.slots[key] = (tag, wp, weakref.ref(weight, lambda _r, wid=wid: self._drop(wid)))
         return wp
 
 

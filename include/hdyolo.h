@@ -10,7 +10,9 @@
  *    The library allocates nothing, keeps no pointers after a call returns and never synchronises.
  *  - All work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the null stream).
  *  - Return value: 0 = ok; < 0 = invalid argument / unsupported shape; > 0 = a hipError_t from the launch.
- *    hdy_last_error() returns a thread-local description of the last failure.  Re-entrant, no global state.
+ *    hdy_last_error() returns a thread-local description of the last failure.  Re-entrant.  Process state is limited to: the
+ *    option table (atomics, initialised once from the environment under std::call_once, changed by hdy_set_option), per-kernel
+ *    once-flags for the "dynamic LDS size" function attribute, and the thread-local error text / dispatch log.
  *  - Activations are NHWC ("channels last") with an explicit pixel pitch `ld*` in ELEMENTS, so a tensor may be
  *    a channel slice of a wider buffer (this is how torch.cat along C costs nothing).  Framework weights stay
  *    in the reference layout [K][C][R][S] fp32 and are re-packed by hdy_conv_pack.
@@ -42,6 +44,18 @@ extern "C" {
 
 const char* hdy_last_error(void);
 int hdy_version(void);
+/* Which kernel ran: every launcher names the kernel family it picked ("igemm_128x128x2", "conv3x3_c64", "deep_256x128", "wgrad3x3", ...).
+ * hdy_last_dispatch: the last pick on this thread; hdy_dispatch_log: every pick since hdy_dispatch_log_reset(), ';'-separated (thread-local,
+ * first 2 KB).  The reference has no counterpart (ATen picks its kernels silently); the tests use it to assert that the shapes meant to hit
+ * a specialised kernel do. */
+const char* hdy_last_dispatch(void);
+const char* hdy_dispatch_log(void);
+void hdy_dispatch_log_reset(void);
+/* Process-wide kernel-selection switches by the name of their environment variable (HDY_NO_CONV3X3, HDY_NO_DEEP, HDY_WGRAD_BLOCKS, ...:
+ * csrc/common.h HdyOption).  hdy_set_option returns the previous value (< 0: unknown name).  They also steer the sizing queries, so set
+ * them before sizing buffers / building plans. */
+int hdy_set_option(const char* name, int value);
+int hdy_get_option(const char* name);
 /* host-only: the reciprocal conv_igemm.hip divides row indices by (n / d == mulhi(2n, *magic) >> *shift for n < 2^31) */
 int hdy_fastdiv_magic(unsigned d, unsigned* magic, int* shift);
 

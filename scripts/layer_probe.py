@@ -23,6 +23,10 @@ l, _ = m(x, t); l['det']['det_loss'].backward()
 plan = next(iter(m._eng().plans.values()))
 torch.cuda.synchronize()
 seen = set()
+# HDY_PROBE_MARKERS=1: a fill kernel on an int16 tensor of 65536 * (index + 1) elements is launched before every matched record, so that
+# scripts/pmc_layers.py can cut a rocprofv3 counter CSV into per-layer segments (several layers run on the same kernel and grid)
+markers = os.environ.get('HDY_PROBE_MARKERS') == '1'
+mark = torch.empty(65536 * 64, dtype=torch.int16, device='cuda:0') if markers else None
 for ph, recs in (('F', plan.fwd), ('B', plan.bwd)):
     for rec in flat_records(recs):
         d, fl, by = describe(rec)
@@ -30,5 +34,7 @@ for ph, recs in (('F', plan.fwd), ('B', plan.bwd)):
         if not pat.search(label) or label in seen:
             continue
         seen.add(label)
+        if markers:
+            mark[:65536 * len(seen)].fill_(1)
         us = time_record(rec, reps)
         print(f'{label:44s} {us:8.1f} us  {fl/us/1e6:7.1f} TF  {by/us/1e3:7.0f} GB/s', flush=True)

@@ -50,6 +50,23 @@ def test_pure_host_queries(lib):
     assert lib.hdy_bn_bwd_blocks(10) == 1 and lib.hdy_bn_bwd_blocks(10 ** 7) == 1024
 
 
+def test_options_and_dispatch_log_are_host_state(lib):
+    """kernel-selection switches: known names round-trip, unknown names fail with a status; the dispatch log starts empty on a thread"""
+    assert lib.hdy_get_option(b'HDY_WGRAD_BLOCKS') == 512 and lib.hdy_get_option(b'HDY_TILE_INTERLEAVE') == 1
+    prev = lib.hdy_set_option(b'HDY_NO_CONV3X3', 1)
+    assert prev == 0 and lib.hdy_get_option(b'HDY_NO_CONV3X3') == 1
+    # the switch steers the sizing query too: the filter-resident kernel's one-slab-per-workgroup count is gone
+    assert lib.hdy_conv_stat_slabs(64, 80, 80, 64, 64, 3, 3, 1, 1, _lib.BF16) != 512
+    assert lib.hdy_set_option(b'HDY_NO_CONV3X3', prev) == 1
+    assert lib.hdy_conv_stat_slabs(64, 80, 80, 64, 64, 3, 3, 1, 1, _lib.BF16) == 512
+    assert lib.hdy_set_option(b'HDY_NO_SUCH_THING', 1) < 0 and b'unknown option' in lib.hdy_last_error()
+    with _lib.option('HDY_NO_BIG_TILES', 1):
+        assert lib.hdy_get_option(b'HDY_NO_BIG_TILES') == 1
+    assert lib.hdy_get_option(b'HDY_NO_BIG_TILES') == 0
+    lib.hdy_dispatch_log_reset()
+    assert lib.hdy_last_dispatch() == b'' and _lib.dispatch_log() == []
+
+
 def test_invalid_arguments_return_status_not_crash(lib):
     rc = lib.hdy_conv_fwd(None, 8, None, None, None, None, 0, None, 8, None, 1, 4, 4, 8, 8, 1, 1, 1, 0, 0, 0, _lib.BF16, 0, 0, None)
     assert rc < 0 and b'null' in lib.hdy_last_error()

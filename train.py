@@ -139,6 +139,13 @@ def train(hyp, opt, device):
             ema.ema.load_state_dict(intersect_dicts(checkpoint_state({'model': ckpt['ema']}), ema.ema.state_dict()), strict=False)
             ema.updates = ckpt.get('updates', 0)
         start_epoch = ckpt.get('epoch', 0)                             # checkpoints store epoch + 1, as the reference (train.py:531)
+        # train.py:267: a finished run's checkpoint (epoch -1 once its optimizer state is stripped) has nothing to resume
+        if start_epoch is None or start_epoch < 0 or ckpt.get('optimizer') is None:
+            raise SystemExit(f'--resume: {opt.weights} is a finished / stripped checkpoint (epoch {start_epoch}, optimizer '
+                             f'{"present" if ckpt.get("optimizer") is not None else "absent"}): nothing to resume; start a new run with --weights alone')
+        if opt.epochs < start_epoch:                                   # train.py:268-270: fine-tune for `epochs` more
+            LOGGER.info(f'{opt.weights} has been trained for {start_epoch} epochs. Fine-tuning for {opt.epochs} more epochs.')
+            opt.epochs += start_epoch
 
     # per-header loss gains scaled to layers / classes / image size (train.py:335-345)
     for header in model.headers.values():
