@@ -34,6 +34,10 @@ enum HdyOption {
     HDY_OPT_LOSS_GRID,         // HDY_LOSS_GRID: workgroups of the detection loss' dense pass (default 2048)
     HDY_OPT_NO_DEEP,           // HDY_NO_DEEP: deep-pipelined 256-row implicit GEMM off (generic kernel instead)
     HDY_OPT_NO_WGRAD_S2,       // HDY_NO_WGRAD_S2: tap-walking stride-2 3x3 weight gradient off
+    HDY_OPT_DEEP_BN,           // HDY_DEEP_BN: column tile of the deep-pipelined kernel (0 = by shape, 128, 256)
+    HDY_OPT_DEEP_DEBUG,        // HDY_DEEP_DEBUG: timing ablations of the deep-pipelined kernel (bit mask, results wrong; measurement only)
+    HDY_OPT_DEEP_ALL,          // HDY_DEEP_ALL: 1 (default) the deep-pipelined kernel takes multi-tap (3x3) layers too, 0 the 1x1 layers only
+    HDY_OPT_DEEP_MIN_TILES,    // HDY_DEEP_MIN_TILES: fewest 256-row tiles the deep-pipelined kernel takes a layer with (default 160)
     HDY_OPT_COUNT
 };
 int hdy_opt(int id);

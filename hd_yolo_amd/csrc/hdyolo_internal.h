@@ -47,6 +47,7 @@ struct ConvArgs {
     int tile_interleave;  // 1: tiles that share A rows (column tiles of one m-tile, parity classes) go to neighbouring workgroups instead of one
     unsigned mg_howo, mg_wo, mg_c, mg_tw[4];
     int sh_howo, sh_wo, sh_c, sh_tw[4];
+    int dbg;              // conv_deep.hip timing ablations (HDY_DEEP_DEBUG; results are wrong when set): 1 no A loads, 2 no B loads, 4 no MFMAs, 8 no epilogue, 16 no fragment reads
 };
 
 // reciprocal for n / d, n < 2^31: q = mulhi(2n, *mg) >> *sh (conv_igemm.hip fdiv)
@@ -91,4 +92,6 @@ int hdy_wgrad3x3_try(const void* x, int ldx, const void* dy, int lddy, int N, in
 int hdy_conv_igemm_stat_grid(long long M, int K, int taps, int ncls);
 int hdy_dgrad3x3s2_try(const ConvArgs& a, int dtype, hipStream_t st, int* rc);
 int hdy_conv3x3s2_c32_try(const ConvArgs& a, int dtype, int out_f32, hipStream_t st, int* rc);
+int hdy_conv_deep_try(const ConvArgs& a, int dtype, int out_f32, hipStream_t st, int* rc);
+int hdy_conv_deep_slabs(long long M, int C, int K, int taps, int pointwise, int dtype);
 int hdy_conv3x3s2_c32_slabs(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dtype);

@@ -1,10 +1,11 @@
 #!/bin/bash
-# build_variant.sh NAME [-DMACRO ...]: csrc/build/libNAME.so = the library with conv3x3.hip recompiled under extra macros (A/B probes)
+# build_variant.sh NAME SRC [-DMACRO ...]: csrc/build/libNAME.so = the library with csrc/SRC.hip recompiled under extra macros (A/B probes,
+# diagnostic builds); load it with HDY_LIB=libNAME.so.  Example: scripts/build_variant.sh hdy_deepdbg conv_deep -DHDY_DEEP_DBG=1
 set -e
-R=/root/repo/hd_yolo_amd/csrc
-name=$1; shift
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -I$R -I/root/repo/include "$@" -c $R/conv3x3.hip -o /tmp/c3_$name.o
+R=$(cd "$(dirname "$0")/.." && pwd)/hd_yolo_amd/csrc
+name=$1; src=$2; shift 2
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -I$R -I$R/../../include "$@" -c $R/$src.hip -o /tmp/var_$name.o
 objs=""
-for o in api conv_igemm conv_stem conv_wgrad bn_act pool detect loss roi; do objs="$objs $R/build/$o.o"; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/build/lib$name.so $objs /tmp/c3_$name.o
+for o in $R/build/*.o; do [ "$(basename $o)" = "$src.o" ] || objs="$objs $o"; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/build/lib$name.so $objs /tmp/var_$name.o
 echo built $R/build/lib$name.so

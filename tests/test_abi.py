@@ -40,7 +40,9 @@ def test_pure_host_queries(lib):
     assert lib.hdy_conv_stat_slabs(2, 20, 20, 32, 32, 3, 3, 1, 1, _lib.BF16) == 7
     assert lib.hdy_conv_stat_slabs(64, 80, 80, 64, 64, 3, 3, 1, 1, _lib.BF16) == 512      # two workgroups per CU
     assert lib.hdy_conv_stat_slabs(64, 80, 80, 64, 64, 3, 3, 1, 1, _lib.F32) == 640      # generic kernel, one column tile: 768 resident workgroups x 5 tiles
-    assert lib.hdy_conv_stat_slabs(64, 20, 20, 128, 256, 1, 1, 1, 0, _lib.BF16) == 200   # two column tiles: one slab per 128 rows
+    assert lib.hdy_conv_stat_slabs(64, 20, 20, 128, 256, 1, 1, 1, 0, _lib.BF16) == 100   # deep-pipelined kernel: one slab per workgroup position (100 row tiles of 256)
+    with _lib.option('HDY_NO_DEEP', 1):
+        assert lib.hdy_conv_stat_slabs(64, 20, 20, 128, 256, 1, 1, 1, 0, _lib.BF16) == 200   # generic kernel, two column tiles: one slab per 128 rows
     # packed sizes: rows padded to the N tile, K-extent padded to 128 bytes
     assert lib.hdy_conv_pack_elems(39, 128, 1, 1, 1, 0, _lib.PACK_FWD, _lib.BF16) == 64 * 128
     assert lib.hdy_conv_pack_elems(64, 64, 3, 3, 1, 1, _lib.PACK_FWD, _lib.F32) == 64 * 576

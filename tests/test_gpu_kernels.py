@@ -84,9 +84,35 @@ CONV_CASES = [
 ]
 
 
+# kernel family the dispatch log must name for a CONV_CASES row in bf16 (forward with statistics, data gradient, weight gradient); None = not
+# asserted.  A regression that silently sends one of these shapes back to the generic kernel passes every numeric check.
+def expected_dispatch(case):
+    N, H, W, C, K, R, stride, pad = case
+    fwd = dgrad = wgrad = None
+    if R == 3 and stride == 1 and pad == 1 and C in (32, 64) and K <= 64 and H % 8 == 0 and W % 16 == 0:
+        fwd = 'conv3x3_c%d' % C
+        if K in (32, 64) and C <= 64:
+            dgrad = 'conv3x3_c%d' % K
+    if R == 3 and stride == 2 and C == 32 and K == 64 and H % 16 == 0 and W % 64 == 0:
+        fwd, dgrad = 'conv3x3s2_c32', 'dgrad3x3s2_k64c32'
+    if R == 3 and stride == 1 and C % 32 == 0 and K % 32 == 0 and C <= 256 and K <= 256:
+        wgrad = 'wgrad3x3'
+    return fwd, dgrad, wgrad
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('case', CONV_CASES)
 def test_conv_fwd_dgrad_wgrad(case, dtype):
+    logs = conv_case(case, dtype)
+    if dtype == torch.bfloat16:
+        for got, want, what in zip(logs, expected_dispatch(case), ('forward', 'data gradient', 'weight gradient')):
+            if want is not None:
+                assert want in got, f'{what} of {case} ran {got}, expected {want}'
+
+
+def conv_case(case, dtype):
+    """forward (+ statistics), epilogue, data gradient, weight gradient of one convolution against torch fp32 on the CPU; returns the kernel
+    families the launchers picked for (forward with statistics, data gradient, weight gradient)"""
     N, H, W, C, K, R, stride, pad = case
     x = q(rnd((N, C, H, W), 1), dtype)
     w = rnd((K, C, R, R), 2, (3.0 / (C * R * R)) ** 0.5)
@@ -99,8 +125,10 @@ def test_conv_fwd_dgrad_wgrad(case, dtype):
     y = ybuf[..., 8:]
     mt = ops.stat_slabs(N, H, W, C, K, R, R, stride, pad, dtype)
     stats = torch.full((mt, 2, K), float('nan'), dtype=torch.float32, device=DEV)       # every slab must be written
-    ops.run([ops.rec_pack(wdev, None, stride, pad, ops.PACK_FWD, wp),
-             ops.rec_conv_fwd(xd, wp, y, K, R, R, stride, pad, stats=stats)])
+    ops.run([ops.rec_pack(wdev, None, stride, pad, ops.PACK_FWD, wp)])
+    _lib.dispatch_log(reset=True)
+    ops.run([ops.rec_conv_fwd(xd, wp, y, K, R, R, stride, pad, stats=stats)])
+    log_fwd = _lib.dispatch_log(reset=True)
     ref = F.conv2d(x, wq, None, stride, pad)
     got = from_dev_nhwc(y)
     assert_close(got, ref, TOL[dtype], 'conv fwd')
@@ -117,7 +145,7 @@ def test_conv_fwd_dgrad_wgrad(case, dtype):
     assert_close(from_dev_nhwc(y2), ref2, TOL[dtype] * 2, 'conv epilogue')
 
     if K % 8 or C % 8:
-        return
+        return log_fwd, [], []
     # dgrad / wgrad against autograd
     dy = q(rnd((N, K, Ho, Wo), 5), dtype)
     xr = x.clone().requires_grad_(True)
@@ -126,8 +154,10 @@ def test_conv_fwd_dgrad_wgrad(case, dtype):
     dyd = to_dev_nhwc(dy, dtype, ld=K + 8, off=0)
     wpd = ops.pack_alloc(K, C, R, R, stride, pad, ops.PACK_DGRAD, dtype, DEV)
     dx = torch.full((N, H, W, C), 1.0, dtype=dtype, device=DEV)
-    ops.run([ops.rec_pack(wdev, None, stride, pad, ops.PACK_DGRAD, wpd),
-             ops.rec_conv_dgrad(dyd, wpd, dx, R, R, stride, pad, accumulate=True)])
+    ops.run([ops.rec_pack(wdev, None, stride, pad, ops.PACK_DGRAD, wpd)])
+    _lib.dispatch_log(reset=True)
+    ops.run([ops.rec_conv_dgrad(dyd, wpd, dx, R, R, stride, pad, accumulate=True)])
+    log_dgrad = _lib.dispatch_log(reset=True)
     assert_close(from_dev_nhwc(dx), xr.grad + 1.0, TOL[dtype] * 2, 'dgrad')
 
     ws = torch.empty(ops.wgrad_ws_bytes(N, H, W, C, K, R, R, stride, pad, dtype) // 4 + 1, dtype=torch.float32, device=DEV)
@@ -135,9 +165,56 @@ def test_conv_fwd_dgrad_wgrad(case, dtype):
     ga = torch.zeros((ka, C, R, R), dtype=torch.float32, device=DEV)
     gb = torch.full((K - ka, C, R, R), 2.0, dtype=torch.float32, device=DEV) if ka < K else None
     ops.run([ops.rec_conv_wgrad(xd, dyd, ga, gb, R, R, stride, pad, ws, accumulate=True)])
+    log_wgrad = _lib.dispatch_log(reset=True)
     assert_close(ga.cpu(), wr.grad[:ka], TOL[dtype] * 3, 'wgrad a')
     if gb is not None:
         assert_close(gb.cpu(), wr.grad[ka:] + 2.0, TOL[dtype] * 3, 'wgrad b')
+    return log_fwd, log_dgrad, log_wgrad
+
+
+DEEP_CASES = [
+    # N, H, W, C, K, R, stride, pad — shapes of the deep-pipelined kernel (C % 64 == 0, K >= 128), small enough for a CPU reference
+    (2, 20, 20, 128, 128, 3, 1, 1),      # 4 row tiles, the last one 32 rows; every tile has border pixels
+    (3, 40, 40, 128, 256, 3, 1, 1),      # tiles straddle images
+    (1, 24, 56, 192, 128, 3, 1, 1),      # three channel blocks per tap
+    (3, 40, 40, 256, 512, 1, 1, 0),      # 1x1: four K-tiles per output tile, the stream runs across tiles
+    (1, 16, 16, 128, 256, 1, 1, 0),      # exactly one row tile
+    (2, 48, 48, 128, 256, 3, 2, 1),      # stride-2 forward (its data gradient is the class walk of the generic kernel)
+    (2, 20, 20, 64, 384, 1, 1, 0),       # K = 1.5 column tiles of 256 / 3 of 128; one K-tile per output tile
+    (1, 20, 20, 64, 136, 3, 1, 1),       # K not a multiple of 16: ragged last column tile
+    (8, 96, 96, 64, 128, 1, 1, 0),       # 288 row tiles on 256 workgroups: some walk two tiles, one K-tile each
+    (5, 96, 96, 64, 128, 3, 1, 1),       # 180 row tiles, nine K-tiles each
+]
+
+
+@pytest.mark.parametrize('bn', [0, 128, 256])
+@pytest.mark.parametrize('case', DEEP_CASES)
+def test_deep_pipelined_conv(case, bn):
+    """conv_deep.hip (256-row tiles, loads in flight across barriers) on shapes the plan would give to the generic kernel at test size:
+    HDY_DEEP_MIN_TILES = 1 sends them to it; both column tiles (HDY_DEEP_BN); forward with BatchNorm sums, epilogue with scale / shift /
+    SiLU / accumulate, stride-1 data gradient with accumulate — against torch fp32 on the CPU, and the dispatch log must name the kernel"""
+    N, H, W, C, K, R, stride, pad = case
+    with _lib.option('HDY_DEEP_MIN_TILES', 1), _lib.option('HDY_DEEP_BN', bn), _lib.option('HDY_DEEP_ALL', 1):
+        log_fwd, log_dgrad, _ = conv_case(case, torch.bfloat16)
+    assert log_fwd == ['deep_256x128'], log_fwd                  # statistics: 128-wide instances
+    if stride == 1 and K % 64 == 0 and C >= 128:
+        assert log_dgrad and log_dgrad[0].startswith('deep_256x'), log_dgrad
+    # A/B: the same forward through the generic kernel agrees to the last bf16 rounding (both accumulate in fp32 over the same k order per tap)
+    x = q(rnd((N, C, H, W), 11), torch.bfloat16)
+    xd = to_dev_nhwc(x, torch.bfloat16)
+    w = rnd((K, C, R, R), 12, (3.0 / (C * R * R)) ** 0.5).to(DEV)
+    wp = ops.pack_alloc(K, C, R, R, stride, pad, ops.PACK_FWD, torch.bfloat16, DEV)
+    Ho, Wo = ops.out_dim(H, R, stride, pad), ops.out_dim(W, R, stride, pad)
+    outs = []
+    for off in (0, 1):
+        y = torch.zeros((N, Ho, Wo, K), dtype=torch.bfloat16, device=DEV)
+        with _lib.option('HDY_DEEP_MIN_TILES', 1), _lib.option('HDY_DEEP_BN', bn), _lib.option('HDY_DEEP_ALL', 1), _lib.option('HDY_NO_DEEP', off):
+            _lib.dispatch_log(reset=True)
+            ops.run([ops.rec_pack(w, None, stride, pad, ops.PACK_FWD, wp), ops.rec_conv_fwd(xd, wp, y, K, R, R, stride, pad)])
+            assert any(n.startswith('deep_') for n in _lib.dispatch_log()) == (off == 0)
+        outs.append(y.float())
+    d = (outs[0] - outs[1]).abs().max().item()
+    assert d <= 2.0 ** -7 * outs[1].abs().max().item(), f'deep vs generic kernel differ by {d}'
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
