@@ -68,8 +68,11 @@ class GradAllReduce:
     BUCKET_BYTES = 64 << 20       # upper bound of one RCCL call
     MIN_BYTES = 4 << 20           # a ready range smaller than this waits for its neighbour (fixed RCCL latency per call)
 
-    def __init__(self, nbuckets=None, group=None, overlap=True):
+    def __init__(self, nbuckets=None, group=None, overlap=True, reduce_fn=None):
+        """reduce_fn(range_tensor): replaces the collective (tests: a kernel on the communication stream that doubles the range stands in
+        for the SUM over two identical ranks, so that a one-GPU box can check the stream ordering of the overlap)"""
         self.nbuckets, self.group, self.overlap = nbuckets, group, overlap
+        self.reduce_fn = reduce_fn
         self.stream = None
         self.sent = []            # ranges already given to the communication stream in this backward pass
         self.pending = None       # a ready range not yet sent (too small on its own)
@@ -77,6 +80,8 @@ class GradAllReduce:
 
     def _active(self):
         # HDY_FORCE_DIST=1: issue the collectives with one rank too (rehearsal of the N > 1 path over RCCL on a one-GPU box)
+        if self.reduce_fn is not None:
+            return True
         return dist.is_initialized() and (dist.get_world_size(self.group) > 1 or os.environ.get('HDY_FORCE_DIST') == '1')
 
     def _send(self, flat, a, b, waits):
@@ -88,12 +93,17 @@ class GradAllReduce:
                     self.stream.wait_stream(s)
             with torch.cuda.stream(self.stream):
                 for x in range(a, b, self.BUCKET_BYTES // 4):
-                    dist.all_reduce(flat[x:min(b, x + self.BUCKET_BYTES // 4)], op=dist.ReduceOp.SUM, group=self.group)
-                    self.calls += 1
+                    self._reduce(flat[x:min(b, x + self.BUCKET_BYTES // 4)])
         else:
-            dist.all_reduce(flat[a:b], op=dist.ReduceOp.SUM, group=self.group)
-            self.calls += 1
+            self._reduce(flat[a:b])
         self.sent.append((a, b))
+
+    def _reduce(self, t):
+        if self.reduce_fn is not None:
+            self.reduce_fn(t)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        self.calls += 1
 
     def bucket(self, store, a, b, side_stream=None):
         """Engine bucket hook: gradient elements [a, b) of store.cur are final once the work issued so far has run."""

@@ -174,3 +174,143 @@ def test_sync_batchnorm_two_ranks_equal_one_process_with_the_whole_batch():
     m2 = m2.to(dev).train()
     _, d2 = m2._eng().forward(x[:2].contiguous(), True, torch.float32)
     assert rel(d2[0].detach().cpu(), dets[0][:2].detach().cpu()) > 1e-3
+
+
+def _bench_size_grads(reducer=None, steps=1):
+    """flat gradient of one yolov5s / 8-class / batch 64 / 640x640 bf16 training step (BASELINE configs[1]) with an optional gradient hook"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.setdefault('YOLOv5_VERBOSE', 'false')
+    from hd_yolo_amd import synth
+    from metayolo.models.yolo import Model
+    dev = torch.device('cuda', 0)
+    model = Model(synth.make_cfg('s', 8), synth.make_hyp())
+    model.load_state_dict(synth.synth_state_dict(synth.shapes_of(model), seed=0), strict=False)
+    model = model.to(dev).train()
+    model.half()
+    eng = model._eng()
+    if reducer is not None:
+        eng.grad_hooks.append(reducer)
+        eng.bucket_hooks.append(reducer.bucket)
+    x = synth.synth_images(64, 640, seed=0).to(dev)
+    t = synth.synth_targets(64, 640, 8, seed=1)
+    out = None
+    for _ in range(steps):
+        for p in model.parameters():
+            p.grad = None
+        losses, _ = model(x, t)
+        losses['det']['det_loss'].backward()
+        torch.cuda.synchronize()
+        out = torch.cat([p.grad.flatten() for p in model.parameters()]).clone()
+    plan = next(iter(eng.plans.values()))
+    return out, plan
+
+
+@pytest.mark.timeout(600)
+def test_overlapped_reduction_waits_for_every_writer_at_bench_size():
+    """The N > 1 overlap on ONE GPU, falsifiable: the collective is replaced by a kernel on the communication stream that doubles the
+    range (= SUM over two identical ranks).  With the reducer's stream dependencies in place every parameter gradient must be exactly
+    twice the single-process gradient — a range doubled before its last writer (main stream or weight-gradient side stream) has finished
+    ends up un-doubled or half-doubled.  Control: the same run with the waits removed must NOT give twice the gradient."""
+    from hd_yolo_amd.parallel import GradAllReduce
+    g, plan = _bench_size_grads()
+    assert len(plan.grad_marks) >= 4                     # the 29 MB of yolov5s gradients leave the backward list in >= 4 ranges
+    red = GradAllReduce(overlap=True, reduce_fn=lambda t: t.mul_(2.0))
+    g2, _ = _bench_size_grads(red, steps=2)              # second step: buffers recycled, streams warm
+    assert red.calls >= 8, red.calls                     # >= 4 per backward pass, issued during it
+    assert torch.equal(g2, 2 * g), f'{(g2 - 2 * g).abs().max().item()} max deviation, {(g2 != 2 * g).float().mean().item():.3f} of the elements'
+    # control: no stream dependencies -> the doubling kernels overtake the launches that write the ranges
+    broken = GradAllReduce(overlap=True, reduce_fn=lambda t: t.mul_(2.0))
+    broken._streams = lambda flat, side: []
+    g3, _ = _bench_size_grads(broken, steps=2)
+    assert not torch.equal(g3, 2 * g), 'the check cannot see a missing dependency'
+
+
+def _hnet_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), YOLOv5_VERBOSE='false',
+                      HDY_GRAD_BUCKET_MB='1')
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.nn.functional as F
+    from hd_yolo_amd import synth
+    from hd_yolo_amd.hnet import HNet
+    from hd_yolo_amd.parallel import DataParallel
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        dev = torch.device('cuda', 0)
+        B, S, nc, ncls = 2, 64, 2, 3
+        cfg = {'backbone': {'type': 'yolov5', 'cfg': synth.make_cfg('n', nc), 'hyp': synth.make_hyp()},
+               'headers': {'seg': {'type': 'PanopticSeg', 'configs': {'num_classes': ncls, 'feature_maps': None, 'in_channels': None, 'scale_factor': 8,
+                                                                       'resize_mode': 'bilinear', 'class_weight': None, 'roi_size': None}}}}
+        m = HNet(cfg)
+        m.detector.load_state_dict(synth.synth_state_dict(synth.shapes_of(m.detector), seed=rank), strict=False)      # ranks differ before the broadcast
+        g = torch.Generator().manual_seed(5 + rank)
+        with torch.no_grad():
+            for k, p in m.headers.named_parameters():
+                p.copy_(torch.randn(p.shape, generator=g) * (0.05 if p.dim() == 4 else 0.3) + (1.0 if p.dim() == 1 and k.endswith('weight') else 0.0))
+        m = m.to(dev).train()
+        net = DataParallel(m, nbuckets=3)
+        net.reducer.MIN_BYTES = 1 << 20
+
+        def batch():
+            x = synth.synth_images(B, S, seed=20 + rank).to(dev)
+            det_t = synth.synth_targets(B, S, nc, nmin=3, nmax=8, seed=30 + rank)
+            lab = torch.randint(0, ncls, (B, S, S), generator=torch.Generator().manual_seed(40 + rank))
+            masks = F.one_hot(lab, ncls).permute(0, 3, 1, 2).float().contiguous()
+            targets = []
+            for i, t in enumerate(det_t):
+                anns = dict(t['anns'])
+                anns['seg'] = [{'roi': torch.tensor([0.0, 0.0, S, S]), 'masks': masks[i].to(dev)}]
+                targets.append({**t, 'anns': anns})
+            return x, targets
+
+        def step():
+            for p in m.parameters():
+                p.grad = None
+            x, targets = batch()
+            losses, _ = net(x, targets)
+            (losses['det_det_loss'] + 2.0 * losses['seg_soft_iou_loss']).backward()
+            return {k: p.grad.detach().cpu().numpy().copy() for k, p in m.named_parameters()}
+
+        start = {k: p.detach().cpu().numpy().copy() for k, p in m.named_parameters()}
+        eng = m._eng()
+        hooks, eng.grad_hooks = eng.grad_hooks, []
+        bhooks, eng.bucket_hooks = eng.bucket_hooks, []
+        bn = {k: v.clone() for k, v in m.state_dict().items() if 'running_' in k or 'num_batches' in k}
+        local = step()
+        m.load_state_dict(bn, strict=False)                  # undo the BatchNorm statistics update of the probe step
+        eng.grad_hooks, eng.bucket_hooks = hooks, bhooks
+        reduced = step()
+        q.put((rank, start, local, reduced))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_hnet_two_ranks_sum_detector_and_segmentation_header_gradients():
+    """BASELINE configs[4] shape of the data-parallel path: HNet (detector plan + PanopticSeg header on its pyramid taps) under DataParallel,
+    two ranks over gloo on one GPU.  The segmentation header's parameters live in the same flat gradient store as the detector's (their
+    gradients are written by the header's own backward, outside the launch list): every parameter — backbone, neck, detection convs,
+    connector ladders, class conv — must start from rank 0's value and receive the SUM of the two ranks' gradients."""
+    import numpy as np
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hnet_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=240) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, s0, l0, r0), (_, s1, l1, r1) = out
+    seg_keys = [k for k in s0 if k.startswith('headers.')]
+    assert len(seg_keys) >= 6 and any('detector.backbone' in k or k.startswith('detector.') for k in s0)
+    for k in s0:
+        assert np.array_equal(s0[k], s1[k]), f'{k}: rank 0 state was not broadcast'
+        assert np.array_equal(r0[k], r1[k]), f'{k}: ranks disagree on the reduced gradient'
+        want = l0[k] + l1[k]
+        err = np.abs(r0[k] - want).max() / (np.abs(want).max() + 1e-12)
+        assert err < 1e-4, f'{k}: reduced gradient is not the sum of the ranks ({err:.2e})'
+    assert any(np.abs(l0[k]).max() > 0 for k in seg_keys)

@@ -46,12 +46,14 @@ def test_bench_py_spawns_its_own_ranks():
     on a one-GPU box they share the card over gloo."""
     import json
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
-    p = subprocess.run([sys.executable, 'bench.py', '--gpus', '2', '--steps', '3', '--warmup', '1', '--batch', '4', '--variant', 'n', '--size', '128',
-                        '--no-roofline', '--no-cpu-baseline'], cwd=ROOT, env=dict(env, YOLOv5_VERBOSE='false'), capture_output=True, text=True, timeout=500)
+    p = subprocess.run([sys.executable, 'bench.py', '--gpus', '2', '--steps', '3', '--warmup', '1', '--batch', '4', '--variant', 's', '--size', '128',
+                        '--no-roofline', '--no-cpu-baseline', '--no-infer'], cwd=ROOT, env=dict(env, YOLOv5_VERBOSE='false'), capture_output=True, text=True, timeout=500)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][-1])
     assert line['n_gpus'] == 2 and line['config']['world_size'] == 2 and line['config']['global_batch'] == 8
     assert line['config']['backend'] in ('gloo', 'nccl') and line['value'] > 0
+    # yolov5s: 28 MB of gradients leave the backward list in >= 4 overlapped ranges per step (6 MB marks)
+    assert line['config']['allreduce_calls_per_step'] >= 4, line['config']
 
 
 def test_train_py_cfg_hyp_freeze_masks_save_period(tmp_path):
