@@ -179,7 +179,7 @@ class option:
 
 
 def dispatch_log(reset=False):
-    """kernel families picked on this thread since the last reset, in launch order"""
+    """kernel families picked (by any thread) since the last reset, in launch order"""
     lib = load()
     names = [n for n in lib.hdy_dispatch_log().decode().split(';') if n]
     if reset:

@@ -51,8 +51,11 @@ int opt_index(const char* name) {
     return -1;
 }
 thread_local char g_disp_last[64] = "";
-thread_local char g_disp_log[2048] = "";
-thread_local size_t g_disp_len = 0;
+// the log is process-wide (autograd runs the backward launch list on its own thread) and ordered; readers get a thread-local copy
+std::mutex g_disp_mu;
+char g_disp_log[32768] = "";
+size_t g_disp_len = 0;
+thread_local char g_disp_copy[32768] = "";
 }  // namespace
 
 int hdy_opt(int id) {
@@ -63,6 +66,7 @@ int hdy_opt(int id) {
 void hdy_note_dispatch(const char* what) {
     snprintf(g_disp_last, sizeof(g_disp_last), "%s", what);
     const size_t n = strlen(g_disp_last);
+    std::lock_guard<std::mutex> lock(g_disp_mu);
     if (g_disp_len + n + 2 < sizeof(g_disp_log)) {
         memcpy(g_disp_log + g_disp_len, g_disp_last, n);
         g_disp_log[g_disp_len + n] = ';';
@@ -107,10 +111,15 @@ const char* hdy_last_error(void) { return g_err; }
 // name of the kernel family the last launcher call on this thread picked ("" before the first)
 const char* hdy_last_dispatch(void) { return g_disp_last; }
 
-// every pick since the last hdy_dispatch_log_reset() on this thread, ';'-separated (first 2 KB)
-const char* hdy_dispatch_log(void) { return g_disp_log; }
+// every pick of every thread since the last hdy_dispatch_log_reset(), in launch order, ';'-separated (first 32 KB)
+const char* hdy_dispatch_log(void) {
+    std::lock_guard<std::mutex> lock(g_disp_mu);
+    memcpy(g_disp_copy, g_disp_log, g_disp_len + 1);
+    return g_disp_copy;
+}
 
 void hdy_dispatch_log_reset(void) {
+    std::lock_guard<std::mutex> lock(g_disp_mu);
     g_disp_log[0] = 0;
     g_disp_len = 0;
     g_disp_last[0] = 0;

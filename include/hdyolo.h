@@ -45,8 +45,8 @@ extern "C" {
 const char* hdy_last_error(void);
 int hdy_version(void);
 /* Which kernel ran: every launcher names the kernel family it picked ("igemm_128x128x2", "conv3x3_c64", "deep_256x128", "wgrad3x3", ...).
- * hdy_last_dispatch: the last pick on this thread; hdy_dispatch_log: every pick since hdy_dispatch_log_reset(), ';'-separated (thread-local,
- * first 2 KB).  The reference has no counterpart (ATen picks its kernels silently); the tests use it to assert that the shapes meant to hit
+ * hdy_last_dispatch: the last pick on this thread; hdy_dispatch_log: every pick of every thread since hdy_dispatch_log_reset(), in launch
+ * order, ';'-separated (process-wide under a mutex — autograd runs the backward list on its own thread — first 32 KB).  The reference has no counterpart (ATen picks its kernels silently); the tests use it to assert that the shapes meant to hit
  * a specialised kernel do. */
 const char* hdy_last_dispatch(void);
 const char* hdy_dispatch_log(void);

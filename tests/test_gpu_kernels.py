@@ -781,3 +781,72 @@ def test_det_targets_equals_the_tensor_expressions():
     assert torch.equal(tcls, one_hot_labels(labels, nc)[:, 1:].float())
     e = ops.det_targets(boxes[:0], img[:0], labels[:0], nc)
     assert e[0].shape == (0, 5) and e[1].shape == (0, nc)
+
+
+AB_CASES = [
+    # (switch that disables the specialised kernel, its dispatch name, what, N, H, W, C, K, stride): shapes with >= 2x the kernel's grid in tiles
+    ('HDY_NO_CONV3X3', 'conv3x3_c64', 'fwd', 8, 128, 128, 64, 64, 1),              # 1024 tiles of 8x16 on 512 workgroups
+    ('HDY_NO_CONV3X3', 'conv3x3_c32', 'fwd', 6, 128, 128, 32, 32, 1),              # 768 tiles, three workgroups per CU
+    ('HDY_NO_CONV3X3S2', 'conv3x3s2_c32', 'fwd', 6, 256, 256, 32, 64, 2),          # 1536 tiles of 4x16 outputs on 768 workgroups
+    ('HDY_NO_DGRAD_S2', 'dgrad3x3s2_k64c32', 'dgrad', 16, 256, 256, 32, 64, 2),    # 1024 dy tiles of 8x16 on 512 workgroups
+    ('HDY_NO_CONV3X3', 'conv3x3_c64', 'dgrad', 8, 128, 128, 64, 64, 1),
+]
+
+
+@pytest.mark.parametrize('case', AB_CASES, ids=[f'{c[1]}-{c[2]}' for c in AB_CASES])
+def test_specialised_kernel_agrees_with_generic_beyond_one_grid(case):
+    """Every patch- / filter-resident kernel against the generic implicit GEMM on the SAME inputs (its switch flips the dispatch), at more than
+    twice its persistent grid in tiles, forward WITH BatchNorm sums and with the scale / shift / SiLU epilogue: outputs within one bf16 ulp
+    of each other, slab sums within 1e-3, the fast kernel also against torch fp32 on the CPU; the dispatch log must show which kernel ran."""
+    sw, name, what, N, H, W, C, K, stride = case
+    dt = torch.bfloat16
+    R, pad = 3, 1
+    Ho, Wo = ops.out_dim(H, R, stride, pad), ops.out_dim(W, R, stride, pad)
+    w = rnd((K, C, R, R), 2, (3.0 / (C * R * R)) ** 0.5)
+    wq, wdev = q(w, dt), w.to(DEV)
+    sc, sh = (rnd((K,), 3).abs() + 0.5).to(DEV), rnd((K,), 4).to(DEV)
+    if what == 'fwd':
+        x = q(rnd((N, C, H, W), 1), dt)
+        xd = to_dev_nhwc(x, dt)
+        wp = ops.pack_alloc(K, C, R, R, stride, pad, ops.PACK_FWD, dt, DEV)
+        ops.run([ops.rec_pack(wdev, None, stride, pad, ops.PACK_FWD, wp)])
+        res = {}
+        for off in (0, 1):
+            with _lib.option(sw, off):
+                mt = ops.stat_slabs(N, H, W, C, K, R, R, stride, pad, dt)
+                stats = torch.full((mt, 2, K), float('nan'), dtype=torch.float32, device=DEV)
+                y = torch.empty((N, Ho, Wo, K), dtype=dt, device=DEV)
+                y2 = torch.empty((N, Ho, Wo, K), dtype=dt, device=DEV)
+                _lib.dispatch_log(reset=True)
+                ops.run([ops.rec_conv_fwd(xd, wp, y, K, R, R, stride, pad, stats=stats),
+                         ops.rec_conv_fwd(xd, wp, y2, K, R, R, stride, pad, scale=sc, shift=sh, act=ops.ACT_SILU)])
+                log = _lib.dispatch_log(reset=True)
+                assert (name in log) == (off == 0) and len(log) == 2 and log[0] == log[1], (off, log)
+                res[off] = (y.float(), y2.float(), stats.sum(0))
+        ref = F.conv2d(x, wq, None, stride, pad)
+        assert_close(from_dev_nhwc(res[0][0].to(dt)), ref, TOL[dt], f'{name} vs torch')
+        assert_close(from_dev_nhwc(res[0][1].to(dt)), F.silu(ref * sc.cpu().view(1, -1, 1, 1) + sh.cpu().view(1, -1, 1, 1)), TOL[dt] * 2, f'{name} epilogue vs torch')
+        for i, what_ in ((0, 'raw output'), (1, 'SiLU epilogue')):
+            a, b = res[0][i], res[1][i]
+            ulp = (a - b).abs() / (b.abs().clamp_min(2.0 ** -10) * 2.0 ** -7)            # bf16: 8 significant bits
+            assert ulp.max().item() <= 1.01, f'{name} {what_}: {ulp.max().item():.2f} bf16 ulps from the generic kernel'
+        assert_close(res[0][2].cpu(), res[1][2].cpu(), 1e-3, f'{name} BatchNorm sums vs generic')
+        assert_close(res[0][2][0].cpu(), ref.sum((0, 2, 3)), 1e-3, f'{name} BatchNorm sum vs torch')
+    else:
+        dy = q(rnd((N, K, Ho, Wo), 5), dt)
+        dyd = to_dev_nhwc(dy, dt)
+        wpd = ops.pack_alloc(K, C, R, R, stride, pad, ops.PACK_DGRAD, dt, DEV)
+        ops.run([ops.rec_pack(wdev, None, stride, pad, ops.PACK_DGRAD, wpd)])
+        res = {}
+        for off in (0, 1):
+            with _lib.option(sw, off):
+                dx = torch.empty((N, H, W, C), dtype=dt, device=DEV)
+                _lib.dispatch_log(reset=True)
+                ops.run([ops.rec_conv_dgrad(dyd, wpd, dx, R, R, stride, pad)])
+                log = _lib.dispatch_log(reset=True)
+                assert (name in log) == (off == 0), (off, log)
+                res[off] = dx.float()
+        ref = F.conv_transpose2d(dy, wq, None, stride, pad, output_padding=(H - ((Ho - 1) * stride - 2 * pad + R), W - ((Wo - 1) * stride - 2 * pad + R)))
+        assert_close(from_dev_nhwc(res[0].to(dt)), ref, TOL[dt], f'{name} vs torch')
+        ulp = (res[0] - res[1]).abs() / (res[1].abs().clamp_min(2.0 ** -10) * 2.0 ** -7)
+        assert ulp.max().item() <= 1.01, f'{name}: {ulp.max().item():.2f} bf16 ulps from the generic kernel'
