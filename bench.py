@@ -293,6 +293,13 @@ def main():
         line['step'] = {'conv_tflop_per_step': round(fl / 1e12, 3), 'mfma_frac': round(fl / ms / 1e9 / PEAK_BF16_TFLOPS, 4),
                         'algorithmic_gb_per_step': round(by / 1e9, 2), 'hbm_frac': round(by / ms / 1e6 / PEAK_HBM_GBS, 4),
                         'launches_per_step': len(bench_util.flat_records(plan.fwd)) + len(bench_util.flat_records(plan.bwd))}
+        # measured HBM bytes of the whole step (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE over 13 steps, scripts/step_traffic.sh) against the
+        # algorithmic bytes: well above 1 = wasted re-reads.  From the committed summary of the same command (PMC passes cannot run inside the timed process).
+        tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r03_step_traffic.json')
+        if args.variant == 's' and args.batch == 64 and args.size == 640 and os.path.exists(tj):
+            tr = json.load(open(tj))
+            line['step'].update(traffic_gb_per_step=tr['hbm_gb_per_step'], traffic_ratio=round(tr['hbm_gb_per_step'] / (by / 1e9), 3),
+                                traffic_source='profiles/r03_step_traffic.json')
         if not args.no_roofline:
             line['roofline'] = conv_roofline(device)
             rows = bench_util.conv3x3_table(plan, PEAK_BF16_TFLOPS)
