@@ -26,6 +26,8 @@ SIGNATURES = {
     'hdy_dispatch_log': (c_char_p, []),
     'hdy_dispatch_log_reset': (None, []),
     'hdy_set_option': (_I, [c_char_p, _I]),
+    'hdy_wgrad_reduce_mode': (_I, [_I, _P, _I]),
+    'hdy_wgrad_reduce_batch': (_I, [_P, _I, _I, _P]),
     'hdy_get_option': (_I, [c_char_p]),
     'hdy_conv_wgrad_stem_fused_ok': (_I, [_I, _I, _I, _I]),
     'hdy_conv_wgrad_stem_fused': (_I, [_P, _P, _I, _P, _I] + [_P] * 6 + [_I, _I, _I, _I, _P, _I, _P, _I, _I, _P, _Z, _P]),
@@ -111,6 +113,12 @@ class PackDesc(ctypes.Structure):
 class BnEvalDesc(ctypes.Structure):
     """mirror of hdy_bn_eval_desc (include/hdyolo.h)"""
     _fields_ = [(n, c_void_p) for n in ('gamma', 'beta', 'running_mean', 'running_var', 'scale', 'shift')] + [('K', c_int), ('eps', c_float)]
+
+
+class ReduceDesc(ctypes.Structure):
+    """mirror of hdy_reduce_desc (include/hdyolo.h)"""
+    _fields_ = [('partial', c_void_p), ('grad', c_void_p), ('slab_stride', ctypes.c_ulonglong)] + [(n, c_int) for n in (
+        'splits', 'K', 'Q', 'mode', 'C', 'R', 'S', 'accumulate', 'vec', 'first_block', 'nblocks', 'pad_')]
 
 
 class SgdDesc(ctypes.Structure):

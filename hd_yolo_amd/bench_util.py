@@ -54,7 +54,9 @@ def flat_records(recs):
     out = []
     for rec in recs or []:
         if rec[0] == '@fork':
-            out.extend(rec[2])
+            out.extend(flat_records(rec[2]))
+        elif rec[0] == '@wgrad':
+            out.append(rec[1])
         elif rec[0][0] != '@':
             out.append(rec)
     return out

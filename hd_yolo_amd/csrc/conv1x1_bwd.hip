@@ -386,7 +386,10 @@ int fused_launch(const FusedArgs& a, int grid, hipStream_t st) {
     return HDY_OK;
 }
 
-inline int tile_rows(int K) { return K == 128 ? 64 : 128; }    // 128-wide: 64-pixel tiles, so that two workgroups fit a CU's LDS
+// 128-wide: 64-pixel tiles, so that two workgroups fit a CU's LDS.  HDY_F1X1_SMALL = 1: 64-pixel tiles for the 32- / 64-wide instances too
+// (33 KB of LDS: four workgroups per CU instead of two — the kernel's waves are parked on waits 54-74 % of their cycles, profiles/r03_layers_pmc_table.txt)
+inline bool small_tiles(int K) { return K < 128 && hdy_opt(HDY_OPT_F1X1_SMALL) != 0; }
+inline int tile_rows(int K) { return (K == 128 || small_tiles(K)) ? 64 : 128; }
 
 }  // namespace
 
@@ -404,7 +407,7 @@ int hdy_conv1x1_bwd_fused_ok(int C, int K, int dtype) {
 int hdy_conv1x1_bwd_fused_grid(long long M, int K) {
     const int bm = tile_rows(K);
     const long long tiles = (M + bm - 1) / bm;
-    const long long cap = 512;                              // two resident workgroups per CU (768 for the 32-wide instance measured slower: 179 vs 160 us)
+    const long long cap = small_tiles(K) ? 1024 : 512;      // two (four) resident workgroups per CU (768 for the 32-wide instance measured slower: 179 vs 160 us)
     return (int)(tiles < cap ? tiles : cap);
 }
 
@@ -474,8 +477,8 @@ static int fused_impl(const void* dz_a, int lddz_a, const void* dz_b, int lddz_b
     const int grid = hdy_conv1x1_bwd_fused_grid(M, K);
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if (K == 32) rc = fused_launch<32, 32, 128, 2>(a, grid, st);
-    else if (K == 64) rc = fused_launch<64, 64, 128, 2>(a, grid, st);
+    if (K == 32) rc = small_tiles(K) ? fused_launch<32, 32, 64, 2>(a, grid, st) : fused_launch<32, 32, 128, 2>(a, grid, st);
+    else if (K == 64) rc = small_tiles(K) ? fused_launch<64, 64, 64, 2>(a, grid, st) : fused_launch<64, 64, 128, 2>(a, grid, st);
     else rc = fused_launch<128, 128, 64, 1>(a, grid, st);
     if (rc || !grad_a) return rc;
     rc = hdy_wgrad_reduce_launch(a.partial, grid, (size_t)K * C, K_a, C, 0, C, 1, 1, grad_a, accumulate_w, st);

@@ -88,6 +88,43 @@ class SideStream:
             main.wait_event(done)
 
 
+class ReduceSlot:
+    """The split reductions (one or two) a weight-gradient record ends with, described once (hdy_wgrad_reduce_mode tee) so that they can be
+    replayed inside a batched launch.  The record's slab workspace belongs to it alone."""
+
+    def __init__(self):
+        self.arr = (_lib.ReduceDesc * 2)()
+        self.n = 0
+        self.group = None
+
+
+class ReduceGroup:
+    """All split reductions of one gradient bucket as ONE launch (hdy_wgrad_reduce_batch) behind the bucket's last weight-gradient record."""
+
+    def __init__(self, slots, device):
+        self.slots, self.device, self.table, self.n, self.blocks = slots, device, None, 0, 0
+        for s in slots:
+            s.group = self
+
+    @property
+    def ready(self):
+        return self.table is not None
+
+    def build(self):
+        descs, blocks = [], 0
+        for s in self.slots:
+            for i in range(s.n):
+                d = _lib.ReduceDesc.from_buffer_copy(bytes(s.arr[i]))
+                d.first_block = blocks
+                blocks += d.nblocks
+                descs.append(d)
+        self.n, self.blocks = len(descs), blocks
+        if descs:
+            self.table = torch.frombuffer(bytearray(b''.join(bytes(d) for d in descs)), dtype=torch.uint8).to(self.device)
+        else:
+            self.table = torch.empty(0, dtype=torch.uint8, device=self.device)
+
+
 def run(records, stream=None):
     """Execute launch records on `stream` (default: torch's current HIP stream)."""
     lib = _lib.load()
@@ -102,6 +139,28 @@ def run(records, stream=None):
                 side.fork(rec[2], rec[3], torch.cuda.current_stream())
             elif name == '@join':
                 side.join(rec[2], torch.cuda.current_stream())
+            elif name == '@wgrad':
+                # a weight-gradient record whose split reduction is batched: first run = tee (reductions run AND are described), later runs
+                # skip them (the group's one launch does them)
+                inner, slot = rec[1], rec[2]
+                ready = slot.group is not None and slot.group.ready
+                try:
+                    lib.hdy_wgrad_reduce_mode(2 if ready else 1, None if ready else ctypes.cast(slot.arr, ctypes.c_void_p), 2)
+                    rc = getattr(lib, inner[0])(*inner[1], s)
+                finally:
+                    n = lib.hdy_wgrad_reduce_mode(0, None, 0)
+                if rc != 0:
+                    raise _lib.HdyError(f'{inner[0]} failed (status {rc}): {lib.hdy_last_error().decode()}')
+                if not ready:
+                    slot.n = n
+            elif name == '@reduce':
+                group = rec[1]
+                if not group.ready:
+                    group.build()                    # first run: the slots before this record have just been described (and reduced one by one)
+                elif group.n:
+                    rc = lib.hdy_wgrad_reduce_batch(group.table.data_ptr(), group.n, group.blocks, s)
+                    if rc != 0:
+                        raise _lib.HdyError(f'hdy_wgrad_reduce_batch failed (status {rc}): {lib.hdy_last_error().decode()}')
             continue
         rc = getattr(lib, name)(*args, s)
         if rc != 0:

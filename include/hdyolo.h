@@ -334,6 +334,27 @@ int hdy_bn_bwd_coeffs_sums(const double* sums, int K, float* c1, float* c2, void
  * hdy_sgd_blocks(n).  g' = g + wd*p; buf = momentum*buf + (1-dampening)*g'; p -= lr * (nesterov ? g' + momentum*buf : buf).
  * lr / momentum / dampening / weight_decay: HOST arrays of ngroups (<= HDY_SGD_MAX_GROUPS) values, passed by value to the kernel. */
 #define HDY_SGD_MAX_GROUPS 8
+/* ---- batched split reduction of the weight gradients --------------------------------------------------------------------------
+ * Every weight-gradient entry point (hdy_conv_wgrad, hdy_conv_wgrad_stem_fused, hdy_conv1x1_bwd_fused[_stats]) ends with one or two
+ * "sum the fp32 slabs into the gradient tensor" launches: ~60 launches of ~14 us per yolov5s step.  A caller with a static launch list
+ * (hd_yolo_amd/plan.py) records them once and replays them as ONE launch per gradient bucket:
+ *   hdy_wgrad_reduce_mode(1, descs_host, cap): TEE  — this thread's reductions run as usual AND are described into descs_host;
+ *   hdy_wgrad_reduce_mode(2, NULL, 0):         SKIP — they are not launched (the caller owns the descriptors and runs hdy_wgrad_reduce_batch);
+ *   hdy_wgrad_reduce_mode(0, NULL, 0):         back to normal.  Returns the number of descriptors recorded since the mode was entered.
+ * The slab workspace of a recorded call must stay untouched until its batch has run (one workspace per call, not a shared one).
+ * Same summation order as the single launches: results are bit-identical.  Replaces nothing in the reference (autograd accumulates
+ * weight gradients inside ATen's conv backward, train.py:472). */
+typedef struct hdy_reduce_desc {
+    const float* partial;
+    float* grad;
+    unsigned long long slab_stride;
+    int splits, K, Q, mode, C, R, S, accumulate, vec;
+    int first_block, nblocks;
+    int pad_;
+} hdy_reduce_desc;
+int hdy_wgrad_reduce_mode(int mode, hdy_reduce_desc* descs_host, int cap);
+int hdy_wgrad_reduce_batch(const hdy_reduce_desc* table_device, int ndesc, int total_blocks, void* stream);
+
 typedef struct hdy_sgd_desc {
     float* p;
     const float* g;
