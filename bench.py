@@ -93,12 +93,14 @@ def make_optimizer(model, hyp, batch_total):
 
 def pmc_traffic():
     """HBM bytes per launch of the roofline kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, see
-    profiles/r02_conv3x3_pmc.json and scripts/roofline_kernel.py); None when the file is absent."""
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'r02_conv3x3_pmc.json')) as f:
-            return json.load(f)['traffic_bytes_per_launch']
-    except (OSError, KeyError, ValueError):
-        return None
+    profiles/r03_conv3x3_pmc.json and scripts/roofline_kernel.py); None when the file is absent."""
+    for name in ('r03_conv3x3_pmc.json', 'r02_conv3x3_pmc.json'):
+        try:
+            with open(os.path.join(ROOT, 'profiles', name)) as f:
+                return json.load(f)['traffic_bytes_per_launch']
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 def conv_roofline(device, iters=30):

@@ -1,4 +1,6 @@
 """Glue between the nn.Module surface and the static HIP plans: plan cache, flat gradient store, autograd hook-in."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -204,12 +206,13 @@ class _FusedLossFn(torch.autograd.Function):
 class Engine:
     """Owns the plans of one (backbone, neck, head) triple."""
 
-    def __init__(self, backbone, neck=None, head=None, max_plans=3, extra=None, taps=()):
+    def __init__(self, backbone, neck=None, head=None, max_plans=None, extra=None, taps=()):
         self.parts = (backbone, neck, head)
         self.extra = extra            # module(s) outside the plans whose parameters share the flat gradient store (hnet's seg header)
         self.taps = tuple(taps)       # layer indices whose outputs those modules read
         self.plans = {}
-        self.max_plans = max_plans
+        # plans kept per (shape, dtype, mode): train.py --multi-scale walks a handful of sizes, each with its own static plan (oldest evicted)
+        self.max_plans = max_plans if max_plans is not None else int(os.environ.get('HDY_MAX_PLANS', '8'))
         self.store = None
         self.hook = None
         self.grad_hooks = []          # callables run after every backward, before publish (data-parallel all-reduce)

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Collect the round's rocprofv3 summaries on a GPU box (run through gpurun from the repo root):
-#   gpurun --timeout 1100 -- 'bash scripts/collect_profiles.sh r02'
+#   gpurun --timeout 1100 -- 'bash scripts/collect_profiles.sh r03'
 # Each counter set is its own run; programs are started directly after `--` (no shell hop between rocprofv3 and python).
 set -o pipefail
-R=${1:-r02}
+R=${1:-r03}
 OUT=gpurun_out/prof_$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -23,6 +23,8 @@ python3 scripts/bench_latency.py 2>/dev/null | tail -3 >> $OUT/variants.log
 python3 scripts/trace_gaps.py $OUT/bench/bench_kernel_trace.csv 6 > $OUT/trace_gaps.txt 2>&1
 python3 scripts/pmc_summary.py $OUT/fetch/fetch_counter_collection.csv $OUT/write/write_counter_collection.csv conv3x3_c64_kernel $OUT/conv3x3_pmc.json > /dev/null 2>&1
 python3 scripts/counters_summary.py $OUT/mfma/mfma_counter_collection.csv $OUT/lds/lds_counter_collection.csv conv3x3_c64_kernel $OUT/roof/roof_kernel_stats.csv $OUT/conv3x3_counters.json > /dev/null 2>&1
+bash scripts/step_traffic.sh $R > /dev/null 2>&1 && cp gpurun_out/traffic_$R/step_traffic.json $OUT/step_traffic.json
+bash scripts/probe_layers_pmc.sh 'B wgrd +128x +256 k3 s2|B wgrd +256x +512 k3 s2|F fwd +128-> +128 k3 s1 @40|F fwd +256-> +256 k1 s1 @40|B bnbw K=256 M=25600|B f1x1 +64<> +64 M=1638400$|B f1x1 +32<> +32|B f1x1 +128<> +128 M=409600|B wgrd +256x +256 k1 s1 @40|B dgrd +128<- +128 k3 s1 @40|B dgrd +512<- +512 k1' ${R}pmc 5 > /dev/null 2>&1 && cp gpurun_out/probe_${R}pmc/table.txt $OUT/layers_pmc_table.txt
 ls $OUT $OUT/* | head -60
 grep "^{" $OUT/bench.log | tail -1 | cut -c1-300
 grep "^{" $OUT/infer.log | tail -1 | cut -c1-300

@@ -41,6 +41,13 @@ def test_train_py_two_ranks_gloo(tmp_path, extra):
     assert 'epochs completed' in out
 
 
+def test_train_py_multi_scale(tmp_path):
+    """--multi-scale 0.5 (reference train.py:447-452, flag :610): the tile size changes from step to step (64..192 in multiples of 32)"""
+    out = run([sys.executable, 'train.py', '--variant', 'n', '--nc', '2', '--batch-size', '4', '--imgsz', '128', '--epochs', '1', '--steps-per-epoch', '6',
+               '--multi-scale', '0.5', '--noval', '--project', str(tmp_path), '--name', 'ms'])
+    assert 'epochs completed' in out
+
+
 def test_bench_py_spawns_its_own_ranks():
     """`python bench.py --gpus 2` with no rendezvous in the environment (how the driver calls it) starts two rank processes itself;
     on a one-GPU box they share the card over gloo."""

@@ -675,3 +675,29 @@ def test_batched_split_reduction_is_bit_identical():
     assert len(plan.reduce_groups) >= 1 and sum(g.n for g in plan.reduce_groups) >= 60 and all(g.ready for g in plan.reduce_groups)
     for a, b in zip(ref, got):
         assert torch.equal(a, b)
+
+
+def test_multi_scale_sizes_reuse_their_cached_plans():
+    """train.py --multi-scale (reference train.py:447-452): the tile size changes between steps; every size gets ONE static plan that is found
+    again when the size comes back (no re-trace, same device buffers), and the losses of a size do not depend on which sizes ran in between."""
+    nc = 8
+    model = build('n', nc).train()
+    eng = model._eng()
+    seen, losses = {}, {}
+    for rnd in range(2):
+        for size in (128, 160, 192):
+            x = synth.synth_images(2, size, seed=size).to(DEV)
+            l, _ = model(x, synth.synth_targets(2, size, nc, nmin=3, nmax=8, seed=size))
+            l['det']['det_loss'].backward()
+            plan = eng.last_plan
+            if rnd == 0:
+                seen[size] = plan
+            else:
+                assert plan is seen[size], f'{size}: the plan was rebuilt'
+            losses.setdefault(size, []).append(float(l['det']['det_loss'].detach()))
+            for p in model.parameters():
+                p.grad = None
+    assert len({id(p) for p in seen.values()}) == 3 and sum(1 for p in eng.plans.values() if p.training) == 3
+    # train-mode BatchNorm statistics moved between the rounds (running stats only: the batch statistics are the batch's own): same loss
+    for size, (a, b) in losses.items():
+        assert abs(a - b) < 1e-4 * abs(a), (size, a, b)

@@ -23,6 +23,7 @@ import argparse
 import json
 import math
 import os
+import random
 import sys
 import time
 from copy import deepcopy
@@ -178,6 +179,12 @@ def train(hyp, opt, device):
         for i, (imgs, targets) in enumerate(loader):
             ni = i + nb * epoch
             imgs = torch.stack(list(imgs)).to(device, non_blocking=True)
+            if opt.multi_scale > 0.0:                                  # train.py:447-452: a random size within +/- multi_scale of imgsz, multiple of the stride
+                sz = random.randrange(int(imgsz * (1 - opt.multi_scale)), int(imgsz * (1 + opt.multi_scale)) + gs) // gs * gs
+                sf = sz / max(imgs.shape[2:])
+                if sf != 1:
+                    ns = [math.ceil(v * sf / gs) * gs for v in imgs.shape[2:]]
+                    imgs, targets = rescale_train_batch(imgs, targets, ns)
             if ni <= nw:                                               # warm-up (train.py:436-444)
                 xi = [0, nw]
                 accumulate = max(1, round(float(torch.tensor(ni / nw * (nbs / opt.batch_size - 1) + 1).clamp(min=1)))) if nbs > opt.batch_size else 1
@@ -240,6 +247,7 @@ def argument_parser():
     p = argparse.ArgumentParser()
     p.add_argument('--weights', default='', help='initial weights: this build\'s or the reference\'s checkpoint, or a bare state_dict')
     p.add_argument('--cfg', default='', help='model.yaml path in the metayolo schema (backbone / fpn / headers); overrides --variant / --nc')
+    p.add_argument('--multi-scale', type=float, default=0.0, help='vary img-size +/- multi-scale%% (train.py:610): every size gets its own cached plan')
     p.add_argument('--variant', default='s', help='n | s | m | l | n6 | m6 | l6 (stock depth/width multiples in the metayolo schema)')
     p.add_argument('--nc', type=int, default=8)
     p.add_argument('--hyp', default='', help='hyperparameters yaml (train keys + one sub-dict per header tag); defaults to the YOLOv5 scratch values')
@@ -267,6 +275,18 @@ def argument_parser():
     p.add_argument('--name', default='exp')
     p.add_argument('--exist-ok', action='store_true')
     return p
+
+
+def rescale_train_batch(imgs, tgts, size):
+    """train.py:72-80: bilinear resize of the tile batch; the boxes are normalised in training, only the recorded sizes change.
+    Every distinct size gets its own static plan (engine plan cache, the oldest evicted beyond its capacity)."""
+    imgs = torch.nn.functional.interpolate(imgs, size=size, mode='bilinear', align_corners=False)
+    for tgt in tgts:
+        tgt['size'] = torch.tensor(size, dtype=tgt['size'].dtype) if torch.is_tensor(tgt['size']) else type(tgt['size'])(size)
+        for anns in tgt['anns'].values():
+            for a in anns:
+                a['size'] = torch.tensor(size, dtype=a['size'].dtype) if torch.is_tensor(a['size']) else type(a['size'])(size)
+    return imgs, tgts
 
 
 def main(opt):
