@@ -33,7 +33,7 @@ const OptDef g_opt_def[HDY_OPT_COUNT] = {
     {"HDY_NO_CLASS_WALK", 0, true}, {"HDY_NO_CONV3X3", 0, true}, {"HDY_C3_GRID", 0, false}, {"HDY_NO_CONV3X3S2", 0, true},
     {"HDY_NO_DGRAD_S2", 0, true}, {"HDY_TILE_INTERLEAVE", 1, false}, {"HDY_NO_BIG_TILES", 0, true}, {"HDY_NO_STEM_KERNEL", 0, true},
     {"HDY_WGRAD_BLOCKS", 512, false}, {"HDY_NO_STEM_WGRAD", 0, true}, {"HDY_NO_WGRAD3X3", 0, true}, {"HDY_WGRAD3X3_S2", 0, true},
-    {"HDY_LOSS_GRID", 2048, false}, {"HDY_NO_DEEP", 0, true}, {"HDY_NO_WGRAD_S2", 0, true}, {"HDY_DEEP_BN", 0, false}, {"HDY_DEEP_DEBUG", 0, false}, {"HDY_DEEP_ALL", 1, false}, {"HDY_F1X1_SMALL", 0, false}, {"HDY_DEEP_MIN_TILES", 160, false},
+    {"HDY_LOSS_GRID", 2048, false}, {"HDY_NO_DEEP", 0, true}, {"HDY_NO_WGRAD_S2", 0, true}, {"HDY_NO_WGRAD_DEEP", 0, true}, {"HDY_WGRAD_DEEP_1X1", 0, false}, {"HDY_WGRAD_DEEP_S1", 0, false}, {"HDY_DEEP_BN", 0, false}, {"HDY_DEEP_DEBUG", 0, false}, {"HDY_DEEP_ALL", 1, false}, {"HDY_F1X1_SMALL", 0, false}, {"HDY_DEEP_MIN_TILES", 160, false},
 };
 std::atomic<int> g_opt[HDY_OPT_COUNT];
 std::once_flag g_opt_once;
@@ -394,6 +394,10 @@ size_t hdy_conv_wgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, 
         const size_t b3 = hdy_wgrad3x3_workspace_bytes(N, Ho, Wo, C, K, stride, dtype);
         if (b3 > bytes) bytes = b3;
     }
+    if (!stem) {                                                       // deep-pipelined 256 x 256 kernel: one slab per pixel split of its own plan
+        const size_t bd = hdy_wgrad_deep_workspace_bytes(N, H, W, Ho, Wo, C, K, R, S, stride, dtype);
+        if (bd > bytes) bytes = bd;
+    }
     return bytes;
 }
 
@@ -421,9 +425,14 @@ int hdy_conv_wgrad(const void* x, int ldx, const void* dy, int lddy, int N, int 
     const int Q = a.TH * a.TW * a.C;
     const int stem_grid = stem ? hdy_wgrad_stem_grid(N, a.Ho, a.Wo, K, dtype) : 0;
     int rc;
-    if (!stem && R == 3 && S == 3 && pad == 1 &&
+    if (!stem && hdy_opt(HDY_OPT_WGRAD_DEEP_S1) &&
+        hdy_wgrad_deep_try(x, ldx, dy, lddy, N, H, W, a.Ho, a.Wo, C, K, R, S, stride, pad, a.partial, dtype, (hipStream_t)stream, &a.splits, &rc)) {
+        // deep-pipelined kernel ahead of the patch-resident one (A/B switch)
+    } else if (!stem && R == 3 && S == 3 && pad == 1 &&
         hdy_wgrad3x3_try(x, ldx, dy, lddy, N, H, W, a.Ho, a.Wo, C, K, stride, a.partial, dtype, (hipStream_t)stream, &a.splits, &rc)) {
         // patch-resident kernel launched (conv_wgrad3x3.hip)
+    } else if (!stem && hdy_wgrad_deep_try(x, ldx, dy, lddy, N, H, W, a.Ho, a.Wo, C, K, R, S, stride, pad, a.partial, dtype, (hipStream_t)stream, &a.splits, &rc)) {
+        // deep-pipelined 256 x 256 kernel launched (conv_wgrad_deep.hip)
     } else if (stem_grid > 0) {
         a.splits = stem_grid;
         rc = hdy_wgrad_stem_launch(a, stem_grid, (hipStream_t)stream);

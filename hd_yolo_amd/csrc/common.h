@@ -34,6 +34,9 @@ enum HdyOption {
     HDY_OPT_LOSS_GRID,         // HDY_LOSS_GRID: workgroups of the detection loss' dense pass (default 2048)
     HDY_OPT_NO_DEEP,           // HDY_NO_DEEP: deep-pipelined 256-row implicit GEMM off (generic kernel instead)
     HDY_OPT_NO_WGRAD_S2,       // HDY_NO_WGRAD_S2: tap-walking stride-2 3x3 weight gradient off
+    HDY_OPT_NO_WGRAD_DEEP,     // HDY_NO_WGRAD_DEEP: deep-pipelined 256 x 256 weight gradient off (generic weight gradient instead)
+    HDY_OPT_WGRAD_DEEP_1X1,    // HDY_WGRAD_DEEP_1X1: the deep-pipelined weight gradient also takes 1x1 layers (measured slower at yolov5s sizes)
+    HDY_OPT_WGRAD_DEEP_S1,     // HDY_WGRAD_DEEP_S1: ... and the 3x3 / stride-1 layers before the patch-resident kernel
     HDY_OPT_DEEP_BN,           // HDY_DEEP_BN: column tile of the deep-pipelined kernel (0 = by shape, 128, 256)
     HDY_OPT_DEEP_DEBUG,        // HDY_DEEP_DEBUG: timing ablations of the deep-pipelined kernel (bit mask, results wrong; measurement only)
     HDY_OPT_DEEP_ALL,          // HDY_DEEP_ALL: 1 (default) the deep-pipelined kernel takes multi-tap (3x3) layers too, 0 the 1x1 layers only

@@ -89,6 +89,9 @@ int hdy_wgrad_plan(int K, int Q, long long P, int dtype, int* splits, int* pix_p
 size_t hdy_wgrad3x3_workspace_bytes(int N, int Ho, int Wo, int C, int K, int stride, int dtype);
 int hdy_wgrad3x3_try(const void* x, int ldx, const void* dy, int lddy, int N, int Hin, int Win, int Ho, int Wo, int C, int K, int stride, float* partial,
                      int dtype, hipStream_t st, int* splits, int* rc);
+size_t hdy_wgrad_deep_workspace_bytes(int N, int Hin, int Win, int Ho, int Wo, int C, int K, int R, int S, int stride, int dtype);
+int hdy_wgrad_deep_try(const void* x, int ldx, const void* dy, int lddy, int N, int Hin, int Win, int Ho, int Wo, int C, int K, int R, int S, int stride,
+                       int pad, float* partial, int dtype, hipStream_t st, int* splits, int* rc);
 int hdy_conv_igemm_stat_grid(long long M, int K, int taps, int ncls);
 int hdy_dgrad3x3s2_try(const ConvArgs& a, int dtype, hipStream_t st, int* rc);
 int hdy_conv3x3s2_c32_try(const ConvArgs& a, int dtype, int out_f32, hipStream_t st, int* rc);

@@ -850,3 +850,40 @@ def test_specialised_kernel_agrees_with_generic_beyond_one_grid(case):
         assert_close(from_dev_nhwc(res[0].to(dt)), ref, TOL[dt], f'{name} vs torch')
         ulp = (res[0] - res[1]).abs() / (res[1].abs().clamp_min(2.0 ** -10) * 2.0 ** -7)
         assert ulp.max().item() <= 1.01, f'{name}: {ulp.max().item():.2f} bf16 ulps from the generic kernel'
+
+
+WGRAD_DEEP_CASES = [
+    # N, H, W, C, K, R, stride, pad — shapes of the deep-pipelined weight gradient (C % 64 == 0, K % 128 == 0, K >= 256, >= 8192 output pixels)
+    (8, 40, 40, 256, 256, 1, 1, 0),      # one 256 x 256 tile, 50 pixel splits
+    (4, 96, 96, 128, 256, 3, 2, 1),      # 3x3 / stride 2: Q = 1152 = 4.5 column tiles, taps that leave the image
+    (4, 96, 96, 64, 256, 3, 2, 1),       # C = 64: one tap per 64-column sub-tile, Q = 576
+    (8, 32, 32, 128, 384, 1, 1, 0),      # K = 1.5 row tiles, Q = 128: half a column tile
+    (3, 53, 53, 64, 256, 1, 1, 0),       # pixel count not a multiple of 64: the last stage of the last split is ragged
+    (2, 72, 72, 64, 256, 5, 1, 2),       # 25 taps (Q = 1600), stride 1 (3x3 / stride 1 belongs to the patch-resident kernel)
+]
+
+
+@pytest.mark.parametrize('case', WGRAD_DEEP_CASES)
+def test_deep_pipelined_weight_gradient(case):
+    """conv_wgrad_deep.hip (256 x 256 output tile, pixels streamed through conv_deep's pipeline, both operands as transposed LDS reads):
+    stacked gradients (grad_a / grad_b), accumulate, pitched x and dy, against torch autograd on the CPU — and against the generic kernel on
+    the same operands (same products, different summation order: 1e-3 of the gradient's scale)."""
+    N, H, W, C, K, R, stride, pad = case
+    dt = torch.bfloat16
+    with _lib.option('HDY_WGRAD_DEEP_1X1', 1):
+        _, _, log_w = conv_case(case, dt)
+    assert 'wgrad_deep' in log_w, log_w
+    x = q(rnd((N, C, H, W), 21), dt)
+    Ho, Wo = ops.out_dim(H, R, stride, pad), ops.out_dim(W, R, stride, pad)
+    dy = q(rnd((N, K, Ho, Wo), 22), dt)
+    xd, dyd = to_dev_nhwc(x, dt), to_dev_nhwc(dy, dt)
+    res = []
+    for off in (0, 1):
+        with _lib.option('HDY_NO_WGRAD_DEEP', off), _lib.option('HDY_WGRAD_DEEP_1X1', 1):
+            ws = torch.empty(ops.wgrad_ws_bytes(N, H, W, C, K, R, R, stride, pad, dt) // 4 + 1, dtype=torch.float32, device=DEV)
+            g = torch.zeros((K, C, R, R), dtype=torch.float32, device=DEV)
+            _lib.dispatch_log(reset=True)
+            ops.run([ops.rec_conv_wgrad(xd, dyd, g, None, R, R, stride, pad, ws)])
+            assert ('wgrad_deep' in _lib.dispatch_log(reset=True)) == (off == 0)
+            res.append(g.cpu())
+    assert_close(res[0], res[1], 1e-3, 'deep vs generic weight gradient')
