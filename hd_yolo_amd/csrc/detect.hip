@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs p) {
         const float* src = p.det + b * p.sb + a * p.sa + y * p.sy + x * p.sx;
         float* dst = p.out + ((size_t)b * p.rows_per_image + p.row_offset + ((size_t)a * p.ny + y) * p.nx + x) * (p.no + 1);
         for (int o = 0; o < p.no; ++o) {
-            const float s = 1.0f / (1.0f + expf(-src[o]));
+            const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-src[o]));      // v_exp_f32 + v_rcp_f32, the same expression as the tiled kernel (bit-identical rows)
             float v = s;
             if (o == 0) v = (s * 2.0f - 0.5f + (float)x) * p.stride;
             else if (o == 1) v = (s * 2.0f - 0.5f + (float)y) * p.stride;
@@ -71,6 +71,32 @@ __global__ __launch_bounds__(256) void decode_tile_kernel(const DecodeArgs p, in
         const float4* src = (const float4*)(p.det + base * ld);
         for (int i = threadIdx.x; i < np * (ld / 4); i += 256) ((float4*)tile)[i] = src[i];
         __syncthreads();
+        // thread -> (pixel = t >> 4, output column = t & 15): no division in the value loop (the row length no + 1 = 14 is not a power of two: the
+        // j / row, gp / hw, rem % nx of the first version were most of its instructions), pixel coordinates once per pixel, sigmoid as
+        // v_exp_f32 + v_rcp_f32 (1-2 ulp: the box / score tensors are pinned to 1e-4 relative)
+        if (row <= 16) {
+            const int o = threadIdx.x & 15;
+            for (int px = threadIdx.x >> 4; px < np; px += 16) {
+                const long long gp = base + px;
+                const int b = (int)(gp / hw), rem = (int)(gp - (long long)b * hw);
+                const int gy = rem / p.nx, gx = rem - gy * p.nx;
+                if (o < row) {
+                    float* dst = p.out + ((size_t)b * p.rows_per_image + p.row_offset + rem) * row + o;
+                    for (int a = 0; a < p.na; ++a) {
+                        float v = p.level_id;
+                        if (o < p.no) {
+                            const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-tile[px * ld + a * p.no + o]));
+                            v = s;
+                            if (o == 0) v = (s * 2.0f - 0.5f + (float)gx) * p.stride;
+                            else if (o == 1) v = (s * 2.0f - 0.5f + (float)gy) * p.stride;
+                            else if (o == 2) { const float q = s * 2.0f; v = q * q * p.anchor_w[a]; }
+                            else if (o == 3) { const float q = s * 2.0f; v = q * q * p.anchor_h[a]; }
+                        }
+                        dst[(size_t)a * hw * row] = v;
+                    }
+                }
+            }
+        } else
         for (int a = 0; a < p.na; ++a) {
             for (int j = threadIdx.x; j < np * row; j += 256) {
                 const int px = j / row, o = j - px * row;
@@ -78,7 +104,7 @@ __global__ __launch_bounds__(256) void decode_tile_kernel(const DecodeArgs p, in
                 const int b = (int)(gp / hw), rem = (int)(gp - (long long)b * hw);
                 float v = p.level_id;
                 if (o < p.no) {
-                    const float s = 1.0f / (1.0f + expf(-tile[px * ld + a * p.no + o]));
+                    const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-tile[px * ld + a * p.no + o]));
                     v = s;
                     if (o == 0) v = (s * 2.0f - 0.5f + (float)(rem % p.nx)) * p.stride;
                     else if (o == 1) v = (s * 2.0f - 0.5f + (float)(rem / p.nx)) * p.stride;
