@@ -111,8 +111,10 @@ __global__ __launch_bounds__(NTHR, 2) void conv_deep_kernel(const ConvArgs p) {
         }
         return;
     }
-    const int my_tiles = (mtiles - mt0 + mstep - 1) / mstep;
-    const int nkt = p.Kdp >> 6;                                   // K-tiles per output tile
+    // stride-2 data gradient: the four parity classes of a spatial tile back to back (tile j -> m-tile j >> 2, class j & 3), each with its
+    // own tap window, K-tile count and packed filter block; the K-tile stream runs across them like across any other tile boundary
+    const bool walk = p.ncls > 1;
+    const int my_tiles = (mtiles - mt0 + mstep - 1) / mstep * (walk ? 4 : 1);
     const int n0 = nt * BN;
 
     // ------------------------------------------------------------------ loader (conv_igemm.hip's descriptor loader, 4 A rows per thread)
@@ -127,17 +129,31 @@ __global__ __launch_bounds__(NTHR, 2) void conv_deep_kernel(const ConvArgs p) {
     __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, OOB, 0x00020000);
     // filter rows beyond the packed block (last column tile of a K that is not a multiple of BN) fail the range check: zeros
     const unsigned wbytes = (unsigned)((size_t)((p.K + p.bn - 1) / p.bn * p.bn) * p.Kdp * 2);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, wbytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, wbytes, 0x00020000);
     constexpr int BR = BN / 64;                                   // filter rows per thread
     unsigned woff[BR];
 #pragma unroll
     for (int i = 0; i < BR; ++i) woff[i] = (unsigned)(((n0 + r0 + 64 * i) * p.Kdp) * 2 + lc * 16);
     int ld_j = 0, ld_kt = 0, ld_buf = 0;                          // loader position: tile number, K-tile inside it, ring buffer
-    int s_th = p.dh0 - p.uh0, s_tw = p.dw0 - p.uw0, s_cb = 0;
-    const int l_tw0 = s_tw, l_TW = l_tw0 + p.TW;
+    int l_th0 = p.dh0 - p.uh0, l_tw0 = p.dw0 - p.uw0, l_TW = l_tw0 + p.TW, l_nkt = p.Kdp >> 6;
+    int s_th = l_th0, s_tw = l_tw0, s_cb = 0;
     bool ld_live = true;
 
     auto loader_set_tile = [&](int j) {
+        if (walk) {
+            const int cls = j & 3;
+            j >>= 2;
+            l_th0 = p.c_dh[cls] - p.uh0; l_tw0 = p.c_dw[cls] - p.uw0;
+            l_TW = l_tw0 + p.c_TW[cls];
+            l_nkt = p.c_nkb[cls];
+            const int kdp = l_nkt << 6;
+            rw = __builtin_amdgcn_make_buffer_rsrc((void*)((const bf16_t*)p.w + p.c_w[cls]), 0,
+                                                   (unsigned)((size_t)((p.K + p.bn - 1) / p.bn * p.bn) * kdp * 2), 0x00020000);
+#pragma unroll
+            for (int i = 0; i < BR; ++i) woff[i] = (unsigned)(((n0 + r0 + 64 * i) * kdp) * 2 + lc * 16);
+            s_th = l_th0; s_tw = l_tw0;
+            if (cls != 0) return;                                 // same pixels as the class before: the row offsets and tap bits stand
+        }
         const int mb = (mt0 + j * mstep) << 8;
         // lanes 0..31 own the wave's 32 rows: row 8 * wave + (lane & 7) + 64 * ((lane >> 3) & 3)
         const int m = mb + 8 * wave + (lane & 7) + 64 * ((lane >> 3) & 3);
@@ -202,9 +218,9 @@ __global__ __launch_bounds__(NTHR, 2) void conv_deep_kernel(const ConvArgs p) {
     auto loader_advance = [&]() {                                 // after the last unit of the loader's K-tile
         if (!ld_live) return;
         ld_buf = ld_buf + 1 == G::NB ? 0 : ld_buf + 1;
-        if (++ld_kt == nkt) {
+        if (++ld_kt == l_nkt) {
             ld_kt = 0;
-            s_th = p.dh0 - p.uh0; s_tw = l_tw0; s_cb = 0;
+            s_th = l_th0; s_tw = l_tw0; s_cb = 0;
             if (++ld_j < my_tiles) loader_set_tile(ld_j);
             else ld_live = false;
         } else {
@@ -311,7 +327,8 @@ __global__ __launch_bounds__(NTHR, 2) void conv_deep_kernel(const ConvArgs p) {
 
     // the asm reads name their destinations as outputs; the wait below is a barrier for the scheduler (rule 18 of the guide)
     for (int j = 0; j < my_tiles; ++j) {
-        const int m0 = (mt0 + j * mstep) << 8;
+        const int m0 = (mt0 + (walk ? j >> 2 : j) * mstep) << 8;
+        const int nkt = walk ? p.c_nkb[j & 3] : p.Kdp >> 6;          // K-tiles of this output tile
         const unsigned long long t_a = (dbg & 32) ? __builtin_readcyclecounter() : 0ull;
         for (int kt = 0; kt < nkt; ++kt) {
             if constexpr (BN == 256) {
@@ -475,6 +492,13 @@ __global__ __launch_bounds__(NTHR, 2) void conv_deep_kernel(const ConvArgs p) {
                         o.i = odd ? i32x4{(int)r0_, (int)r1_, (int)pk[1][0], (int)pk[1][1]} : i32x4{(int)pk[0][0], (int)pk[0][1], (int)r0_, (int)r1_};
                         const int mg = m0 + a * 128 + (BN == 256 ? wr * 64 : wr * 32) + m * 16 + fr;
                         const int kc = n0 + cb + cl;
+                        size_t opix = (size_t)mg;
+                        if (walk) {                                // class pixel (n, oi, oj) -> its place in the strided output image
+                            const int mc = min(mg, p.M - 1);
+                            const int n = (int)fdiv((unsigned)mc, p.mg_howo, p.sh_howo), rem = mc - n * HoWo;
+                            const int oi = (int)fdiv((unsigned)rem, p.mg_wo, p.sh_wo), oj = rem - oi * p.Wo;
+                            opix = ((size_t)n * p.Hout + (p.c_oh[j & 3] + oi * p.oh_mul)) * p.Wout + (p.c_ow[j & 3] + oj * p.ow_mul);
+                        }
                         if (mg < p.M && kc < p.K) {
                             if (p.res || p.accumulate) {
                                 float f[8];
@@ -482,20 +506,20 @@ __global__ __launch_bounds__(NTHR, 2) void conv_deep_kernel(const ConvArgs p) {
                                 for (int e = 0; e < 8; ++e) f[e] = (float)o.h[e];
                                 if (p.res) {
                                     V16 q;
-                                    q.i = *(const i32x4*)((const bf16_t*)p.res + (size_t)mg * p.ldr + kc);
+                                    q.i = *(const i32x4*)((const bf16_t*)p.res + opix * p.ldr + kc);
 #pragma unroll
                                     for (int e = 0; e < 8; ++e) f[e] += (float)q.h[e];
                                 }
                                 if (p.accumulate) {
                                     V16 q;
-                                    q.i = *(const i32x4*)(y + (size_t)mg * p.ldy + kc);
+                                    q.i = *(const i32x4*)(y + opix * p.ldy + kc);
 #pragma unroll
                                     for (int e = 0; e < 8; ++e) f[e] += (float)q.h[e];
                                 }
 #pragma unroll
                                 for (int e = 0; e < 8; ++e) o.h[e] = (bf16_t)f[e];
                             }
-                            *(i32x4*)(y + (size_t)mg * p.ldy + kc) = o.i;
+                            *(i32x4*)(y + opix * p.ldy + kc) = o.i;
                         }
                     }
         }
@@ -594,12 +618,12 @@ int deep_launch_epi(const ConvArgs& a, int grid, hipStream_t st) {
 // First version (fragments read at the top of a phase): 1x1 layers 5-17 % faster than conv_igemm.hip, 3x3 layers 3-8 % slower.  With the
 // fragments read one segment ahead: yolov5s train step 12.37 -> 12.17 ms, yolov5l inference network 56.0 -> 49.6 ms with every eligible
 // layer here (HDY_DEEP_ALL = 0 keeps the multi-tap layers on the generic kernel).
-bool deep_shape_ok(long long M, int C, int K, int taps, bool pointwise, bool stats, int* bn_out) {
+bool deep_shape_ok(long long M, int C, int K, int taps, bool pointwise, bool stats, int* bn_out, int classes = 1) {
     if (hdy_opt(HDY_OPT_NO_DEEP)) return false;
     if (!pointwise && !hdy_opt(HDY_OPT_DEEP_ALL)) return false;
     if (C % 64 != 0 || K < 128 || K % 8 != 0) return false;
     const int bn = stats ? 128 : deep_bn(M, K);
-    const long long tiles = (M + 255) / 256 * cdiv(K, bn);
+    const long long tiles = (M + 255) / 256 * cdiv(K, bn) * classes;
     if (tiles < hdy_opt(HDY_OPT_DEEP_MIN_TILES)) return false;     // too few 256-row tiles for 256 CUs: the 128-row kernel spreads wider
     if (bn_out) *bn_out = bn;
     return true;
@@ -625,16 +649,20 @@ int hdy_conv_deep_slabs(long long M, int C, int K, int taps, int pointwise, int 
 
 // called by hdy_conv_igemm_launch after its own validation (a.M, a.Kdp, a.pointwise, union tap window, reciprocals are set)
 int hdy_conv_deep_try(const ConvArgs& a_in, int dtype, int out_f32, hipStream_t st, int* rc) {
-    if (dtype != HDY_BF16 || out_f32 || a_in.ncls > 1 || a_in.nstat > 0 || !a_in.dense_out || a_in.span_pixels || !a_in.vec_out || !a_in.utap) return 0;
+    const bool walk = a_in.ncls > 1;                               // the four-class stride-2 data gradient (validated by the caller)
+    if (dtype != HDY_BF16 || out_f32 || a_in.nstat > 0 || (!a_in.dense_out && !walk) || a_in.span_pixels || !a_in.vec_out || !a_in.utap) return 0;
+    // measured at the yolov5s bench shapes (dy L2-resident, scripts/probes/dgrad_walk.py): 46 / 71 / 31 / 44 us here against 34 / 34 / 23 / 22 us
+    // for conv_igemm.hip's 128-row walk — these layers have 25-100 row tiles of 256 pixels per class, too few for 256 CUs.  Opt-in.
+    if (walk && !hdy_opt(HDY_OPT_DEEP_WALK)) return 0;
     int bn = 0;
-    if (!deep_shape_ok(a_in.M, a_in.C, a_in.K, a_in.TH * a_in.TW, a_in.pointwise != 0, a_in.stats != nullptr, &bn)) return 0;
+    if (!deep_shape_ok(a_in.M, a_in.C, a_in.K, a_in.TH * a_in.TW, a_in.pointwise != 0, a_in.stats != nullptr, &bn, walk ? 4 : 1)) return 0;
     if (a_in.ldx % 8 != 0) return 0;
     ConvArgs a = a_in;
     a.dbg = hdy_opt(HDY_OPT_DEEP_DEBUG);
     a.ntiles = cdiv(a.K, bn);
     // a.bn stays the PACKING tile (rows of the packed filter block are padded to it)
     const int grid = deep_grid(a.M, a.ntiles);
-    hdy_note_dispatch(bn == 256 ? "deep_256x256" : "deep_256x128");
+    hdy_note_dispatch(bn == 256 ? (walk ? "deep_256x256_walk" : "deep_256x256") : (walk ? "deep_256x128_walk" : "deep_256x128"));
     if (bn == 256) *rc = deep_launch_epi<256, false>(a, grid, st);
     else if (a.stats) *rc = deep_launch_epi<128, true>(a, grid, st);
     else *rc = deep_launch_epi<128, false>(a, grid, st);

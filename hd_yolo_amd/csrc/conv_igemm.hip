@@ -839,6 +839,7 @@ int hdy_conv_igemm_launch(ConvArgs a, int dtype, int out_f32, hipStream_t st) {
         HDY_ARG(!a.stats || a.span_pixels || hdy_conv_deep_slabs(a.M, a.C, a.K, a.TH * a.TW, a.pointwise, dtype) == 0,
                 "conv: this shape's statistic slabs were sized for the deep-pipelined kernel, which declined the launch (alignment)");
     }
+    if (a.ncls > 1 && a.nstat == 0 && hdy_conv_deep_try(a, dtype, out_f32, st, &rc)) return rc;      // stride-2 data gradient on the deep pipeline
     if (dtype == HDY_BF16) return out_f32 ? launch_bn<bf16_t, float>(a, st) : launch_bn<bf16_t, bf16_t>(a, st);
     return launch_bn<float, float>(a, st);
 }

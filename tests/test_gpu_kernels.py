@@ -179,7 +179,9 @@ DEEP_CASES = [
     (1, 24, 56, 192, 128, 3, 1, 1),      # three channel blocks per tap
     (3, 40, 40, 256, 512, 1, 1, 0),      # 1x1: four K-tiles per output tile, the stream runs across tiles
     (1, 16, 16, 128, 256, 1, 1, 0),      # exactly one row tile
-    (2, 48, 48, 128, 256, 3, 2, 1),      # stride-2 forward (its data gradient is the class walk of the generic kernel)
+    (2, 48, 48, 128, 256, 3, 2, 1),      # stride-2 forward; its data gradient is the four-class walk on the deep pipeline (1 + 2 + 2 + 4 taps)
+    (2, 40, 40, 256, 512, 3, 2, 1),      # ... with two 128-wide column tiles (one 256-wide)
+    (1, 36, 44, 128, 128, 3, 2, 1),      # ... 396 class pixels: a ragged second row tile
     (2, 20, 20, 64, 384, 1, 1, 0),       # K = 1.5 column tiles of 256 / 3 of 128; one K-tile per output tile
     (1, 20, 20, 64, 136, 3, 1, 1),       # K not a multiple of 16: ragged last column tile
     (8, 96, 96, 64, 128, 1, 1, 0),       # 288 row tiles on 256 workgroups: some walk two tiles, one K-tile each
@@ -194,11 +196,15 @@ def test_deep_pipelined_conv(case, bn):
     HDY_DEEP_MIN_TILES = 1 sends them to it; both column tiles (HDY_DEEP_BN); forward with BatchNorm sums, epilogue with scale / shift /
     SiLU / accumulate, stride-1 data gradient with accumulate — against torch fp32 on the CPU, and the dispatch log must name the kernel"""
     N, H, W, C, K, R, stride, pad = case
-    with _lib.option('HDY_DEEP_MIN_TILES', 1), _lib.option('HDY_DEEP_BN', bn), _lib.option('HDY_DEEP_ALL', 1):
+    with _lib.option('HDY_DEEP_MIN_TILES', 1), _lib.option('HDY_DEEP_BN', bn), _lib.option('HDY_DEEP_ALL', 1), _lib.option('HDY_DEEP_WALK', 1):
         log_fwd, log_dgrad, _ = conv_case(case, torch.bfloat16)
     assert log_fwd == ['deep_256x128'], log_fwd                  # statistics: 128-wide instances
     if stride == 1 and K % 64 == 0 and C >= 128:
         assert log_dgrad and log_dgrad[0].startswith('deep_256x'), log_dgrad
+    if stride == 2 and K % 64 == 0 and C >= 128:
+        assert log_dgrad and log_dgrad[0].startswith('deep_256x') and log_dgrad[0].endswith('_walk'), log_dgrad
+        with _lib.option('HDY_DEEP_MIN_TILES', 1):
+            assert conv_case(case, torch.bfloat16)[1][0].startswith('igemm_')      # default: the generic kernel's walk (HDY_DEEP_WALK = 0)
     # A/B: the same forward through the generic kernel agrees to the last bf16 rounding (both accumulate in fp32 over the same k order per tap)
     x = q(rnd((N, C, H, W), 11), torch.bfloat16)
     xd = to_dev_nhwc(x, torch.bfloat16)
