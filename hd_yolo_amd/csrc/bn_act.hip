@@ -129,50 +129,56 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const ST* __restrict__
     const int k = blockIdx.x * FCL + cl;
     if (count_dev) count = *count_dev;                   // SyncBatchNorm: the all-reduced element count
     double s = 0.0, ss = 0.0;
+    // the whole kernel is one chain of load latencies (each a round trip to another XCD's slabs): the parameters the last stage needs are
+    // requested first, and the slabs in batches of 8 per lane — 16 loads in flight, out-of-range slots clamped and weighted 0 so that the
+    // batch has no branch (a tail loop of single loads cost a round trip per slab: 3-4 of them for the usual 100-250 slabs)
+    const bool fin = tl == 0 && k < K;
+    const bool second = k >= bn.Ka;                      // channels of the second BatchNorm of a pair
+    const int kk = second ? k - bn.Ka : k;
+    float* const rmean = second ? bn.rmean_b : bn.rmean;
+    float* const rvar = second ? bn.rvar_b : bn.rvar;
+    float p_gamma = 0.f, p_beta = 0.f, p_rmean = 0.f, p_rvar = 0.f;
+    if (fin) {
+        p_gamma = (second ? bn.gamma_b : bn.gamma)[kk];
+        p_beta = (second ? bn.beta_b : bn.beta)[kk];
+        if (rmean) { p_rmean = rmean[kk]; p_rvar = rvar[kk]; }
+    }
     if (k < K) {
-        // the whole kernel is one chain of load latencies: keep 8 independent loads in flight per lane
-        int t = tl;
-        for (; t + 96 < mtiles; t += 128) {
-            ST a[4], b[4];
+        for (int t = tl; t < mtiles; t += 8 * FTL) {
+            ST a[8], b[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                a[u] = stats[((size_t)(t + 32 * u) * 2 + 0) * stats_ld + k];
-                b[u] = stats[((size_t)(t + 32 * u) * 2 + 1) * stats_ld + k];
+            for (int u = 0; u < 8; ++u) {
+                const int tt = min(t + FTL * u, mtiles - 1);
+                a[u] = stats[((size_t)tt * 2 + 0) * stats_ld + k];
+                b[u] = stats[((size_t)tt * 2 + 1) * stats_ld + k];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                s += (double)a[u];
-                ss += (double)b[u];
+            for (int u = 0; u < 8; ++u) {
+                const bool live = t + FTL * u < mtiles;
+                s += live ? (double)a[u] : 0.0;
+                ss += live ? (double)b[u] : 0.0;
             }
-        }
-        for (; t < mtiles; t += 32) {
-            s += (double)stats[((size_t)t * 2 + 0) * stats_ld + k];
-            ss += (double)stats[((size_t)t * 2 + 1) * stats_ld + k];
         }
     }
     red[0][tl][cl] = s;
     red[1][tl][cl] = ss;
     __syncthreads();
-    if (tl == 0 && k < K) {
+    if (fin) {
         s = 0.0; ss = 0.0;
         for (int t = 0; t < FTL; ++t) { s += red[0][t][cl]; ss += red[1][t][cl]; }
         const double mean = s / count;
         double var = ss / count - mean * mean;
         if (var < 0.0) var = 0.0;
         const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-        const bool second = k >= bn.Ka;                  // channels of the second BatchNorm of a pair
-        const int kk = second ? k - bn.Ka : k;
-        const float sc = (second ? bn.gamma_b : bn.gamma)[kk] * invstd;
+        const float sc = p_gamma * invstd;
         scale[k] = sc;
-        shift[k] = (second ? bn.beta_b : bn.beta)[kk] - (float)mean * sc;
+        shift[k] = p_beta - (float)mean * sc;
         save_mean[k] = (float)mean;
         save_invstd[k] = invstd;
-        float* rmean = second ? bn.rmean_b : bn.rmean;
-        float* rvar = second ? bn.rvar_b : bn.rvar;
         if (rmean) {
             const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-            rmean[kk] = (1.0f - momentum) * rmean[kk] + momentum * (float)mean;
-            rvar[kk] = (1.0f - momentum) * rvar[kk] + momentum * (float)unbiased;
+            rmean[kk] = (1.0f - momentum) * p_rmean + momentum * (float)mean;
+            rvar[kk] = (1.0f - momentum) * p_rvar + momentum * (float)unbiased;
         }
     }
 }
@@ -324,33 +330,33 @@ __global__ __launch_bounds__(CL * TL) void bn_bwd_finalize_kernel(const float* _
     const int cl = threadIdx.x % CL, tl = threadIdx.x / CL;
     const int k = blockIdx.x * CL + cl;
     double s1 = 0.0, s2 = 0.0;
+    const bool fin = tl == 0 && k < K;
+    float p_mean = 0.f, p_invstd = 0.f;
+    if (fin && mean) { p_mean = mean[k]; p_invstd = invstd[k]; }
     if (k < K) {
-        int t = tl;
-        for (; t + 3 * TL < nblocks; t += 4 * TL) {       // 8 independent loads in flight per lane (see bn_finalize_kernel)
-            float a[4], b[4];
+        for (int t = tl; t < nblocks; t += 8 * TL) {          // 16 independent loads in flight per lane, no tail loop (see bn_finalize_kernel)
+            float a[8], b[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                a[u] = partial[((size_t)(t + TL * u) * 2 + 0) * K + k];
-                b[u] = partial[((size_t)(t + TL * u) * 2 + 1) * K + k];
+            for (int u = 0; u < 8; ++u) {
+                const int tt = min(t + TL * u, nblocks - 1);
+                a[u] = partial[((size_t)tt * 2 + 0) * K + k];
+                b[u] = partial[((size_t)tt * 2 + 1) * K + k];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                s1 += (double)a[u];
-                s2 += (double)b[u];
+            for (int u = 0; u < 8; ++u) {
+                const bool live = t + TL * u < nblocks;
+                s1 += live ? (double)a[u] : 0.0;
+                s2 += live ? (double)b[u] : 0.0;
             }
-        }
-        for (; t < nblocks; t += TL) {
-            s1 += (double)partial[((size_t)t * 2 + 0) * K + k];
-            s2 += (double)partial[((size_t)t * 2 + 1) * K + k];
         }
     }
     red[0][tl][cl] = s1;
     red[1][tl][cl] = s2;
     __syncthreads();
-    if (tl == 0 && k < K) {
+    if (fin) {
         s1 = 0.0; s2 = 0.0;
         for (int t = 0; t < TL; ++t) { s1 += red[0][t][cl]; s2 += red[1][t][cl]; }
-        if (mean) s2 = (double)invstd[k] * (s2 - (double)mean[k] * s1);      // slabs of (SUM du, SUM du*y) from a producer's epilogue
+        if (mean) s2 = (double)p_invstd * (s2 - (double)p_mean * s1);      // slabs of (SUM du, SUM du*y) from a producer's epilogue
         float* const db = k < Ka ? dbeta : dbeta_b;      // parameter gradients of the pair's second module
         float* const dg = k < Ka ? dgamma : dgamma_b;
         const int kk = k < Ka ? k : k - Ka;
