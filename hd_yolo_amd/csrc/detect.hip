@@ -373,6 +373,53 @@ inline int next_pow2(int v) {
 
 }  // namespace
 
+// Tail of Detect.compute_outputs (metayolo/models/yolo_head.py:335-345) for the whole batch in one launch: hierarchical scores (every
+// (child, parent) pair of the class tree in the reference's order: child *= parent, in place on the padded NMS rows), then per kept box
+// score = best class score if it beats conf, else objectness; label = best class + 1, else -100 — written COMPACTED (image b's rows start
+// at the sum of the earlier images' counts, which every workgroup adds up for itself) so that the host splits three tensors instead of
+// slicing 3 x B padded ones.  multi_label: all 1 + nc scores per box and (score > conf) flags.
+__global__ __launch_bounds__(256) void det_outputs_kernel(float* __restrict__ scores, const float* __restrict__ boxes, const int* __restrict__ n_keep,
+                                                          int B, int max_det, int nc, const int* __restrict__ pairs, int npairs, float conf,
+                                                          int multi_label, float* __restrict__ out_boxes, float* __restrict__ out_scores,
+                                                          void* __restrict__ out_labels, int* __restrict__ offsets) {
+    __shared__ int red[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    int part = 0;
+    for (int i = tid; i < b; i += 256) part += n_keep[i];
+    red[tid] = part;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    const int off = red[0], n = n_keep[b], C = 1 + nc;
+    if (offsets && tid == 0) {
+        offsets[b] = off;
+        if (b == B - 1) offsets[B] = off + n;
+    }
+    for (int j = tid; j < n; j += 256) {
+        float* row = scores + ((size_t)b * max_det + j) * C;
+        for (int q = 0; q < npairs; ++q) row[pairs[2 * q]] *= row[pairs[2 * q + 1]];
+        const float* bx = boxes + ((size_t)b * max_det + j) * 4;
+        float* ob = out_boxes + (size_t)(off + j) * 4;
+        ob[0] = bx[0]; ob[1] = bx[1]; ob[2] = bx[2]; ob[3] = bx[3];
+        if (multi_label) {
+            for (int c = 0; c < C; ++c) {
+                out_scores[(size_t)(off + j) * C + c] = row[c];
+                ((unsigned char*)out_labels)[(size_t)(off + j) * C + c] = row[c] > conf ? 1 : 0;
+            }
+        } else {
+            float best = row[1];
+            int arg = 0;
+            for (int c = 1; c < nc; ++c)
+                if (row[1 + c] > best) { best = row[1 + c]; arg = c; }       // first maximum, as torch.max
+            const bool hit = best > conf;
+            out_scores[off + j] = hit ? best : row[0];
+            ((long long*)out_labels)[off + j] = hit ? arg + 1 : -100;
+        }
+    }
+}
+
 extern "C" {
 
 int hdy_decode(const float* det, long long sb, long long sa, long long sy, long long sx, const float* anchor_px, float stride, float* out,
@@ -440,6 +487,17 @@ int hdy_nms_batched(const float* preds, int B, int N, int row, int nc, float con
     (void)hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(NT), smem, (hipStream_t)stream, a);
     HDY_LAUNCH_CHECK("nms");
+    return HDY_OK;
+}
+
+int hdy_det_outputs(float* scores, const float* boxes, const int* n_keep, int B, int max_det, int nc, const int* pairs, int npairs, float conf,
+                    int multi_label, float* out_boxes, float* out_scores, void* out_labels, int* offsets, void* stream) {
+    HDY_ARG(B >= 0 && max_det >= 1 && nc >= 1 && npairs >= 0, "det_outputs: bad sizes");
+    if (B == 0) return HDY_OK;
+    HDY_ARG(scores && boxes && n_keep && out_boxes && out_scores && out_labels && (npairs == 0 || pairs), "det_outputs: null pointer");
+    hipLaunchKernelGGL(det_outputs_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, scores, boxes, n_keep, B, max_det, nc, pairs, npairs, conf, multi_label,
+                       out_boxes, out_scores, out_labels, offsets);
+    HDY_LAUNCH_CHECK("det_outputs");
     return HDY_OK;
 }
 

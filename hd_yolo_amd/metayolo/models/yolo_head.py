@@ -131,6 +131,15 @@ class Detect(nn.Module):
                     res += below
         return res
 
+    def _score_pairs(self, dev):
+        """(child, parent) score columns in the order hierarchical_scores applies them, as an int32 device tensor (cached per device)"""
+        key = (str(dev), tuple((k, tuple(v)) for k, v in self.descendants.items()))
+        cache = self.__dict__.setdefault('_pairs', {})
+        if cache.get('key') != key:
+            pairs = [(c, k) for k, v in self.descendants.items() for c in v]
+            cache['key'], cache['t'] = key, torch.tensor(pairs, dtype=torch.int32, device=dev).reshape(-1, 2)
+        return cache['t']
+
     def hierarchical_scores(self, x: torch.Tensor) -> torch.Tensor:
         """In place: every node's score is multiplied by its ancestors' (default tree: cls *= obj)."""
         for k, v in self.descendants.items():
@@ -230,17 +239,13 @@ class Detect(nn.Module):
         if bs == 0:
             return []
         res = _ops.nms_batched(flat.float().contiguous(), self.nc, conf, self.nms_params['iou_thres'], max_det, min_wh=2.0, class_aware=False)
+        # hierarchical scores, best class / objectness fallback and labels for every kept box, compacted over the batch by ONE launch
+        # (hdy_det_outputs) issued before the sync; the host then splits three tensors instead of slicing 3 x bs padded ones
+        boxes_c, scores_c, labels_c = _ops.det_outputs(res, self.nc, conf, self._score_pairs(flat.device), self.multi_label)
         n_keep = res['n_keep'].tolist()                    # the one D2H sync of the batch
-        scores = self.hierarchical_scores(res['scores'].reshape(bs * max_det, 1 + self.nc))
-        if self.multi_label:
-            out_scores, out_labels = scores.view(bs, max_det, -1), (scores > conf).view(bs, max_det, -1)
-        else:
-            obj = scores[:, 0]
-            cls_scores, cls_labels = scores[:, 1:].max(1)
-            hit = cls_scores > conf
-            out_scores = torch.where(hit, cls_scores, obj).view(bs, max_det)
-            out_labels = torch.where(hit, cls_labels + 1, torch.full_like(cls_labels, -100)).view(bs, max_det)
-        results = [{'boxes': res['boxes'][b, :n], 'scores': out_scores[b, :n], 'labels': out_labels[b, :n]} for b, n in enumerate(n_keep)]
+        total = sum(n_keep)
+        results = [{'boxes': b, 'scores': s, 'labels': l} for b, s, l in
+                   zip(boxes_c[:total].split(n_keep), scores_c[:total].split(n_keep), labels_c[:total].split(n_keep))]
         if compute_masks and sum(n_keep) > 0 and not self.multi_label:
             self.attach_masks(results, res, n_keep, features)
         return results

@@ -618,6 +618,21 @@ def nms_batched(preds, nc, conf_thres, iou_thres, max_det, min_wh=2.0, class_awa
     return {'keep': keep, 'n_keep': n_keep, 'boxes': boxes, 'scores': scores, 'extra': extra[:, :, :nex], 'conf': conf, 'cls': cls}
 
 
+def det_outputs(res, nc, conf_thres, pairs, multi_label=False):
+    """Score / label logic of Detect.compute_outputs on nms_batched's result, compacted over the batch (hdy_det_outputs).  pairs: int32
+    device tensor (npairs, 2) of (child, parent) score columns.  res['scores'] is updated in place (hierarchical products)."""
+    B, max_det = res['boxes'].shape[:2]
+    dev = res['boxes'].device
+    C = 1 + nc
+    boxes = torch.empty((B * max_det, 4), dtype=torch.float32, device=dev)
+    scores = torch.empty((B * max_det, C) if multi_label else (B * max_det,), dtype=torch.float32, device=dev)
+    labels = torch.empty((B * max_det, C) if multi_label else (B * max_det,), dtype=torch.bool if multi_label else torch.int64, device=dev)
+    _lib.call('hdy_det_outputs', res['scores'].data_ptr(), res['boxes'].data_ptr(), res['n_keep'].data_ptr(), B, max_det, nc,
+              pairs.data_ptr() if pairs.numel() else None, pairs.shape[0], float(conf_thres), int(multi_label), boxes.data_ptr(), scores.data_ptr(),
+              labels.data_ptr(), None, stream_ptr())
+    return boxes, scores, labels
+
+
 NMS_LAUNCH_KEEP = 4096          # kept boxes one hdy_nms_boxes launch can hold (its LDS kept-list)
 
 

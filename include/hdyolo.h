@@ -243,6 +243,15 @@ int hdy_nms_batched(const float* preds, int B, int N, int row, int nc, float con
                     long long* keep, int* n_keep, float* out_boxes, float* out_scores, float* out_extra, float* out_conf, int* out_cls,
                     void* workspace, size_t ws_bytes, void* stream);
 
+/* Tail of Detect.compute_outputs (metayolo/models/yolo_head.py:335-345) on hdy_nms_batched's padded rows, whole batch, one launch:
+ * hierarchical scores in place on scores [B][max_det][1 + nc] (pairs: npairs x (child, parent) column indices in the order the reference
+ * applies them: child *= parent), then per kept box score / label (best class if > conf, else objectness / -100; multi_label: all 1 + nc
+ * scores and score > conf flags).  Outputs are COMPACTED: image b's rows start at n_keep[0] + .. + n_keep[b - 1].  out_boxes [T][4],
+ * out_scores [T] (multi_label: [T][1 + nc]), out_labels int64 [T] (multi_label: uint8 [T][1 + nc]) with T >= the total; offsets [B + 1]
+ * (optional) receives the row offsets. */
+int hdy_det_outputs(float* scores, const float* boxes, const int* n_keep, int B, int max_det, int nc, const int* pairs, int npairs, float conf,
+                    int multi_label, float* out_boxes, float* out_scores, void* out_labels, int* offsets, void* stream);
+
 /* torchvision.ops.nms on explicit boxes, as the reference calls it outside nms_per_image (Ensemble.merge, metayolo/models/yolo.py:189-199):
  * boxes_scores [B][N][5] = (x1, y1, x2, y2, score >= 0) fp32; every row is a candidate; keep[B][max_det] row indices in descending
  * score order (stable), -1 padded; n_keep[B].  Same kernel, workspace and max_det limit as hdy_nms_batched. */

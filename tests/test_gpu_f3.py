@@ -217,3 +217,37 @@ def test_inference_on_slide_merges_rois():
     assert (s[:-1] >= s[1:]).all()                                 # NMS order
     again = ops.nms(dup['boxes'], dup['scores'], m.headers['det'].nms_params['iou_thres'])
     assert len(again) == len(dup['boxes'])                         # idempotent: nothing left to suppress
+
+
+@pytest.mark.parametrize('ml', [False, True])
+def test_det_outputs_kernel_equals_the_tensor_expressions(ml):
+    """hdy_det_outputs (hierarchical scores, best class / objectness fallback, labels, compaction over the batch) against the reference's
+    per-image tensor expressions (yolo_head.py:335-345, :473-479) on a three-level class tree, with empty images and ties between classes"""
+    from hd_yolo_amd import ops
+    g = torch.Generator().manual_seed(9)
+    B, max_det, nc = 7, 40, 6
+    n_keep = torch.tensor([5, 0, 40, 1, 0, 17, 33], dtype=torch.int32)
+    scores = torch.rand((B, max_det, 1 + nc), generator=g)
+    scores[2, :, 3] = scores[2, :, 2]                                  # ties: the first maximum wins, as torch.max
+    boxes = torch.rand((B, max_det, 4), generator=g) * 100
+    # tree 0 -> {1 -> {2, 3}, 4, 5 -> {6}}: descendants in the order Detect.get_descendants records them (children before their parent)
+    descendants = {1: [2, 3], 5: [6], 0: [1, 2, 3, 4, 5, 6]}
+    pairs = torch.tensor([(c, k) for k, v in descendants.items() for c in v], dtype=torch.int32, device=DEV)
+    res = {'scores': scores.clone().to(DEV), 'boxes': boxes.to(DEV), 'n_keep': n_keep.to(DEV)}
+    conf = 0.2
+    bx, sc, lb = ops.det_outputs(res, nc, conf, pairs, ml)
+    off = 0
+    for b in range(B):
+        n = int(n_keep[b])
+        x = scores[b, :n].clone()
+        for k, v in descendants.items():
+            x[:, v] *= x[:, k:k + 1]
+        assert torch.equal(bx[off:off + n].cpu(), boxes[b, :n])
+        assert torch.equal(res['scores'][b, :n].cpu(), x)              # in place on the padded rows, like the reference on its own rows
+        if ml:
+            assert torch.equal(sc[off:off + n].cpu(), x) and torch.equal(lb[off:off + n].cpu(), x > conf)
+        elif n:
+            cs, cl = x[:, 1:].max(1)
+            assert torch.equal(sc[off:off + n].cpu(), torch.where(cs > conf, cs, x[:, 0]))
+            assert torch.equal(lb[off:off + n].cpu(), torch.where(cs > conf, cl + 1, torch.full_like(cl, -100)))
+        off += n
