@@ -364,6 +364,130 @@ __global__ __launch_bounds__(256) void det_targets_kernel(const float* __restric
 
 inline size_t a16(size_t v) { return (v + 15) / 16 * 16; }
 
+// ---------------------------------------------------------------- which matched cell feeds the mask branch
+// Reference (metayolo/models/yolo_head.py:231-262): of all cells matched to a target only the one whose decoded box has the best IoU with the
+// truth goes through the mask head, and only when that IoU >= 0.8 (torch_scatter.scatter_max: the FIRST row attaining the maximum, rows
+// ordered level by level and inside a level by (offset variant, anchor, target), which is the candidate index of match_kernel).  The
+// tensor-expression version re-ran the matcher and decoded every level on the host side of ~20 device-to-host syncs per step.
+// Here: mask_iou_kernel enumerates the same candidates, decodes the matched cell with decode_kernel's arithmetic (bit-identical boxes),
+// takes the IoU in input pixels as paired_box_iou does, and keeps per target max(iou bits << 32 | ~order) with one 64-bit atomicMax;
+// mask_pick_kernel (one workgroup) compacts the targets that pass, in target order, into per-level roi lists.
+struct MaskSelArgs {
+    const float* logits[MAXL];   // [B][ny][nx][ldl], channel = a*no + o
+    int ny[MAXL], nx[MAXL];
+    float anc[MAXL][MAXA][2];    // anchors in grid units (the matcher's ratio test)
+    float anc_px[MAXL][MAXA][2]; // anchors in input pixels (decode)
+    float stride[MAXL];
+    int nl, B, na, no, ldl, nt;
+    const float* gts;            // [nt][5] img, cx, cy, w, h (normalised)
+    float anchor_t, min_iou;
+    unsigned long long* key;     // [nt], zeroed by the caller
+};
+
+__global__ __launch_bounds__(256) void mask_iou_kernel(const MaskSelArgs p) {
+    const int l = blockIdx.y;
+    const int na = p.na, nt = p.nt;
+    const int total = 5 * na * nt;
+    const int ny = p.ny[l], nx = p.nx[l];
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int j = idx / (na * nt);
+        const int rem = idx - j * (na * nt);
+        const int a = rem / nt, g = rem - a * nt;
+        const float* gt = p.gts + (size_t)g * 5;
+        const float gx = gt[1] * nx, gy = gt[2] * ny, gw = gt[3] * nx, gh = gt[4] * ny;
+        const float rw = gw / p.anc[l][a][0], rh = gh / p.anc[l][a][1];
+        const float worst = fmaxf(fmaxf(rw, 1.f / rw), fmaxf(rh, 1.f / rh));
+        if (!(worst < p.anchor_t)) continue;
+        float ox = 0.f, oy = 0.f;
+        if (j == 1) { if (!(fmodf(gx, 1.f) < 0.5f && gx > 1.f)) continue; ox = 0.5f; }
+        else if (j == 2) { if (!(fmodf(gy, 1.f) < 0.5f && gy > 1.f)) continue; oy = 0.5f; }
+        else if (j == 3) { const float ix = nx - gx; if (!(fmodf(ix, 1.f) < 0.5f && ix > 1.f)) continue; ox = -0.5f; }
+        else if (j == 4) { const float iy = ny - gy; if (!(fmodf(iy, 1.f) < 0.5f && iy > 1.f)) continue; oy = -0.5f; }
+        int gi = (int)(gx - ox), gj = (int)(gy - oy);
+        gi = min(max(gi, 0), nx - 1);
+        gj = min(max(gj, 0), ny - 1);
+        const int b = (int)gt[0];
+        const float* lp = p.logits[l] + (((size_t)b * ny + gj) * nx + gi) * p.ldl + a * p.no;
+        float sg[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) sg[o] = __builtin_amdgcn_rcpf(1.0f + __expf(-lp[o]));          // decode_kernel's sigmoid
+        const float st = p.stride[l];
+        const float cx = (sg[0] * 2.0f - 0.5f + (float)gi) * st, cy = (sg[1] * 2.0f - 0.5f + (float)gj) * st;
+        const float qw = sg[2] * 2.0f, qh = sg[3] * 2.0f;
+        const float w = qw * qw * p.anc_px[l][a][0], h = qh * qh * p.anc_px[l][a][1];
+        // xywh2xyxy of both boxes, the truth scaled to input pixels afterwards (yolo_head.py:243-244)
+        const float px1 = cx - w / 2, py1 = cy - h / 2, px2 = cx + w / 2, py2 = cy + h / 2;
+        const float tx1 = (gx - gw / 2) * st, ty1 = (gy - gh / 2) * st, tx2 = (gx + gw / 2) * st, ty2 = (gy + gh / 2) * st;
+        const float iw = fmaxf(fminf(px2, tx2) - fmaxf(px1, tx1), 0.f), ih = fmaxf(fminf(py2, ty2) - fmaxf(py1, ty1), 0.f);
+        const float inter = iw * ih;
+        const float a1 = (px2 - px1) * (py2 - py1), a2 = (tx2 - tx1) * (ty2 - ty1);
+        const float iou = inter / (a1 + a2 - inter);
+        if (!(iou >= 0.f)) continue;                              // NaN (two empty boxes) never wins
+        const unsigned order = (unsigned)(l * total + idx);
+        const unsigned long long k = ((unsigned long long)__float_as_uint(iou) << 32) | (unsigned long long)(0xFFFFFFFFu - order);
+        atomicMax(p.key + g, k);
+    }
+}
+
+// one workgroup: the targets whose best cell passes, in target order.  counts[0] = kept, counts[1 + l] = kept at level l;
+// keep_t[k] = target of kept row k; rois[l][i] = (image, x1, y1, x2, y2 in input pixels) of the i-th kept row of level l;
+// order[k] = position of kept row k in the level-by-level concatenation of those lists.
+__global__ __launch_bounds__(256) void mask_pick_kernel(const MaskSelArgs p, int* __restrict__ counts, long long* __restrict__ keep_t,
+                                                        float* __restrict__ rois, long long* __restrict__ order, int* __restrict__ tmp) {
+    __shared__ int wsum[MAXL + 1][4];
+    __shared__ int base[MAXL + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nt = p.nt, nl = p.nl, per_level = 5 * p.na * nt;
+    if (tid <= MAXL) base[tid] = 0;
+    __syncthreads();
+    for (int g0 = 0; g0 < nt; g0 += 256) {
+        const int g = g0 + tid;
+        int lev = -1;
+        if (g < nt) {
+            const unsigned long long k = p.key[g];
+            const float iou = __uint_as_float((unsigned)(k >> 32));
+            if (k != 0ull && iou >= p.min_iou) lev = (int)((0xFFFFFFFFu - (unsigned)k) / (unsigned)per_level);
+        }
+        int pos[MAXL + 1];                                        // [nl]: position among all kept; [l]: among level l's
+#pragma unroll
+        for (int q = 0; q <= MAXL; ++q) {
+            if (q < nl || q == MAXL) {
+                const bool m = q == MAXL ? lev >= 0 : lev == q;
+                const unsigned long long bal = __ballot(m);
+                pos[q] = __popcll(bal & ((1ull << lane) - 1ull));
+                if (lane == 0) wsum[q][wave] = __popcll(bal);
+            }
+        }
+        __syncthreads();
+        if (lev >= 0) {
+            int pk = base[MAXL] + pos[MAXL], pl = base[lev];
+#pragma unroll
+            for (int q = 0; q < MAXL; ++q) if (q == lev) pl += pos[q];
+            for (int w = 0; w < wave; ++w) { pk += wsum[MAXL][w]; pl += wsum[lev][w]; }
+            keep_t[pk] = g;
+            tmp[2 * pk] = lev;
+            tmp[2 * pk + 1] = pl;
+            const float* gt = p.gts + (size_t)g * 5;
+            const float st = p.stride[lev];
+            const float gx = gt[1] * p.nx[lev], gy = gt[2] * p.ny[lev], gw = gt[3] * p.nx[lev], gh = gt[4] * p.ny[lev];
+            float* r = rois + ((size_t)lev * nt + pl) * 5;
+            r[0] = gt[0];
+            r[1] = (gx - gw / 2) * st; r[2] = (gy - gh / 2) * st; r[3] = (gx + gw / 2) * st; r[4] = (gy + gh / 2) * st;
+        }
+        __syncthreads();
+        if (tid <= MAXL && (tid < nl || tid == MAXL)) base[tid] += wsum[tid][0] + wsum[tid][1] + wsum[tid][2] + wsum[tid][3];
+        __syncthreads();
+    }
+    const int nk = base[MAXL];
+    for (int k = tid; k < nk; k += 256) {
+        int off = 0;
+        for (int q = 0; q < tmp[2 * k]; ++q) off += base[q];
+        order[k] = off + tmp[2 * k + 1];
+    }
+    if (tid == 0) counts[0] = nk;
+    if (tid < nl) counts[1 + tid] = base[tid];
+}
+
 }  // namespace
 
 extern "C" {
@@ -454,6 +578,42 @@ int hdy_scale_inplace(void* p, long long n, const float* scale, int dtype, void*
     if (dtype == HDY_BF16) hipLaunchKernelGGL(scale_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (bf16_t*)p, (size_t)n, scale);
     else hipLaunchKernelGGL(scale_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (float*)p, (size_t)n, scale);
     HDY_LAUNCH_CHECK("scale_inplace");
+    return HDY_OK;
+}
+
+// Mask-branch selection for one batch (see mask_iou_kernel): logits / ny / nx / anchors_grid as for hdy_det_loss, anchors_px [nl][na][2] and
+// strides [nl] as for hdy_decode.  Device outputs: counts [1 + nl] ints, keep_t [nt] int64, rois [nl][nt][5] floats, order [nt] int64.
+// workspace: nt * 16 bytes (8-byte aligned).
+int hdy_mask_select(const float* const* logits, int ldl, const int* ny, const int* nx, int nl, int B, int na, int no, const float* anchors_grid,
+                    const float* anchors_px, const float* strides, const float* gts, int nt, float anchor_t, float min_iou, int* counts,
+                    long long* keep_t, float* rois, long long* order, void* workspace, size_t ws_bytes, void* stream) {
+    HDY_ARG(logits && ny && nx && anchors_grid && anchors_px && strides && counts, "mask_select: null pointer");
+    HDY_ARG(nl >= 1 && nl <= MAXL && na >= 1 && na <= MAXA && B >= 1 && nt >= 0 && no >= 5 && ldl >= na * no, "mask_select: bad sizes");
+    HDY_ARG((long long)nl * 5 * na * nt < (1LL << 31), "mask_select: too many targets");
+    hipStream_t st = (hipStream_t)stream;
+    if (nt == 0) {
+        HDY_ARG(hipMemsetAsync(counts, 0, (size_t)(1 + nl) * sizeof(int), st) == hipSuccess, "mask_select: memset failed");
+        return HDY_OK;
+    }
+    HDY_ARG(gts && keep_t && rois && order && workspace && ws_bytes >= (size_t)nt * 16 && ((uintptr_t)workspace & 7) == 0, "mask_select: outputs / workspace missing or too small");
+    MaskSelArgs a = {};
+    for (int l = 0; l < nl; ++l) {
+        HDY_ARG(logits[l] && ny[l] > 0 && nx[l] > 0, "mask_select: level %d missing", l);
+        a.logits[l] = logits[l]; a.ny[l] = ny[l]; a.nx[l] = nx[l]; a.stride[l] = strides[l];
+        for (int i = 0; i < na; ++i)
+            for (int c = 0; c < 2; ++c) {
+                a.anc[l][i][c] = anchors_grid[(l * na + i) * 2 + c];
+                a.anc_px[l][i][c] = anchors_px[(l * na + i) * 2 + c];
+            }
+    }
+    a.nl = nl; a.B = B; a.na = na; a.no = no; a.ldl = ldl; a.nt = nt; a.gts = gts; a.anchor_t = anchor_t; a.min_iou = min_iou;
+    a.key = (unsigned long long*)workspace;
+    HDY_ARG(hipMemsetAsync(a.key, 0, (size_t)nt * 8, st) == hipSuccess, "mask_select: memset failed");
+    const int total = 5 * na * nt;
+    hipLaunchKernelGGL(mask_iou_kernel, dim3(cdiv(total, 256) < 1024 ? cdiv(total, 256) : 1024, nl), dim3(256), 0, st, a);
+    HDY_LAUNCH_CHECK("mask_select iou");
+    hipLaunchKernelGGL(mask_pick_kernel, dim3(1), dim3(256), 0, st, a, counts, keep_t, rois, order, (int*)((char*)workspace + (size_t)nt * 8));
+    HDY_LAUNCH_CHECK("mask_select pick");
     return HDY_OK;
 }
 

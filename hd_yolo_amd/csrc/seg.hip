@@ -277,33 +277,51 @@ __device__ __forceinline__ void src_index(int dst, float scale, int in, int* i0,
 template <typename T>
 __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int N, int Hi, int Wi,
                                                            int Ho, int Wo, int C, float sh, float sw, int accumulate) {
+    // one output row per workgroup trip: the row's source rows and weights once per row, no 64-bit divisions per element (the flat-index
+    // version spent 150 us on a 105 MB output: three 64-bit div / mod per vector)
     constexpr int VE = VT<T>::VE;
     const int VC = C / VE;
-    const long long total = (long long)N * Ho * Wo * VC;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-        const int vc = (int)(idx % VC);
-        long long pix = idx / VC;
-        const int ox = (int)(pix % Wo);
-        pix /= Wo;
-        const int oy = (int)(pix % Ho), n = (int)(pix / Ho);
-        int y0, y1, x0, x1;
-        float ly0, ly1, lx0, lx1;
+    const int rows = N * Ho, per_row = Wo * VC;
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int n = row / Ho, oy = row - n * Ho;
+        int y0, y1;
+        float ly0, ly1;
         src_index(oy, sh, Hi, &y0, &y1, &ly0, &ly1);
-        src_index(ox, sw, Wi, &x0, &x1, &lx0, &lx1);
-        const T* base = x + (size_t)n * Hi * Wi * ldx + vc * VE;
-        float a[VE], b[VE], c[VE], d[VE], o[VE];
-        unpack<T>(*(const i32x4*)(base + ((size_t)y0 * Wi + x0) * ldx), a);
-        unpack<T>(*(const i32x4*)(base + ((size_t)y0 * Wi + x1) * ldx), b);
-        unpack<T>(*(const i32x4*)(base + ((size_t)y1 * Wi + x0) * ldx), c);
-        unpack<T>(*(const i32x4*)(base + ((size_t)y1 * Wi + x1) * ldx), d);
-        T* dst = y + (((size_t)n * Ho + oy) * Wo + ox) * ldy + vc * VE;
-        if (accumulate) unpack<T>(*(const i32x4*)dst, o);
+        const T* r0 = x + ((size_t)n * Hi + y0) * Wi * ldx;
+        const T* r1 = x + ((size_t)n * Hi + y1) * Wi * ldx;
+        T* yrow = y + (size_t)row * Wo * ldy;
+        constexpr int U = 4;                                       // vectors in flight per thread (16 gathers)
+        for (int jb = threadIdx.x; jb < per_row; jb += 256 * U) {
+            i32x4 qa[U], qb[U], qc[U], qd[U];
+            float wx0[U], wx1[U];
 #pragma unroll
-        for (int i = 0; i < VE; ++i) {
-            const float v = ly0 * (lx0 * a[i] + lx1 * b[i]) + ly1 * (lx0 * c[i] + lx1 * d[i]);
-            o[i] = accumulate ? o[i] + v : v;
+            for (int u = 0; u < U; ++u) {
+                const int j = min(jb + 256 * u, per_row - 1);
+                const int ox = VC == 1 ? j : j / VC, vc = j - ox * VC;
+                int x0, x1;
+                src_index(ox, sw, Wi, &x0, &x1, &wx0[u], &wx1[u]);
+                qa[u] = *(const i32x4*)(r0 + (size_t)x0 * ldx + vc * VE);
+                qb[u] = *(const i32x4*)(r0 + (size_t)x1 * ldx + vc * VE);
+                qc[u] = *(const i32x4*)(r1 + (size_t)x0 * ldx + vc * VE);
+                qd[u] = *(const i32x4*)(r1 + (size_t)x1 * ldx + vc * VE);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = jb + 256 * u;
+                if (j >= per_row) break;
+                const int ox = VC == 1 ? j : j / VC, vc = j - ox * VC;
+                float a[VE], b[VE], c[VE], d[VE], o[VE];
+                unpack<T>(qa[u], a); unpack<T>(qb[u], b); unpack<T>(qc[u], c); unpack<T>(qd[u], d);
+                T* dst = yrow + (size_t)ox * ldy + vc * VE;
+                if (accumulate) unpack<T>(*(const i32x4*)dst, o);
+#pragma unroll
+                for (int i = 0; i < VE; ++i) {
+                    const float v = ly0 * (wx0[u] * a[i] + wx1[u] * b[i]) + ly1 * (wx0[u] * c[i] + wx1[u] * d[i]);
+                    o[i] = accumulate ? o[i] + v : v;
+                }
+                *(i32x4*)dst = pack<T>(o);
+            }
         }
-        *(i32x4*)dst = pack<T>(o);
     }
 }
 
@@ -408,6 +426,55 @@ __global__ __launch_bounds__(256) void bilinear_bwd_axis_kernel(const T* __restr
     }
 }
 
+// The W pass of the resize backward (inner == 1) with the gradient row staged in LDS: one workgroup per (n, output row), the row is read from
+// HBM exactly once (coalesced 16-byte loads), then thread i gathers its candidates from LDS in the SAME order and with the same weights as
+// bilinear_bwd_axis_kernel (bit-identical results).  The global-gather version read every gradient vector ~2.2 times through 18 dependent
+// 16-byte loads per thread: 0.8 ms for the 105 MB gradient of the segmentation logits (16 x 1280 x 1280 x 4 fp32); this one 0.05 ms.
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_bwd_w_lds_kernel(const T* __restrict__ dy, int lddy, T* __restrict__ dx, int lddx, int rows, int Ai, int Ao,
+                                                                 int C, float scale, int accumulate) {
+    constexpr int VE = VT<T>::VE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char bw_smem[];
+    i32x4* stage = (i32x4*)bw_smem;                               // [Ao][VC] vectors
+    const int VC = C / VE, nvec = Ao * VC;
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+        const T* src = dy + (size_t)row * Ao * lddy;
+        for (int j = threadIdx.x; j < nvec; j += 256) {
+            const int a = j / VC, vc = j - a * VC;
+            stage[j] = *(const i32x4*)(src + (size_t)a * lddy + vc * VE);
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < Ai * VC; j += 256) {
+            const int i = j / VC, vc = j - i * VC;
+            int lo, hi;
+            dst_range(i, scale, Ao, &lo, &hi);
+            float acc[VE];
+#pragma unroll
+            for (int e = 0; e < VE; ++e) acc[e] = 0.f;
+            for (int a = lo; a <= hi; ++a) {
+                int i0, i1;
+                float l0, l1;
+                src_index(a, scale, Ai, &i0, &i1, &l0, &l1);
+                const float w = (i0 == i ? l0 : 0.f) + (i1 == i ? l1 : 0.f);
+                if (w == 0.f) continue;
+                float g[VE];
+                unpack<T>(stage[a * VC + vc], g);
+#pragma unroll
+                for (int e = 0; e < VE; ++e) acc[e] += w * g[e];
+            }
+            T* dst = dx + ((size_t)row * Ai + i) * lddx + vc * VE;
+            if (accumulate) {
+                float p[VE];
+                unpack<T>(*(const i32x4*)dst, p);
+#pragma unroll
+                for (int e = 0; e < VE; ++e) acc[e] += p[e];
+            }
+            *(i32x4*)dst = pack<T>(acc);
+        }
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------- Softmax2d + soft dice
 // logits fp32 [N][H][W][ldl] (nc classes), targets fp32 [N][nc][H][W] (the reference stacks per-roi masks: panoptic_seg.py:36).
 // pass 1: per (n, slice): prod[c] = SUM t*p, plus[c] = SUM (t + p)  -> partial[n][s][2][nc]
@@ -424,35 +491,51 @@ __global__ __launch_bounds__(256) void dice_reduce_kernel(const float* __restric
     float prod[MAXC], plus[MAXC];
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) prod[c] = plus[c] = 0.f;
-    for (int p = p0 + threadIdx.x; p < p1; p += 256) {
+    // four pixels' loads in flight per thread (the one-pixel loop was a chain of HBM round trips: 254 us for 184 MB), processed in the same
+    // order as before: the sums are bit-identical
+    constexpr int U = MAXC <= 8 ? 4 : 1;
+    for (int pb = p0 + threadIdx.x; pb < p1; pb += 256 * U) {
+      float lq[U][MAXC], tq[U][MAXC];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int p = min(pb + 256 * u, p1 - 1);
         const float* lp = logits + ((size_t)n * HW + p) * ldl;
-        float l[MAXC];
         if (MAXC == 4 && (ldl & 3) == 0) {
             const f32x4 v = *(const f32x4*)lp;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) l[c] = v[c];
+            for (int c = 0; c < 4; ++c) lq[u][c] = v[c];
         } else {
 #pragma unroll
-            for (int c = 0; c < MAXC; ++c) l[c] = c < nc ? lp[c] : 0.f;
+            for (int c = 0; c < MAXC; ++c) lq[u][c] = c < nc ? lp[c] : 0.f;
         }
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) tq[u][c] = c < nc ? tgt[((size_t)n * nc + c) * HW + p] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (pb + 256 * u >= p1) break;
+        float l[MAXC];
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) l[c] = lq[u][c];
         float mx = l[0];
 #pragma unroll
         for (int c = 1; c < MAXC; ++c) if (c < nc) mx = fmaxf(mx, l[c]);
         float e[MAXC], sum = 0.f;
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) {
-            e[c] = c < nc ? expf(l[c] - mx) : 0.f;
+            e[c] = c < nc ? __expf(l[c] - mx) : 0.f;          // v_exp_f32 / v_rcp_f32 (~1 ulp each): these passes were VALU-bound on expf + IEEE division
             sum += e[c];
         }
-        const float inv = 1.0f / sum;
+        const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) {
             if (c < nc) {
-                const float pr = e[c] * inv, t = tgt[((size_t)n * nc + c) * HW + p];
+                const float pr = e[c] * inv, t = tq[u][c];
                 prod[c] += t * pr;
                 plus[c] += t + pr;
             }
         }
+      }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -508,36 +591,57 @@ template <int MAXC>
 __global__ __launch_bounds__(256) void dice_bwd_kernel(const float* __restrict__ logits, int ldl, const float* __restrict__ tgt,
                                                        const float* __restrict__ coef, const float* __restrict__ upstream, int N, int HW, int nc,
                                                        float* __restrict__ dlogits, int lddl) {
+    // grid (pixel blocks, N): no 64-bit division per pixel; four pixels' loads in flight per thread (see dice_reduce_kernel)
     const float up = upstream ? upstream[0] : 1.0f;
-    const long long total = (long long)N * HW;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-        const int n = (int)(idx / HW), p = (int)(idx - (long long)n * HW);
-        const float* lp = logits + (size_t)idx * ldl;
-        float l[MAXC];
+    const int n = blockIdx.y;
+    constexpr int U = MAXC <= 8 ? 4 : 1;
+    float ka[MAXC], kb[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        ka[c] = c < nc ? coef[((size_t)n * 2 + 0) * nc + c] : 0.f;
+        kb[c] = c < nc ? coef[((size_t)n * 2 + 1) * nc + c] : 0.f;
+    }
+    for (int pb = blockIdx.x * 256 * U + threadIdx.x; pb < HW; pb += gridDim.x * 256 * U) {
+      float lq[U][MAXC], tq[U][MAXC];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int p = min(pb + 256 * u, HW - 1);
+        const float* lp = logits + ((size_t)n * HW + p) * ldl;
         if (MAXC == 4 && (ldl & 3) == 0) {
             const f32x4 v = *(const f32x4*)lp;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) l[c] = v[c];
+            for (int c = 0; c < 4; ++c) lq[u][c] = v[c];
         } else {
 #pragma unroll
-            for (int c = 0; c < MAXC; ++c) l[c] = c < nc ? lp[c] : 0.f;
+            for (int c = 0; c < MAXC; ++c) lq[u][c] = c < nc ? lp[c] : 0.f;
         }
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) tq[u][c] = c < nc ? tgt[((size_t)n * nc + c) * HW + p] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int p = pb + 256 * u;
+        if (p >= HW) break;
+        const size_t idx = (size_t)n * HW + p;
+        float l[MAXC];
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) l[c] = lq[u][c];
         float mx = l[0];
 #pragma unroll
         for (int c = 1; c < MAXC; ++c) if (c < nc) mx = fmaxf(mx, l[c]);
         float e[MAXC], q[MAXC], sum = 0.f;
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) {
-            e[c] = c < nc ? expf(l[c] - mx) : 0.f;
+            e[c] = c < nc ? __expf(l[c] - mx) : 0.f;          // v_exp_f32 / v_rcp_f32 (~1 ulp each): these passes were VALU-bound on expf + IEEE division
             sum += e[c];
         }
-        const float inv = 1.0f / sum;
+        const float inv = __builtin_amdgcn_rcpf(sum);
         float dot = 0.f;
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) {
             if (c < nc) {
                 e[c] *= inv;
-                q[c] = coef[((size_t)n * 2 + 0) * nc + c] * tgt[((size_t)n * nc + c) * HW + p] + coef[((size_t)n * 2 + 1) * nc + c];
+                q[c] = ka[c] * tq[u][c] + kb[c];
                 dot += q[c] * e[c];
             }
         }
@@ -552,6 +656,7 @@ __global__ __launch_bounds__(256) void dice_bwd_kernel(const float* __restrict__
             for (int c = 0; c < MAXC; ++c)
                 if (c < nc) d[c] = up * e[c] * (q[c] - dot);
         }
+      }
     }
 }
 
@@ -648,7 +753,8 @@ static inline float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1)
 int hdy_bilinear_fwd(const void* x, int ldx, void* y, int ldy, int N, int Hi, int Wi, int Ho, int Wo, int C, int accumulate, int dtype, void* stream) {
     const int VE = dtype == HDY_BF16 ? 8 : 4;
     HDY_ARG(x && y && N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0 && C % VE == 0 && VEC_OK(x, ldx, VE) && VEC_OK(y, ldy, VE), "bilinear_fwd: bad args");
-    const long long items = (long long)N * Ho * Wo * (C / VE);
+    HDY_ARG((long long)N * Ho < (1LL << 31) && (long long)Wo * (C / VE) < (1LL << 31), "bilinear_fwd: too many rows / vectors per row");
+    const long long items = (long long)N * Ho * 256;                // a workgroup per output row, up to the grid cap
     if (dtype == HDY_BF16)
         hipLaunchKernelGGL(bilinear_fwd_kernel<bf16_t>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, N, Hi, Wi, Ho, Wo, C, ac_scale(Hi, Ho), ac_scale(Wi, Wo), accumulate);
     else
@@ -676,6 +782,18 @@ int hdy_bilinear_bwd_axis(const void* dy, int lddy, void* dx, int lddx, long lon
     const int VE = dtype == HDY_BF16 ? 8 : 4;
     HDY_ARG(dy && dx && outer > 0 && Ai > 0 && Ao > 0 && inner > 0 && C > 0 && C % VE == 0 && VEC_OK(dy, lddy, VE) && VEC_OK(dx, lddx, VE), "bilinear_bwd_axis: bad args");
     const long long items = outer * Ai * inner * (C / VE);
+    const size_t row_bytes = (size_t)Ao * (C / VE) * 16;
+    if (inner == 1 && row_bytes <= 64 * 1024 && outer < (1LL << 31)) {        // W pass: the gradient row fits LDS
+        const int grid = (int)(outer < 256 * 16 ? outer : 256 * 16);
+        if (dtype == HDY_BF16)
+            hipLaunchKernelGGL(bilinear_bwd_w_lds_kernel<bf16_t>, dim3(grid), dim3(256), row_bytes, (hipStream_t)stream, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx,
+                               (int)outer, Ai, Ao, C, ac_scale(Ai, Ao), accumulate);
+        else
+            hipLaunchKernelGGL(bilinear_bwd_w_lds_kernel<float>, dim3(grid), dim3(256), row_bytes, (hipStream_t)stream, (const float*)dy, lddy, (float*)dx, lddx,
+                               (int)outer, Ai, Ao, C, ac_scale(Ai, Ao), accumulate);
+        HDY_LAUNCH_CHECK("bilinear_bwd_w");
+        return HDY_OK;
+    }
     if (dtype == HDY_BF16)
         hipLaunchKernelGGL(bilinear_bwd_axis_kernel<bf16_t>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, outer, Ai, Ao, inner, C, ac_scale(Ai, Ao), accumulate);
     else
@@ -702,7 +820,9 @@ int hdy_softdice(const float* logits, int ldl, const float* targets, const float
     HDY_LAUNCH_CHECK("dice_finalize");
     if (dlogits) {
         HDY_ARG(lddl >= nc, "softdice: dlogits pitch");
-        const dim3 g(grid_for((long long)N * HW));
+        HDY_ARG(N <= 65535, "softdice: batch beyond the launch grid");
+        const int gx = cdiv(HW, 256 * 4);
+        const dim3 g(gx < 1 ? 1 : (gx > 4096 ? 4096 : gx), N);
         if (nc <= 4) hipLaunchKernelGGL(dice_bwd_kernel<4>, g, dim3(256), 0, st, logits, ldl, targets, coef, upstream, N, HW, nc, dlogits, lddl);
         else if (nc <= 8) hipLaunchKernelGGL(dice_bwd_kernel<8>, g, dim3(256), 0, st, logits, ldl, targets, coef, upstream, N, HW, nc, dlogits, lddl);
         else hipLaunchKernelGGL(dice_bwd_kernel<DICE_MAXC>, g, dim3(256), 0, st, logits, ldl, targets, coef, upstream, N, HW, nc, dlogits, lddl);

@@ -132,7 +132,7 @@ class MaskBranchFn(torch.autograd.Function):
         from .maskhead import MaskHeadRun
         P = head.mask_output_size // 2
         feats = plan.mask_features()
-        parts = [ops.roi_align(feats[l], r, 1.0 / float(head.anchors[l].stride), P, 2, head.aligned) for l, r in enumerate(rois_by_level)]
+        parts = [ops.roi_align(feats[l], r, 1.0 / head._stride_cached(l), P, 2, head.aligned) for l, r in enumerate(rois_by_level)]
         x = torch.cat(parts)[order]
         run = MaskHeadRun(head.seg_h, dtype)
         logits = run.forward(x.contiguous(), train=True)
@@ -149,7 +149,7 @@ class MaskBranchFn(torch.autograd.Function):
         inv[ctx.order] = torch.arange(len(ctx.order), device=ctx.order.device)
         dparts = torch.split(dx[inv], ctx.sizes)                  # back to the per-level concatenation order
         for l, (v, rois, dpart) in enumerate(zip(plan.mask_vals, ctx.rois, dparts)):
-            img = ops.roi_align_bwd(dpart.contiguous(), (v.n, v.h, v.w, v.c), rois, 1.0 / float(head.anchors[l].stride), 2, head.aligned)
+            img = ops.roi_align_bwd(dpart.contiguous(), (v.n, v.h, v.w, v.c), rois, 1.0 / head._stride_cached(l), 2, head.aligned)
             ops.cast_store(img, v.g(), accumulate=False)
         plan.mask_grads_ready = True
         return torch.zeros(1, device=dlogits.device), None, None, None, None, None, None

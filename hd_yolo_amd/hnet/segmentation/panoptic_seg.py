@@ -65,6 +65,18 @@ def ops_is_nhwc(t):
         return False
 
 
+def _stack_masks(ms):
+    """torch.stack(ms).float().contiguous() (reference: panoptic_seg.py:36) — without the copy when the loader already holds the per-image
+    masks as consecutive fp32 slices of one batch tensor (a 79 MB device copy per step at 16 x 3 x 1280 x 1280)."""
+    m0 = ms[0]
+    if (m0.dtype == torch.float32 and m0.is_contiguous() and
+            all(m.dtype == m0.dtype and m.shape == m0.shape and m.is_contiguous() and m.device == m0.device and
+                m.untyped_storage().data_ptr() == m0.untyped_storage().data_ptr() and
+                m.storage_offset() == m0.storage_offset() + i * m0.numel() for i, m in enumerate(ms))):
+        return m0.as_strided((len(ms),) + tuple(m0.shape), (m0.numel(),) + tuple(m0.stride()), m0.storage_offset())
+    return torch.stack(ms).float().contiguous()
+
+
 class PanopticSeg(torch.nn.Module):
     def __init__(self, config):
         super().__init__()
@@ -115,7 +127,7 @@ class PanopticSeg(torch.nn.Module):
                 for a in anns:
                     if 'roi' in a and [float(v) for v in a['roi']] != [0.0, 0.0, float(W), float(H)]:
                         raise _lib.HdyError('PanopticSeg on this path takes whole-tile rois only (roi == [0, 0, W, H])')
-            masks = torch.stack([a['masks'] for a in anns]).float().contiguous()
+            masks = _stack_masks([a['masks'] for a in anns])
             if tuple(masks.shape[-2:]) != out_size:
                 # reference (panoptic_seg.py:13-19, :37-39): Upsample(scale_factor) -> conv -> Softmax2d, THEN the probabilities are
                 # interpolated to the mask size.  This path resizes the logits once and applies the softmax last, which is the same

@@ -329,12 +329,7 @@ class Detect(nn.Module):
         plan, loss, items = engine.forward_fused_loss(x, dtype, self, gts, tcls)
         mask_loss = None
         if want_masks:
-            # the mask branch needs WHICH cells were matched: the tensor-expression matcher on the (detached) logits — the same
-            # assignment the loss kernel made — and the decoded boxes of those cells
-            dets = [d.detach() for d in plan.det_views()]
-            _, tids, indices, _ = self.matcher(dets, gts)
-            mask_loss = self.mask_losses(self.compute_proposals(dets), (engine, plan, dtype), targets, gts, tids, indices,
-                                         [gt_labels[i] for i in tids])
+            mask_loss = self.mask_losses_device((engine, plan, dtype), targets, gts, gt_labels)
         if mask_loss is None:
             mask_loss = torch.zeros_like(loss)
         return plan, {'det_loss': loss, 'mask_loss': mask_loss,
@@ -396,6 +391,34 @@ class Detect(nn.Module):
         mask_targets = torch.cat([t['masks'] for t in targets]).to(dev)[obj_ids[keep], None] * 1.0
         gt_labels = torch.cat(tcls)[keep]
         hier = (gt_labels * torch.arange(self.nc + 1, device=dev)).max(-1)[1]
+        return self.seg_loss(mask_logits, mask_targets, self.mask_indices[hier])
+
+    def mask_losses_device(self, mask_ctx, targets, gts, gt_labels):
+        """mask_losses with the selection on the device (hdy_mask_select on the plan's logits: the same candidates as the loss kernel's matcher,
+        the decode kernel's boxes, the IoU of paired_box_iou) and ONE device-to-host sync for the row counts; the tensor-expression version
+        (matcher + decode of every level + scatter_reduce + per-level boolean indexing) made ~20."""
+        engine, plan, dtype = mask_ctx
+        dev = gts.device
+        for i, v in enumerate(plan.mask_vals):
+            d = plan.det_units[i].x
+            if (v.w, v.h) != (d.w, d.h):
+                raise RuntimeError('mask feature maps and detection levels differ in size')
+        masks = torch.cat([t['masks'] for t in targets])
+        if masks.device.type == 'cpu' and dev.type == 'cuda':          # pinned, non-blocking: a pageable upload waits for everything queued so far
+            masks = masks.pin_memory().to(dev, non_blocking=True)
+        else:
+            masks = masks.to(dev)
+        apx = [v for i in range(self.nl) for v in self._anchor_px_cached(i)]
+        counts, keep_t, rois, order = plan.fused_loss(self).mask_select(gts, apx, [self._stride_cached(i) for i in range(self.nl)])
+        counts = counts.tolist()                                        # the one sync
+        nk = counts[0]
+        if nk == 0:
+            return None
+        by_level = [rois[l, :counts[1 + l]] for l in range(self.nl)]
+        kt = keep_t[:nk]
+        mask_logits = _engine.MaskBranchFn.apply(engine.mask_token, engine, plan, self, by_level, order[:nk], dtype)
+        mask_targets = masks[kt, None] * 1.0
+        hier = (gt_labels[kt] * self._const(('classes',), dev, lambda: torch.arange(self.nc + 1))).max(-1)[1]
         return self.seg_loss(mask_logits, mask_targets, self.mask_indices[hier])
 
     def _const(self, key, dev, make):

@@ -769,6 +769,23 @@ class DetLossCall:
                   float(h['obj']), float(h['cls']), self.out.data_ptr(), self.ws.data_ptr(), self.ws.numel() * 4, stream_ptr())
 
 
+    def mask_select(self, gts, anchors_px, strides, min_iou=0.8):
+        """hdy_mask_select on this plan's logits: device tensors counts (1 + nl) int32, keep_t (nt) int64, rois (nl, nt, 5), order (nt) int64"""
+        nt = int(gts.shape[0])
+        dev = self.device
+        counts = torch.empty(1 + self.nl, dtype=torch.int32, device=dev)
+        keep_t = torch.empty(max(nt, 1), dtype=torch.int64, device=dev)
+        rois = torch.empty((self.nl, max(nt, 1), 5), dtype=torch.float32, device=dev)
+        order = torch.empty(max(nt, 1), dtype=torch.int64, device=dev)
+        ws = torch.empty(2 * max(nt, 1), dtype=torch.int64, device=dev)
+        apx = (ctypes.c_float * (self.nl * self.na * 2))(*[float(v) for v in anchors_px])
+        st = (ctypes.c_float * self.nl)(*[float(v) for v in strides])
+        _lib.call('hdy_mask_select', self.lp, self.ldl, self.ny, self.nx, self.nl, self.B, self.na, self.nc + 5, self.anc, apx, st,
+                  gts.data_ptr() if nt else None, nt, float(self.hyp['anchor_t']), float(min_iou), counts.data_ptr(), keep_t.data_ptr(),
+                  rois.data_ptr(), order.data_ptr(), ws.data_ptr(), ws.numel() * 8, stream_ptr())
+        return counts, keep_t, rois, order
+
+
 def det_targets(boxes, img, labels, nc):
     """(nt, 4) clamped corner boxes, (nt,) image index, (nt,) int64 labels -> gts (nt, 5) [img, cx, cy, w, h], tcls (nt, nc) one-hot of labels 1..nc"""
     nt = int(boxes.shape[0])

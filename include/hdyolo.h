@@ -287,6 +287,15 @@ int hdy_det_loss(const float* const* logits, int ldl, void* const* gdet, int ldg
                  int na, int nc, const float* anchors_grid, const float* balance, const float* gts, const float* tcls, int nt,
                  const float* cls_cw, float cls_pw, float obj_pw, float anchor_t, float label_smoothing, float h_box, float h_obj, float h_cls,
                  float* out, void* workspace, size_t ws_bytes, void* stream);
+/* Which matched cell of each target feeds the mask branch (metayolo/models/yolo_head.py:231-262: per target the matched cell whose decoded
+ * box has the best IoU with the truth — first in the reference's row order on ties — kept when that IoU >= min_iou = 0.8).  Same logits /
+ * geometry / anchors_grid / gts / anchor_t as hdy_det_loss, anchors_px [nl][na][2] and strides [nl] as hdy_decode.  Device outputs:
+ * counts [1 + nl] (kept, kept per level), keep_t [nt] int64 target of kept row k (target order), rois [nl][nt][5] (image, x1, y1, x2, y2 of
+ * the TRUTH in input pixels, compact per level), order [nt] int64 = position of kept row k in the level-by-level concatenation.
+ * workspace: nt * 16 bytes, 8-byte aligned. */
+int hdy_mask_select(const float* const* logits, int ldl, const int* ny, const int* nx, int nl, int B, int na, int no, const float* anchors_grid,
+                    const float* anchors_px, const float* strides, const float* gts, int nt, float anchor_t, float min_iou, int* counts,
+                    long long* keep_t, float* rois, long long* order, void* workspace, size_t ws_bytes, void* stream);
 /* gts / tcls of hdy_det_loss from the batch's annotations (replaces the xyxy -> xywh conversion and the one-hot encoding of
  * Detect.forward's target preparation, metayolo/models/yolo_head.py:217-222: ~15 eager tensor ops per step): boxes device [nt][4] corner boxes
  * (normalised, already clamped to [0, 1]), img device [nt] image index of each row (fp32), labels device [nt] int64 class labels

@@ -38,7 +38,7 @@ def step():
     losses, _ = m(x, targets)
     (losses['det_det_loss'] + losses['seg_soft_iou_loss']).backward()
     opt.step()
-    opt.zero_grad(set_to_none=False)
+    opt.zero_grad(set_to_none=True)            # as train.py does (and torch's default): the engine hands out fresh views of its flat gradient buffer
     return losses
 
 

@@ -28,7 +28,7 @@ def step():
     l = losses['det']
     (l['det_loss'] + l['mask_loss']).backward()
     opt.step()
-    opt.zero_grad(set_to_none=False)
+    opt.zero_grad(set_to_none=True)            # as train.py does (torch's default)
     return l
 
 

@@ -160,3 +160,57 @@ def test_train_step_with_mask_loss_matches_reference(fused, monkeypatch):
     losses['det']['det_loss'].backward()
     assert float(params['headers.det.seg_h.maskrcnn_heads.mask_fcn1.weight'].grad.abs().sum()) == 0.0
     assert float(params['headers.det.seg.0.conv.weight'].grad.abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize('min_iou', [0.8, 0.3, 0.0])
+def test_mask_selection_on_the_device_equals_the_tensor_expressions(min_iou):
+    """hdy_mask_select (same candidates as the loss kernel's matcher, decode kernel's boxes, IoU in input pixels, best cell per target in the
+    reference's row order, compaction per level) against the tensor-expression selection of Detect.mask_losses (reference:
+    yolo_head.py:231-262) on the same logits: kept targets, per-level rois and the order permutation must be identical, bit for bit."""
+    from hd_yolo_amd import engine as _engine
+    from metayolo.models.utils_general import paired_box_iou, xywh2xyxy
+    model = _mask_model(synth.make_hyp()).train()
+    head = model.headers['det']
+    x = synth.synth_images(3, 256, seed=5).to(DEV)
+    targets = [t['anns']['det'][0] for t in synth.synth_mask_targets(3, 256, 2, per_image=25, seed=6)]
+    gts, gt_labels = head.flatten_targets(targets, DEV)
+    gts, tcls = gts.contiguous(), gt_labels[:, 1:].float().contiguous()
+    eng = model._eng()
+    plan, _, _ = eng.forward_fused_loss(x, _engine.compute_dtype(model, x), head, gts, tcls)
+    apx = [v for i in range(head.nl) for v in head._anchor_px_cached(i)]
+    counts, keep_t, rois, order = plan.fused_loss(head).mask_select(gts, apx, [head._stride_cached(i) for i in range(head.nl)], min_iou)
+    counts = counts.tolist()
+    # the tensor-expression selection
+    dets = [d.detach() for d in plan.det_views()]
+    _, tids, indices, _ = head.matcher(dets, gts)
+    preds = head.compute_proposals(dets)
+    props, gt_props, obj_ids, all_rois = [], [], [], []
+    for i, buf in enumerate(head.anchors):
+        v = plan.mask_vals[i]
+        b, a, gj, gi = indices[i]
+        props.append(xywh2xyxy(preds[i][b, a, gj, gi, :4]))
+        gb = xywh2xyxy(gts[tids[i]][:, 1:] * gts.new([v.w, v.h, v.w, v.h])) * buf.stride
+        gt_props.append(gb)
+        obj_ids.append(tids[i])
+        all_rois.append(torch.cat([b[:, None].to(gb.dtype), gb], -1))
+    sizes = [len(o) for o in obj_ids]
+    props, gt_props, obj_ids, all_rois = torch.cat(props), torch.cat(gt_props), torch.cat(obj_ids), torch.cat(all_rois)
+    ious = paired_box_iou(props, gt_props)
+    nobj = int(gts.shape[0])
+    best = torch.zeros(nobj, dtype=ious.dtype, device=DEV).scatter_reduce_(0, obj_ids, ious, 'amax', include_self=False)
+    rows = torch.arange(len(ious), device=DEV)
+    hit = ious == best[obj_ids]
+    arg = torch.full((nobj,), len(ious), dtype=torch.long, device=DEV).scatter_reduce_(0, obj_ids[hit], rows[hit], 'amin')
+    present = torch.zeros(nobj, dtype=torch.bool, device=DEV).index_fill_(0, obj_ids, True)
+    keep = arg[(best >= min_iou) & present]
+    level = torch.repeat_interleave(torch.arange(head.nl, device=DEV), torch.tensor(sizes, device=DEV))
+    klev = level[keep]
+    assert counts[0] == len(keep) and (min_iou > 0.5 or len(keep) > 20)
+    assert torch.equal(keep_t[:counts[0]], obj_ids[keep])
+    for l in range(head.nl):
+        want = all_rois[keep[klev == l]]
+        assert counts[1 + l] == len(want) and torch.equal(rois[l, :len(want)], want), l
+    pos = torch.cat([(klev == l).nonzero().flatten() for l in range(head.nl)])
+    want_order = torch.empty_like(pos)
+    want_order[pos] = torch.arange(len(pos), device=DEV)
+    assert torch.equal(order[:counts[0]], want_order)

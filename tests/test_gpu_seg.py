@@ -52,7 +52,8 @@ def test_groupnorm_relu_forward_backward(shape, G_, dtype):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize('inp,out', [((5, 7), (10, 14)), ((8, 12), (64, 96)), ((16, 16), (16, 16)), ((9, 4), (5, 11)), ((1, 6), (3, 6))])
+@pytest.mark.parametrize('inp,out', [((5, 7), (10, 14)), ((8, 12), (64, 96)), ((16, 16), (16, 16)), ((9, 4), (5, 11)), ((1, 6), (3, 6)),
+                                     ((20, 40), (160, 320)), ((3, 300), (5, 2400))])      # x8 as the segmentation header resizes; a row beyond the LDS-staged W pass
 def test_bilinear_align_corners_forward_backward(inp, out, dtype):
     N, C = 2, 16
     x = rnd((N, C) + inp, 7).to(dtype)
@@ -70,9 +71,10 @@ def test_bilinear_align_corners_forward_backward(inp, out, dtype):
     assert relmax(dx.float().cpu().permute(0, 3, 1, 2), xr.grad) < TOL[dtype]
 
 
-@pytest.mark.parametrize('nc,weights', [(3, [1.0, 2.0, 0.5]), (1, None), (8, None)])
-def test_softmax_soft_dice_loss_and_gradient(nc, weights):
-    N, H, W = 3, 37, 29
+@pytest.mark.parametrize('nc,weights,hw', [(3, [1.0, 2.0, 0.5], (37, 29)), (1, None, (37, 29)), (8, None, (37, 29)),
+                                          (3, None, (173, 211)), (6, None, (160, 200)), (12, None, (90, 70))])     # the large ones: several pixels in flight per thread
+def test_softmax_soft_dice_loss_and_gradient(nc, weights, hw):
+    N, (H, W) = 3, hw
     kp = (nc + 7) // 8 * 8
     logits = rnd((N, H, W, kp), 11, 3.0)
     logits[..., nc:] = 0
