@@ -94,6 +94,7 @@ SIGNATURES = {
     'hdy_decode': (_I, [_P, _L, _L, _L, _L, _P, _F, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'hdy_nms_workspace_bytes': (_Z, [_I, _I]),
     'hdy_mask_select': (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _F, _F, _P, _P, _P, _P, _P, _Z, _P]),
+    'hdy_softdice_wgrad': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     'hdy_det_outputs': (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _F, _I, _P, _P, _P, _P, _P]),
     'hdy_nms_batched': (_I, [_P, _I, _I, _I, _I, _F, _F, _I, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     'hdy_nms_boxes': (_I, [_P, _I, _I, _F, _I, _P, _P, _P, _Z, _P]),

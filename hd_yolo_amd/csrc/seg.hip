@@ -660,6 +660,87 @@ __global__ __launch_bounds__(256) void dice_bwd_kernel(const float* __restrict__
     }
 }
 
+// dice_bwd_kernel<4> and the W pass of the resize backward in one launch (4-float pixels, <= 4 classes): a workgroup computes the gradient
+// of one full-resolution row (the same expressions as dice_bwd_kernel, upstream = 1) into LDS and gathers it down to Wi vectors exactly as
+// bilinear_bwd_w_lds_kernel does — bit-identical to the two launches, without the full-resolution gradient tensor (419 MB written and read
+// back at 16 x 1280 x 1280).  dw [N][H][Wi][4].
+__global__ __launch_bounds__(256) void dice_bwd_w_kernel(const float* __restrict__ logits, const float* __restrict__ tgt, const float* __restrict__ coef,
+                                                         int N, int H, int W, int nc, int Wi, float scale, float* __restrict__ dw) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dbw_smem[];
+    f32x4* stage = (f32x4*)dbw_smem;                              // [W]
+    const int HW = H * W;
+    for (int row = blockIdx.x; row < N * H; row += gridDim.x) {
+        const int n = row / H, y = row - n * H;
+        float ka[4], kb[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            ka[c] = c < nc ? coef[((size_t)n * 2 + 0) * nc + c] : 0.f;
+            kb[c] = c < nc ? coef[((size_t)n * 2 + 1) * nc + c] : 0.f;
+        }
+        constexpr int U = 4;
+        for (int xb = threadIdx.x; xb < W; xb += 256 * U) {
+            f32x4 lq[U];
+            float tq[U][4];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int x = min(xb + 256 * u, W - 1);
+                lq[u] = *(const f32x4*)(logits + ((size_t)row * W + x) * 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) tq[u][c] = c < nc ? tgt[((size_t)n * nc + c) * HW + (size_t)y * W + x] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int x = xb + 256 * u;
+                if (x >= W) break;
+                float l[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) l[c] = lq[u][c];
+                float mx = l[0];
+#pragma unroll
+                for (int c = 1; c < 4; ++c) if (c < nc) mx = fmaxf(mx, l[c]);
+                float e[4], q[4], sum = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    e[c] = c < nc ? __expf(l[c] - mx) : 0.f;
+                    sum += e[c];
+                }
+                const float inv = __builtin_amdgcn_rcpf(sum);
+                float dot = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (c < nc) {
+                        e[c] *= inv;
+                        q[c] = ka[c] * tq[u][c] + kb[c];
+                        dot += q[c] * e[c];
+                    }
+                }
+                f32x4 o;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) o[c] = c < nc ? 1.0f * e[c] * (q[c] - dot) : 0.f;
+                stage[x] = o;
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < Wi; i += 256) {
+            int lo, hi;
+            dst_range(i, scale, W, &lo, &hi);
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int a = lo; a <= hi; ++a) {
+                int i0, i1;
+                float l0, l1;
+                src_index(a, scale, Wi, &i0, &i1, &l0, &l1);
+                const float w = (i0 == i ? l0 : 0.f) + (i1 == i ? l1 : 0.f);
+                if (w == 0.f) continue;
+                const f32x4 g = stage[a];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += w * g[e];
+            }
+            *(f32x4*)(dw + ((size_t)row * Wi + i) * 4) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+        }
+        __syncthreads();
+    }
+}
+
 // probabilities for inference: p = softmax over the nc channels, fp32 [N][HW][ldp]
 __global__ __launch_bounds__(256) void softmax2d_kernel(const float* __restrict__ logits, int ldl, float* __restrict__ probs, int ldp, long long M, int nc) {
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < M; idx += (long long)gridDim.x * 256) {
@@ -828,6 +909,26 @@ int hdy_softdice(const float* logits, int ldl, const float* targets, const float
         else hipLaunchKernelGGL(dice_bwd_kernel<DICE_MAXC>, g, dim3(256), 0, st, logits, ldl, targets, coef, upstream, N, HW, nc, dlogits, lddl);
         HDY_LAUNCH_CHECK("dice_bwd");
     }
+    return HDY_OK;
+}
+
+// hdy_softdice's loss plus the gradient already reduced along W by the transposed resize (the first of hdy_bilinear_bwd_axis' two passes):
+// logits fp32 [N][H][W][4] with nc <= 4 classes, dw [N][H][Wi][4] = W pass of d loss / d logits (upstream 1); the caller runs the H pass
+// (hdy_bilinear_bwd_axis(dw, 4, dx, ldx, N, Hi, H, Wi, 4, ...)).  Same results as hdy_softdice + the W pass, bit for bit.
+int hdy_softdice_wgrad(const float* logits, const float* targets, const float* class_weight, int N, int H, int W, int nc, int Wi, float* loss, float* dw,
+                       float* workspace, void* stream) {
+    HDY_ARG(logits && targets && loss && dw && workspace && N > 0 && H > 0 && W > 0 && Wi > 0 && nc > 0 && nc <= 4 && N * nc <= 65536, "softdice_wgrad: bad args (nc <= 4)");
+    HDY_ARG((size_t)W * 16 <= 64 * 1024 && (long long)N * H < (1LL << 31), "softdice_wgrad: row of %d pixels beyond the LDS stage", W);
+    hipStream_t st = (hipStream_t)stream;
+    const int HW = H * W;
+    float* coef = workspace + (size_t)N * DICE_SLICES * 2 * nc;
+    hipLaunchKernelGGL(dice_reduce_kernel<4>, dim3(N, DICE_SLICES), dim3(256), 0, st, logits, 4, targets, HW, nc, workspace);
+    HDY_LAUNCH_CHECK("dice_reduce");
+    hipLaunchKernelGGL(dice_finalize_kernel, dim3(1), dim3(256), 0, st, workspace, class_weight, N, nc, loss, coef);
+    HDY_LAUNCH_CHECK("dice_finalize");
+    const int rows = N * H;
+    hipLaunchKernelGGL(dice_bwd_w_kernel, dim3(rows < 4096 ? rows : 4096), dim3(256), (size_t)W * 16, st, logits, targets, coef, N, H, W, nc, Wi, ac_scale(Wi, W), dw);
+    HDY_LAUNCH_CHECK("dice_bwd_w");
     return HDY_OK;
 }
 

@@ -47,13 +47,19 @@ class _SegFn(torch.autograd.Function):
         nhwc = [f.permute(0, 2, 3, 1) for f in feats]
         nhwc = [f if f.dtype == run.dtype else f.to(run.dtype) for f in nhwc]
         logits = run.forward([f if ops_is_nhwc(f) else f.contiguous() for f in nhwc], out_size=masks.shape[-2:], train=True)
-        loss, dl = ops.softdice(logits, masks, seg.criterion.weights(seg.config['num_classes'], logits.device), want_grad=True)
+        cw = seg.criterion.weights(seg.config['num_classes'], logits.device)
+        low_w = run.low_shape[2]
+        ctx.w_reduced = tuple(run.out_size) != tuple(run.low_shape[1:3]) and ops.softdice_wgrad_ok(logits, masks.shape[1], low_w)
+        if ctx.w_reduced:          # loss + gradient already reduced along W: the full-resolution gradient tensor is never written
+            loss, dl = ops.softdice_wgrad(logits, masks, cw, low_w)
+        else:
+            loss, dl = ops.softdice(logits, masks, cw, want_grad=True)
         ctx.run, ctx.dl, ctx.grad_of, ctx.dtypes = run, dl, grad_of, [f.dtype for f in feats]
         return loss
 
     @staticmethod
     def backward(ctx, g):
-        dfeats = ctx.run.backward(ctx.dl, ctx.grad_of, scale=g)          # the upstream factor goes in at the connector's resolution
+        dfeats = ctx.run.backward(ctx.dl, ctx.grad_of, scale=g, w_reduced=ctx.w_reduced)          # the upstream factor goes in at the connector's resolution
         return (None, None, None, None) + tuple(d.permute(0, 3, 1, 2).to(t) for d, t in zip(dfeats, ctx.dtypes))
 
 

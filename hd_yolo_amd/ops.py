@@ -868,10 +868,40 @@ def softdice(logits, targets, class_weight=None, upstream=None, want_grad=False)
     assert tuple(targets.shape) == (N, nc, H, W) and ld >= nc
     loss = torch.empty(1, dtype=torch.float32, device=logits.device)
     ws = torch.empty(_lib.query('hdy_softdice_workspace_floats', N, nc), dtype=torch.float32, device=logits.device)
-    dl = torch.zeros_like(logits) if want_grad else None
+    # 4-float pixels with <= 4 classes: the backward pass writes whole pixels (padding channels as zeros) — no 419 MB memset at 16 x 1280 x 1280
+    dl = (torch.empty_like(logits) if ld == 4 and nc <= 4 else torch.zeros_like(logits)) if want_grad else None
     _lib.call('hdy_softdice', logits.data_ptr(), ld, targets.data_ptr(), ptr(class_weight), N, H * W, nc, loss.data_ptr(), ptr(upstream),
               ptr(dl), ld, ws.data_ptr(), stream_ptr())
     return loss, dl
+
+
+def softdice_wgrad_ok(logits, nc, in_w):
+    """the fused loss + W-pass gradient (hdy_softdice_wgrad) covers 4-float pixels with <= 4 classes and rows that fit the LDS stage"""
+    N, H, W, ld = logits.shape
+    return ld == 4 and nc <= 4 and W * 16 <= 64 * 1024 and W >= 2 * in_w
+
+
+def softdice_wgrad(logits, targets, class_weight, in_w):
+    """(loss[1], dw (N, H, in_w, 4)): hdy_softdice's loss and the W pass of the resize backward of its gradient, in one launch sequence"""
+    require_gpu(logits)
+    N, H, W, ld = logits.shape
+    nc = targets.shape[1]
+    assert logits.dtype == torch.float32 and logits.is_contiguous() and targets.dtype == torch.float32 and targets.is_contiguous()
+    assert tuple(targets.shape) == (N, nc, H, W) and softdice_wgrad_ok(logits, nc, in_w)
+    loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+    ws = torch.empty(_lib.query('hdy_softdice_workspace_floats', N, nc), dtype=torch.float32, device=logits.device)
+    dw = torch.empty((N, H, in_w, 4), dtype=torch.float32, device=logits.device)
+    _lib.call('hdy_softdice_wgrad', logits.data_ptr(), targets.data_ptr(), ptr(class_weight), N, H, W, nc, in_w, loss.data_ptr(), dw.data_ptr(),
+              ws.data_ptr(), stream_ptr())
+    return loss, dw
+
+
+def bilinear_bwd_h(dw, in_h, out, accumulate=False):
+    """H pass of the resize backward: dw (N, Ho, Wi, C) -> out (N, in_h, Wi, C) (+)="""
+    dp, N, Ho, Wi, C, ldd = nhwc(dw)
+    op, _, _, _, _, ldo = nhwc(out)
+    _lib.call('hdy_bilinear_bwd_axis', dp, ldd, op, ldo, N, in_h, Ho, Wi, C, int(accumulate), dcode(dw.dtype), stream_ptr())
+    return out
 
 
 def softmax2d(logits, nc):

@@ -112,7 +112,7 @@ class PanopticRun:
             self.tape = None
         return logits                                          # fp32 NHWC (N, Ho, Wo, nc4 or kp), channels [nc, ..) are zero
 
-    def backward(self, dlogits, grad_of, scale=None):
+    def backward(self, dlogits, grad_of, scale=None, w_reduced=False):
         """dlogits fp32 (N, Ho, Wo, nc4 | kp) -> list of feature gradients (NHWC, finest first); parameter gradients into grad_of(p).
         scale: 1-element tensor multiplied in AFTER the resize backward (linear: the same result, on 1/64 of the elements)."""
         dt = self.dtype
@@ -122,6 +122,9 @@ class PanopticRun:
         nc = cc.out_channels
         if self.out_size == (H, W):
             dlow = dlogits
+        elif w_reduced:                                        # (N, Ho, W, 4): the loss kernel already ran the W pass of the resize backward
+            dlow = torch.zeros((N, H, W, kp), dtype=torch.float32, device=dev)
+            ops.bilinear_bwd_h(dlogits, H, dlow[..., :dlogits.shape[3]])
         else:
             dlow = torch.zeros((N, H, W, kp), dtype=torch.float32, device=dev)
             ops.bilinear_bwd(dlogits, (H, W), out=dlow[..., :dlogits.shape[3]])

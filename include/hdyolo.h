@@ -324,6 +324,12 @@ int hdy_bilinear_bwd_axis(const void* dy, int lddy, void* dx, int lddx, long lon
 size_t hdy_softdice_workspace_floats(int N, int nc);
 int hdy_softdice(const float* logits, int ldl, const float* targets, const float* class_weight, int N, int HW, int nc, float* loss,
                  const float* upstream, float* dlogits, int lddl, float* workspace, void* stream);
+/* hdy_softdice's loss, and its gradient already reduced along W by the transposed resize (the W pass of hdy_bilinear_bwd_axis) without the
+ * full-resolution gradient tensor: logits fp32 [N][H][W][4] with nc <= 4 classes (the segmentation header's resized class logits,
+ * hnet/segmentation/panoptic_seg.py:37-40), dw [N][H][Wi][4]; the caller finishes with the H pass.  Bit-identical to the two-call path.
+ * workspace: hdy_softdice_workspace_floats(N, nc). */
+int hdy_softdice_wgrad(const float* logits, const float* targets, const float* class_weight, int N, int H, int W, int nc, int Wi, float* loss, float* dw,
+                       float* workspace, void* stream);
 int hdy_softmax2d(const float* logits, int ldl, float* probs, int ldp, long long M, int nc, void* stream);
 
 /* The stem's weight gradient (layers.py:31 Conv(3, c, 6, 2, 2), backward of train.py:472) with the BatchNorm / SiLU backward of its unit applied

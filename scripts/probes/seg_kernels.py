@@ -28,3 +28,7 @@ print('softdice loss only       %7.1f us' % timed(lambda: ops.softdice(logits, m
 print('softdice loss + gradient %7.1f us' % timed(lambda: ops.softdice(logits, masks, None, upstream=up, want_grad=True)))
 g = torch.randn_like(logits)
 print('bilinear_bwd fp32        %7.1f us' % timed(lambda: ops.bilinear_bwd(g, (S // 8, S // 8))))
+print('softdice_wgrad (fused)   %7.1f us' % timed(lambda: ops.softdice_wgrad(logits, masks, None, S // 8)))
+dw = ops.softdice_wgrad(logits, masks, None, S // 8)[1]
+dlow = torch.zeros((N, S // 8, S // 8, 8), device=dev)
+print('H pass                   %7.1f us' % timed(lambda: ops.bilinear_bwd_h(dw, S // 8, dlow[..., :4])))

@@ -205,3 +205,23 @@ def test_hnet_eval_outputs():
     assert losses == {} and len(outputs['det']) == 2 and 'boxes' in outputs['det'][0]
     assert len(outputs['seg']) == 2 and tuple(outputs['seg'][0].shape) == (1, 3, 64, 64)
     assert abs(float(outputs['seg'][0].sum(1).mean()) - 1.0) < 1e-5
+
+
+@pytest.mark.parametrize('nc,size,low_w', [(3, (48, 256), 32), (4, (33, 1000), 125), (1, (20, 64), 8)])
+def test_fused_dice_gradient_and_w_pass_equals_the_two_launches(nc, size, low_w):
+    """hdy_softdice_wgrad (loss + gradient reduced along W inside the loss kernel: no full-resolution gradient tensor) against hdy_softdice
+    followed by the W pass of the resize backward: the loss and the reduced gradient must be identical bit for bit"""
+    N, (H, W) = 2, size
+    logits = rnd((N, H, W, 4), 21, 3.0)
+    logits[..., nc:] = 0
+    lab = torch.randint(0, max(nc, 2), (N, H, W), generator=torch.Generator().manual_seed(22))
+    masks = F.one_hot(lab, max(nc, 2)).permute(0, 3, 1, 2).float()[:, :nc].contiguous()
+    cw = None if nc != 3 else torch.tensor([1.0, 2.0, 0.5], device=DEV)
+    ld, md = logits.to(DEV), masks.to(DEV)
+    assert ops.softdice_wgrad_ok(ld, nc, low_w)
+    loss_a, dl = ops.softdice(ld, md, cw, want_grad=True)
+    want = torch.empty((N, H, low_w, 4), dtype=torch.float32, device=DEV)
+    from hd_yolo_amd import _lib
+    _lib.call('hdy_bilinear_bwd_axis', dl.data_ptr(), 4, want.data_ptr(), 4, N * H, low_w, W, 1, 4, 0, ops.dcode(torch.float32), ops.stream_ptr())
+    loss_b, dw = ops.softdice_wgrad(ld, md, cw, low_w)
+    assert torch.equal(loss_a, loss_b) and torch.equal(dw, want)
