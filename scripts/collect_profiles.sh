@@ -20,6 +20,8 @@ python3 scripts/layer_bench.py > $OUT/layer_table.txt 2>&1
 for v in "m 32 640" "l 16 640" "m6 16 1280"; do set -- $v; python3 bench.py --variant $1 --batch $2 --size $3 --steps 10 --warmup 3 --no-cpu-baseline --no-infer --no-roofline 2>/dev/null | tail -1 | cut -c1-420 >> $OUT/variants.log; done
 python3 scripts/bench_mask.py s 16 1280 4 2>/dev/null | tail -1 >> $OUT/variants.log
 python3 scripts/bench_latency.py 2>/dev/null | tail -3 >> $OUT/variants.log
+PYTHONPATH=. python3 scripts/probes/seg_kernels.py > $OUT/seg_kernels.txt 2>/dev/null
+PYTHONPATH=. python3 scripts/probes/dgrad_walk.py > $OUT/dgrad_walk.txt 2>/dev/null
 python3 scripts/trace_gaps.py $OUT/bench/bench_kernel_trace.csv 6 > $OUT/trace_gaps.txt 2>&1
 python3 scripts/pmc_summary.py $OUT/fetch/fetch_counter_collection.csv $OUT/write/write_counter_collection.csv conv3x3_c64_kernel $OUT/conv3x3_pmc.json > /dev/null 2>&1
 python3 scripts/counters_summary.py $OUT/mfma/mfma_counter_collection.csv $OUT/lds/lds_counter_collection.csv conv3x3_c64_kernel $OUT/roof/roof_kernel_stats.csv $OUT/conv3x3_counters.json > /dev/null 2>&1
