@@ -651,8 +651,8 @@ int hdy_conv_deep_slabs(long long M, int C, int K, int taps, int pointwise, int 
 int hdy_conv_deep_try(const ConvArgs& a_in, int dtype, int out_f32, hipStream_t st, int* rc) {
     const bool walk = a_in.ncls > 1;                               // the four-class stride-2 data gradient (validated by the caller)
     if (dtype != HDY_BF16 || out_f32 || a_in.nstat > 0 || (!a_in.dense_out && !walk) || a_in.span_pixels || !a_in.vec_out || !a_in.utap) return 0;
-    // measured at the yolov5s bench shapes (dy L2-resident, scripts/probes/dgrad_walk.py): 46 / 71 / 31 / 44 us here against 34 / 34 / 23 / 22 us
-    // for conv_igemm.hip's 128-row walk — these layers have 25-100 row tiles of 256 pixels per class, too few for 256 CUs.  Opt-in.
+    // measured at the yolov5s bench shapes (B = 64, scripts/probes/dgrad_walk.py): 105 / 80 / 62 / 48 us here against 94 / 86 / 59 / 51 us for
+    // conv_igemm.hip's 128-row walk, and 12.37-12.45 against 12.30 ms in the train step.  Opt-in.
     if (walk && !hdy_opt(HDY_OPT_DEEP_WALK)) return 0;
     int bn = 0;
     if (!deep_shape_ok(a_in.M, a_in.C, a_in.K, a_in.TH * a_in.TW, a_in.pointwise != 0, a_in.stats != nullptr, &bn, walk ? 4 : 1)) return 0;

@@ -23,5 +23,5 @@ def run(N, H, W, C, K):
             e1.record(); torch.cuda.synchronize()
             out.append((name, e0.elapsed_time(e1) / 50 * 1000))
     print((N, H, W, C, K), ' | '.join('%s %.1f us' % o for o in out), flush=True)
-for c in [(16, 160, 160, 64, 128), (16, 80, 80, 128, 256), (16, 40, 40, 256, 512), (16, 80, 80, 128, 128), (16, 40, 40, 256, 256)]:
+for c in [(64, 160, 160, 64, 128), (64, 80, 80, 128, 256), (64, 40, 40, 256, 512), (64, 80, 80, 128, 128), (64, 40, 40, 256, 256)]:      # the yolov5s bench shapes (B = 64)
     run(*c)
