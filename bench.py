@@ -16,7 +16,8 @@ Extra objects on the line:
                 worst of them: the named kernel is 2 % of the step, the others are where the time goes.  Each row also names the
                 roofline that bounds THAT layer (`bound`: max(FLOPs / 2.5 PFLOP/s, read-once/write-once bytes / 8 TB/s)) and its
                 `frac_of_bound`: the stride-2 layers at 320x320 / 160x160 are HBM-bound (0.24 of the MFMA peak AT the HBM roofline).
-  roofline_hbm  the step's dominant HBM-bound kernel (BatchNorm backward over the largest activation) timed alone, bytes / time vs 8 TB/s.
+  roofline_hbm  the step's dominant HBM-bound kernel (BatchNorm backward over the largest activation) timed alone, bytes / time vs 8 TB/s;
+                `all_launches`: the same over every BatchNorm-backward call of the plan (the kernel family with the most time in the step).
   step          whole-step fractions: conv FLOPs of the step / time / 2.5 PFLOP/s and read-once/write-once bytes of its conv and
                 BatchNorm launches / time / 8 TB/s.
   infer         BASELINE configs[3] (yolov5l, batch 128, 1024x1024 inference): tiles/s, decode and NMS microseconds per tile.

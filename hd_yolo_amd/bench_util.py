@@ -116,8 +116,19 @@ def hbm_kernel_roofline(plan, peak_gbs=8000.0, reps=8):
     if best is None:
         return None
     us = time_record(best[0], reps)
-    return {'bound': 'hbm', 'kernel': best[0][0][4:] + ' ' + best[1], 'achieved': round(best[2] / us / 1e3, 1), 'peak': peak_gbs, 'unit': 'GB/s',
-            'frac': round(best[2] / us / 1e3 / peak_gbs, 4), 'us_per_launch': round(us, 1), 'algorithmic_mb_per_launch': round(best[2] / 1e6, 1)}
+    out = {'bound': 'hbm', 'kernel': best[0][0][4:] + ' ' + best[1], 'achieved': round(best[2] / us / 1e3, 1), 'peak': peak_gbs, 'unit': 'GB/s',
+           'frac': round(best[2] / us / 1e3 / peak_gbs, 4), 'us_per_launch': round(us, 1), 'algorithmic_mb_per_launch': round(best[2] / 1e6, 1)}
+    # the same family over ALL its in-plan launches (bn_act_bwd_reduce + finalize + apply per call: the kernel family with the most time in the
+    # step, profiles/r03_step_kernel_stats.txt), each replayed alone: sum of algorithmic bytes / sum of times
+    tot_b, tot_us, n = 0.0, 0.0, 0
+    for rec in flat_records(plan.bwd):
+        if rec[0] in ('hdy_bn_act_bwd', 'hdy_bn_act_bwd_pair'):
+            tot_b += describe(rec)[2]
+            tot_us += time_record(rec, 4)
+            n += 1
+    out['all_launches'] = {'n': n, 'us_total': round(tot_us, 1), 'algorithmic_gb': round(tot_b / 1e9, 3), 'achieved': round(tot_b / tot_us / 1e3, 1),
+                           'frac': round(tot_b / tot_us / 1e3 / peak_gbs, 4)}
+    return out
 
 
 def timed(fn, n):

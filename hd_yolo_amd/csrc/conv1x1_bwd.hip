@@ -61,6 +61,23 @@ __device__ __forceinline__ float dsilu_f(float u) {
     return s * (1.0f + u * (1.0f - s));
 }
 
+// The element-wise part of this kernel was its bound (PMC, 64<>64 @160x160: 6.2e7 VALU wave-instructions for 1.05e8 elements = 38 lane
+// instructions per element, ~180 us of VALU issue in a 258 us launch whose bytes take 167 us).  It now runs on PAIRS of channels with packed
+// fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two lanes' worth per issue) and explicit FMAs (the file is built with
+// -ffp-contract=off): 17 packed / conversion instructions + 4 quarter-rate transcendentals per pair instead of ~27 + 4 per ELEMENT.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+// d SiLU(u) / du = s (1 + u (1 - s)), s = sigmoid(u) by v_exp_f32 + v_rcp_f32 (the same exponent argument as __expf(-u))
+__device__ __forceinline__ f32x2 dsilu2(f32x2 u) {
+    const f32x2 one = {1.0f, 1.0f};
+    const f32x2 e = u * f32x2{-1.4426950408889634f, -1.4426950408889634f};
+    const f32x2 t = f32x2{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)} + one;
+    const f32x2 s = {__builtin_amdgcn_rcpf(t.x), __builtin_amdgcn_rcpf(t.y)};
+    return s * fma2(u, one - s, one);
+}
+// the two bf16 values of one dword as fp32
+__device__ __forceinline__ f32x2 bf16_pair(int w) { return f32x2{__uint_as_float((unsigned)w << 16), __uint_as_float((unsigned)w & 0xFFFF0000u)}; }
+
 // BM pixels per tile, NXB x-tile buffers (2: the next tile's x is fetched during this tile's MFMAs; 1: after them, for the instance
 // whose LDS budget must leave room for a second workgroup on the CU — the other workgroup's phases cover the wait)
 template <int KT, int CT, int BM, int NXB>
@@ -150,9 +167,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_kernel(const FusedArgs p) 
     // statistics served by the dx store loop (instances up to 64 channels: the 128-wide one has no registers to spare): a thread owns
     // one 16-byte channel chunk of dx for the whole launch
     constexpr bool STATS_OK = CT <= 64;
-    float bs1[8], bs2[8];
+    f32x2 bs1[4], bs2[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bs1[e] = bs2[e] = 0.f;
+    for (int e = 0; e < 4; ++e) bs1[e] = bs2[e] = f32x2{0.f, 0.f};
     int st_req = -1;
     {
         const int kc0 = (tid % (CT * 2 / 16)) * 8;
@@ -183,20 +200,27 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_kernel(const FusedArgs p) 
             *(f32x4*)(mu + 4 * h) = *(const f32x4*)(sCo + 2 * KT + c0 + 4 * h); *(f32x4*)(is + 4 * h) = *(const f32x4*)(sCo + 3 * KT + c0 + 4 * h);
             *(f32x4*)(k1 + 4 * h) = *(const f32x4*)(sCo + 4 * KT + c0 + 4 * h); *(f32x4*)(k2 + 4 * h) = *(const f32x4*)(sCo + 5 * KT + c0 + 4 * h);
         }
+        f32x2 sc2[4], sh2[4], is2[4], nm2[4], k12[4], nk22[4];       // channel pairs; xhat = y * invstd + (-mean * invstd)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            sc2[q] = f32x2{sc[2 * q], sc[2 * q + 1]}; sh2[q] = f32x2{sh[2 * q], sh[2 * q + 1]};
+            is2[q] = f32x2{is[2 * q], is[2 * q + 1]}; nm2[q] = f32x2{-mu[2 * q] * is[2 * q], -mu[2 * q + 1] * is[2 * q + 1]};
+            k12[q] = f32x2{k1[2 * q], k1[2 * q + 1]}; nk22[q] = f32x2{-k2[2 * q], -k2[2 * q + 1]};
+        }
 #pragma unroll
         for (int j = 0; j < NPASS; ++j) {
             const int row = r0 + j * RPP;
-            V16 gv, yv, o;
-            gv.i = gq[j];
-            yv.i = vq[j];
+            V16 o;
+            const i32x4 gw = gq[j], yw = vq[j];
             const bool live = t * BM + row < p.M;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float v = (float)yv.h[i];
-                const float du = (float)gv.h[i] * dsilu_f(v * sc[i] + sh[i]);
-                const float xh = (v - mu[i]) * is[i];
-                const float d = sc[i] * (du - k1[i] - xh * k2[i]);
-                o.h[i] = (bf16_t)(live ? d : 0.0f);
+            for (int q = 0; q < 4; ++q) {
+                const f32x2 v = bf16_pair(yw[q]), g = bf16_pair(gw[q]);
+                const f32x2 du = g * dsilu2(fma2(v, sc2[q], sh2[q]));
+                const f32x2 xh = fma2(v, is2[q], nm2[q]);
+                const f32x2 d = sc2[q] * fma2(xh, nk22[q], du - k12[q]);        // scale * (du - c1 - xhat * c2)
+                o.h[2 * q] = (bf16_t)(live ? d.x : 0.0f);
+                o.h[2 * q + 1] = (bf16_t)(live ? d.y : 0.0f);
             }
             *(i32x4*)(sD + (ch >> 3) * SUB + toff(row, ch & 7)) = o.i;
         }
@@ -296,24 +320,40 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_kernel(const FusedArgs p) 
                     }
                 }
             }
-            i32x4 ynext = {0, 0, 0, 0};                             // statistics: the next row's raw output is requested one row ahead
+            // statistics: the raw outputs of ALL of this thread's rows of the tile are requested up front (one row ahead — the first version —
+            // made the store loop a chain of NIT global-load latencies per tile)
+            constexpr int NIT = BM / RPI;
+            i32x4 yrows[NIT];
             if constexpr (STATS_OK) {
-                if (st_y && t * BM + rr < p.M) ynext = *(const i32x4*)(st_y + (size_t)(t * BM + rr) * st_ldy);
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int m = t * BM + rr + it * RPI;
+                    yrows[it] = (st_y && m < p.M) ? *(const i32x4*)(st_y + (size_t)m * st_ldy) : i32x4{0, 0, 0, 0};
+                }
             }
-#pragma unroll 4
-            for (int row = rr; row < BM; row += RPI) {
+            // accumulate: the gradient already in dx, all rows in flight too (not in the 128-wide instance: it sits at 255 registers and
+            // got 30 % slower with the extra live values; it loads row by row as before)
+            constexpr bool PRE = CT <= 64;
+            i32x4 arows[PRE ? NIT : 1];
+            if (PRE && p.accumulate) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int m = t * BM + rr + it * RPI;
+                    arows[it] = m < p.M ? *(const i32x4*)(dx + (size_t)m * p.lddx + cc * 8) : i32x4{0, 0, 0, 0};
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int row = rr + it * RPI;
                 const int m = t * BM + row;
                 if (m >= p.M) break;
                 V16 v, yv;
-                yv.i = ynext;
-                if constexpr (STATS_OK) {
-                    if (st_y && row + RPI < BM && m + RPI < p.M) ynext = *(const i32x4*)(st_y + (size_t)(m + RPI) * st_ldy);
-                }
+                yv.i = STATS_OK ? yrows[it] : i32x4{0, 0, 0, 0};
                 v.i = *(const i32x4*)(sD + row * ROWB + ((cc ^ ((row & SWM) >> 1)) << 4));
                 bf16_t* dst = dx + (size_t)m * p.lddx + cc * 8;
                 if (p.accumulate) {
                     V16 q;
-                    q.i = *(const i32x4*)dst;
+                    q.i = PRE ? arows[PRE ? it : 0] : *(const i32x4*)dst;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v.h[e] = (bf16_t)((float)v.h[e] + (float)q.h[e]);
                 }
@@ -321,12 +361,12 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_kernel(const FusedArgs p) 
                 if constexpr (STATS_OK) {
                     if (st_y) {                                     // v = the final gradient of this pixel, as the consumer will read it
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const float yy = (float)yv.h[e];
-                            float du = (float)v.h[e];
-                            if (st_act == 1) du *= dsilu_f(yy * st_sc[e] + st_sh[e]);
-                            bs1[e] += du;
-                            bs2[e] += du * yy;
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x2 yy = bf16_pair(yv.i[q]);
+                            f32x2 du = bf16_pair(v.i[q]);
+                            if (st_act == 1) du = du * dsilu2(fma2(yy, f32x2{st_sc[2 * q], st_sc[2 * q + 1]}, f32x2{st_sh[2 * q], st_sh[2 * q + 1]}));
+                            bs1[q] = bs1[q] + du;
+                            bs2[q] = fma2(du, yy, bs2[q]);
                         }
                     }
                 }
@@ -340,7 +380,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_kernel(const FusedArgs p) 
         float* red = (float*)sD;                                     // [256][16]; D / staging are free
         __syncthreads();
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { red[tid * 16 + e] = bs1[e]; red[tid * 16 + 8 + e] = bs2[e]; }
+        for (int e = 0; e < 8; ++e) { red[tid * 16 + e] = bs1[e >> 1][e & 1]; red[tid * 16 + 8 + e] = bs2[e >> 1][e & 1]; }
         __syncthreads();
         for (int j = tid; j < CPR * 16; j += 256) {
             const int ch = j / 16, e16 = j - ch * 16;
