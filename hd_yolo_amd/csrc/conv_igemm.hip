@@ -834,6 +834,7 @@ int hdy_conv_igemm_launch(ConvArgs a, int dtype, int out_f32, hipStream_t st) {
         if (hdy_conv_stem_try(a, dtype, out_f32, st, &rc)) return rc;         // patch-resident 6x6/s2 stem
         if (hdy_conv3x3_c64_try(a, dtype, out_f32, st, &rc)) return rc;      // filter-resident 3x3 kernel when the shape qualifies
         if (hdy_conv3x3s2_c32_try(a, dtype, out_f32, st, &rc)) return rc;    // patch-resident 3x3 / stride 2 kernel (32 input channels)
+        if (hdy_conv3x3_wide_try(a, dtype, out_f32, st, &rc)) return rc;     // patch-resident 3x3 of the wide layers (C % 64 == 0, C, K >= 128)
         if (hdy_conv_deep_try(a, dtype, out_f32, st, &rc)) return rc;        // deep-pipelined 256-row kernel (C % 64 == 0, K >= 128)
         // the slab count the caller sized its statistics buffer with must be the generic kernel's from here on
         HDY_ARG(!a.stats || a.span_pixels || hdy_conv_deep_slabs(a.M, a.C, a.K, a.TH * a.TW, a.pointwise, dtype) == 0,

@@ -96,5 +96,7 @@ int hdy_conv_igemm_stat_grid(long long M, int K, int taps, int ncls);
 int hdy_dgrad3x3s2_try(const ConvArgs& a, int dtype, hipStream_t st, int* rc);
 int hdy_conv3x3s2_c32_try(const ConvArgs& a, int dtype, int out_f32, hipStream_t st, int* rc);
 int hdy_conv_deep_try(const ConvArgs& a, int dtype, int out_f32, hipStream_t st, int* rc);
+int hdy_conv3x3_wide_try(const ConvArgs& a, int dtype, int out_f32, hipStream_t st, int* rc);
+int hdy_conv3x3_wide_slabs(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dtype);
 int hdy_conv_deep_slabs(long long M, int C, int K, int taps, int pointwise, int dtype);
 int hdy_conv3x3s2_c32_slabs(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dtype);

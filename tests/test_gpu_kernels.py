@@ -186,21 +186,38 @@ DEEP_CASES = [
     (1, 20, 20, 64, 136, 3, 1, 1),       # K not a multiple of 16: ragged last column tile
     (8, 96, 96, 64, 128, 1, 1, 0),       # 288 row tiles on 256 workgroups: some walk two tiles, one K-tile each
     (5, 96, 96, 64, 128, 3, 1, 1),       # 180 row tiles, nine K-tiles each
+    # the patch-resident 3x3 kernel of the wide layers (conv3x3_wide.hip: C % 64 == 0, C >= 128) beyond the three 3x3 rows above
+    (1, 64, 64, 128, 128, 3, 1, 1),      # 8 x 32 blocks, two across
+    (1, 32, 80, 128, 128, 3, 1, 1),      # 16 x 16 blocks (fewer tiles than 8 x 32), ragged right edge
+    (2, 37, 70, 192, 136, 3, 1, 1),      # blocks ragged on both edges, three channel blocks, K not a multiple of 16
+    (8, 96, 96, 128, 128, 3, 1, 1),      # 288 blocks on 256 workgroups: some walk two tiles (the patch stream crosses tiles)
+    (70, 20, 20, 128, 256, 3, 1, 1),     # flattened 256-pixel tiles: two per image (the second 144 pixels), two column tiles, 280 tiles
 ]
 
 
-@pytest.mark.parametrize('bn', [0, 128, 256])
+def deep_family(C, K, R, stride, pad):
+    """kernel family that takes a bf16 conv with C input / K output channels among the two deep-pipelined kernels"""
+    if R == 3 and stride == 1 and pad == 1 and C % 64 == 0 and C >= 128 and K >= 128:
+        return 'wide3x3_256x128'
+    return 'deep_256x'
+
+
+@pytest.mark.parametrize('bn', [0, 128, 256, 'wide'])
 @pytest.mark.parametrize('case', DEEP_CASES)
 def test_deep_pipelined_conv(case, bn):
     """conv_deep.hip (256-row tiles, loads in flight across barriers) on shapes the plan would give to the generic kernel at test size:
     HDY_DEEP_MIN_TILES = 1 sends them to it; both column tiles (HDY_DEEP_BN); forward with BatchNorm sums, epilogue with scale / shift /
     SiLU / accumulate, stride-1 data gradient with accumulate — against torch fp32 on the CPU, and the dispatch log must name the kernel"""
     N, H, W, C, K, R, stride, pad = case
-    with _lib.option('HDY_DEEP_MIN_TILES', 1), _lib.option('HDY_DEEP_BN', bn), _lib.option('HDY_DEEP_ALL', 1), _lib.option('HDY_DEEP_WALK', 1):
+    wide = 1 if bn == 'wide' else 0                              # the opt-in patch-resident 3x3 kernel (conv3x3_wide.hip) takes the 3x3 rows with C >= 128
+    bn = 0 if bn == 'wide' else bn
+    with _lib.option('HDY_DEEP_MIN_TILES', 1), _lib.option('HDY_DEEP_BN', bn), _lib.option('HDY_DEEP_ALL', 1), _lib.option('HDY_DEEP_WALK', 1), \
+            _lib.option('HDY_WIDE3', wide):
         log_fwd, log_dgrad, _ = conv_case(case, torch.bfloat16)
-    assert log_fwd == ['deep_256x128'], log_fwd                  # statistics: 128-wide instances
+    fam = deep_family(C, K, R, stride, pad) if wide else 'deep_256x'
+    assert log_fwd == [fam if fam.startswith('wide') else 'deep_256x128'], log_fwd                  # statistics: 128-wide instances
     if stride == 1 and K % 64 == 0 and C >= 128:
-        assert log_dgrad and log_dgrad[0].startswith('deep_256x'), log_dgrad
+        assert log_dgrad and log_dgrad[0].startswith(deep_family(K, C, R, stride, pad) if wide else 'deep_256x'), log_dgrad
     if stride == 2 and K % 64 == 0 and C >= 128:
         assert log_dgrad and log_dgrad[0].startswith('deep_256x') and log_dgrad[0].endswith('_walk'), log_dgrad
         with _lib.option('HDY_DEEP_MIN_TILES', 1):
@@ -214,10 +231,11 @@ def test_deep_pipelined_conv(case, bn):
     outs = []
     for off in (0, 1):
         y = torch.zeros((N, Ho, Wo, K), dtype=torch.bfloat16, device=DEV)
-        with _lib.option('HDY_DEEP_MIN_TILES', 1), _lib.option('HDY_DEEP_BN', bn), _lib.option('HDY_DEEP_ALL', 1), _lib.option('HDY_NO_DEEP', off):
+        with _lib.option('HDY_DEEP_MIN_TILES', 1), _lib.option('HDY_DEEP_BN', bn), _lib.option('HDY_DEEP_ALL', 1), _lib.option('HDY_NO_DEEP', off), \
+                _lib.option('HDY_WIDE3', wide if off == 0 else 0):
             _lib.dispatch_log(reset=True)
             ops.run([ops.rec_pack(w, None, stride, pad, ops.PACK_FWD, wp), ops.rec_conv_fwd(xd, wp, y, K, R, R, stride, pad)])
-            assert any(n.startswith('deep_') for n in _lib.dispatch_log()) == (off == 0)
+            assert any(n.startswith(('deep_', 'wide3x3')) for n in _lib.dispatch_log()) == (off == 0)
         outs.append(y.float())
     d = (outs[0] - outs[1]).abs().max().item()
     assert d <= 2.0 ** -7 * outs[1].abs().max().item(), f'deep vs generic kernel differ by {d}'
