@@ -27,6 +27,7 @@
 // besides its 16 MFMAs (barriers, DMA issue, LDS latency), not by the bytes it stages — conv_deep.hip's "47 B/clk against 36" was not the limit — and
 // this kernel adds per-lane address arithmetic (VALU instructions 8.6 M vs 4.5 M) and per-image tile quantisation (448 tiles for 400 tiles' worth of
 // pixels at 40 x 40).  Timing ablations (-DHDY_W3_DBG=1): all DMA off 76 -> 73 us, MFMAs off 60, fragment reads off 54, everything off 41.
+// With the address arithmetic dealt out between the MFMAs (sched_group_barrier: yolov5l 3x3 layers 20 % -> 10 % slower than conv_deep.hip) it still loses.
 // What carries over: the rotation swizzle below (fragment rows read at ANY alignment without bank conflicts: 21 % -> 8 % conflict cycles).
 //
 // Reference semantics replaced: nn.Conv2d(k = 3, s = 1, p = 1) inside metayolo/models/layers.py:92-93 (Bottleneck.cv2), its autograd
@@ -293,6 +294,9 @@ __global__ __launch_bounds__(NTHR, 2) void conv3x3_wide_kernel(const ConvArgs p,
     long long kt_done = 0;                                        // K-tiles consumed (for the end-of-stream waits)
     bool pprev = false;                                           // a patch instruction was issued in the previous K-tile's phase 1
 
+// The address arithmetic of the reads that FOLLOW a compute segment (per-lane patch addresses: ~10 VALU instructions per 16-row sub-tile) is written
+// in front of the segment's MFMAs and the scheduler is asked to deal it out between them (one MFMA, two VALU instructions, ...): an MFMA holds the
+// matrix pipe for 16 cycles and the issue port for 4, the wave's own VALU work fits in the shadow instead of extending the segment.
 #define W3_MFMA(A_, AF)                                                                                                                 \
     if (!(dbg & 4)) {                                                                                                                                   \
         __builtin_amdgcn_s_setprio(1);                                                                                                  \
@@ -300,6 +304,10 @@ __global__ __launch_bounds__(NTHR, 2) void conv3x3_wide_kernel(const ConvArgs p,
             _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                                               \
                 _Pragma("unroll") for (int n = 0; n < 4; ++n)                                                                           \
                     acc[AI(A_, m, n)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfa[n][kh].h, AF[m][kh].h, acc[AI(A_, m, n)], 0, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                                                \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                          \
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                                                                          \
+        }                                                                                                                               \
         __builtin_amdgcn_s_setprio(0);                                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                                              \
     }
@@ -329,13 +337,14 @@ __global__ __launch_bounds__(NTHR, 2) void conv3x3_wide_kernel(const ConvArgs p,
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
+                unsigned ra0[MT], ra1[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) a_addr(1, m, tap, pbase, ra0[m], ra1[m]);
                 W3_MFMA(0, afl)
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
-                    unsigned ad0, ad1;
-                    a_addr(1, m, tap, pbase, ad0, ad1);
-                    W3_READ(afh[m][0].i, ad0);
-                    W3_READ(afh[m][1].i, ad1);
+                    W3_READ(afh[m][0].i, ra0[m]);
+                    W3_READ(afh[m][1].i, ra1[m]);
                 }
                 __builtin_amdgcn_s_barrier();
                 // ---- phase 2: rows 128..255; afterwards the next K-tile's rows 0..127 fragments and filter fragments.
@@ -344,24 +353,26 @@ __global__ __launch_bounds__(NTHR, 2) void conv3x3_wide_kernel(const ConvArgs p,
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
-                W3_MFMA(1, afh)
                 ++kt_done;
                 const unsigned cnext = cb_off + (unsigned)BUNIT == (unsigned)(NB * BUNIT) ? 0u : cb_off + (unsigned)BUNIT;
-                if (kt_done < total_kt) {
-                    // next K-tile: the same patch at the next tap, or the next channel block's / tile's patch (the other buffer) at tap 0
-                    const bool newp = tap == 8;
-                    const int ntap = newp ? 0 : tap + 1;
-                    unsigned pbn = pbase;
-                    if (newp) {
-                        pbn = (pbase - lds0) == (unsigned)L_PATCH ? lds0 + (unsigned)(L_PATCH + PATCH_B) : lds0 + (unsigned)L_PATCH;
-                        if (cb + 1 == g.ncb) cons_set_tile(j + 1);        // fragment geometry of the next tile (its output pixels after this tile's epilogue)
-                    }
+                const bool more = kt_done < total_kt;
+                // next K-tile: the same patch at the next tap, or the next channel block's / tile's patch (the other buffer) at tap 0
+                const bool newp = tap == 8;
+                const int ntap = newp ? 0 : tap + 1;
+                unsigned pbn = pbase;
+                if (more && newp) {
+                    pbn = (pbase - lds0) == (unsigned)L_PATCH ? lds0 + (unsigned)(L_PATCH + PATCH_B) : lds0 + (unsigned)L_PATCH;
+                    if (cb + 1 == g.ncb) cons_set_tile(j + 1);            // fragment geometry of the next tile (its output pixels after this tile's epilogue)
+                }
+                unsigned rb0[MT], rb1[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) a_addr(0, m, ntap, pbn, rb0[m], rb1[m]);
+                W3_MFMA(1, afh)
+                if (more) {
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
-                        unsigned ad0, ad1;
-                        a_addr(0, m, ntap, pbn, ad0, ad1);
-                        W3_READ(afl[m][0].i, ad0);
-                        W3_READ(afl[m][1].i, ad1);
+                        W3_READ(afl[m][0].i, rb0[m]);
+                        W3_READ(afl[m][1].i, rb1[m]);
                     }
 #pragma unroll
                     for (int kh = 0; kh < 2; ++kh) {
