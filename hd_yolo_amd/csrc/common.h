@@ -42,7 +42,7 @@ enum HdyOption {
     HDY_OPT_DEEP_ALL,          // HDY_DEEP_ALL: 1 (default) the deep-pipelined kernel takes multi-tap (3x3) layers too, 0 the 1x1 layers only
     HDY_OPT_F1X1_SMALL,        // HDY_F1X1_SMALL: fused 1x1 backward with 64-pixel tiles / four workgroups per CU for the 32- and 64-wide instances
     HDY_OPT_DEEP_MIN_TILES,    // HDY_DEEP_MIN_TILES: fewest 256-row tiles the deep-pipelined kernel takes a layer with (default 160)
-    HDY_OPT_DEEP_WALK,         // HDY_DEEP_WALK=1: stride-2 data gradients (four-class walk) on the deep pipeline (default 0: measured no faster at the bench shapes)
+    HDY_OPT_DEEP_WALK,         // HDY_DEEP_WALK: stride-2 data gradients (four-class walk) on the deep pipeline: 0 never, 1 always, 2 (default) with >= 256 output channels
     HDY_OPT_WIDE3,             // HDY_WIDE3=1: patch-resident 3x3 kernel of the wide layers (conv3x3_wide.hip; default 0: measured no faster than conv_deep.hip)
     HDY_OPT_COUNT
 };

@@ -657,7 +657,8 @@ int hdy_conv_deep_try(const ConvArgs& a_in, int dtype, int out_f32, hipStream_t 
     if (dtype != HDY_BF16 || out_f32 || a_in.nstat > 0 || (!a_in.dense_out && !walk) || a_in.span_pixels || !a_in.vec_out || !a_in.utap) return 0;
     // measured at the yolov5s bench shapes (B = 64, scripts/probes/dgrad_walk.py): 105 / 80 / 62 / 48 us here against 94 / 86 / 59 / 51 us for
     // conv_igemm.hip's 128-row walk, and 12.37-12.45 against 12.30 ms in the train step.  Opt-in.
-    if (walk && !hdy_opt(HDY_OPT_DEEP_WALK)) return 0;
+    // HDY_DEEP_WALK: 0 never, 1 always, 2 (default) where it measured faster: 256 or more gradient channels out (256<-512 @40x40 80.5 vs 85.9 us, 256<-256 47.5 vs 51.1)
+    if (walk && (hdy_opt(HDY_OPT_DEEP_WALK) == 0 || (hdy_opt(HDY_OPT_DEEP_WALK) == 2 && a_in.K < 256))) return 0;
     int bn = 0;
     if (!deep_shape_ok(a_in.M, a_in.C, a_in.K, a_in.TH * a_in.TW, a_in.pointwise != 0, a_in.stats != nullptr, &bn, walk ? 4 : 1)) return 0;
     if (a_in.ldx % 8 != 0) return 0;

@@ -220,8 +220,10 @@ def test_deep_pipelined_conv(case, bn):
         assert log_dgrad and log_dgrad[0].startswith(deep_family(K, C, R, stride, pad) if wide else 'deep_256x'), log_dgrad
     if stride == 2 and K % 64 == 0 and C >= 128:
         assert log_dgrad and log_dgrad[0].startswith('deep_256x') and log_dgrad[0].endswith('_walk'), log_dgrad
-        with _lib.option('HDY_DEEP_MIN_TILES', 1):
-            assert conv_case(case, torch.bfloat16)[1][0].startswith('igemm_')      # default: the generic kernel's walk (HDY_DEEP_WALK = 0)
+        with _lib.option('HDY_DEEP_MIN_TILES', 1):                 # default (HDY_DEEP_WALK = 2): the deep pipeline from 256 gradient channels out, else the generic kernel's walk
+            assert conv_case(case, torch.bfloat16)[1][0].startswith('deep_256x' if C >= 256 else 'igemm_')
+        with _lib.option('HDY_DEEP_MIN_TILES', 1), _lib.option('HDY_DEEP_WALK', 0):
+            assert conv_case(case, torch.bfloat16)[1][0].startswith('igemm_')
     # A/B: the same forward through the generic kernel agrees to the last bf16 rounding (both accumulate in fp32 over the same k order per tap)
     x = q(rnd((N, C, H, W), 11), torch.bfloat16)
     xd = to_dev_nhwc(x, torch.bfloat16)
