@@ -177,6 +177,10 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        # the product path has no CPU fallback; under `--gpus N` this is the failing rank whose exit code spawn_ranks relays
+        print(f'bench.py rank {rank}: no MI355X visible (torch.cuda.is_available() is False) — hd_yolo_amd has no CPU path', file=sys.stderr, flush=True)
+        sys.exit(3)
     # HDY_FORCE_DIST=1: go through process-group init, DataParallel and the overlapped all-reduce with ONE rank too — the only way to run
     # RCCL itself on a one-GPU box (rehearsal of the N > 1 path, tests/test_gpu_entrypoints.py)
     force_dist = os.environ.get('HDY_FORCE_DIST') == '1'
@@ -275,6 +279,14 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = tmax.item()
     final_loss = float(loss.detach())
+    param_spread = 0.0
+    if world > 1 or force_dist:
+        # every rank must hold the same parameters after the same number of SUM-all-reduced steps: largest minus smallest per-rank checksum
+        chk = torch.stack([p.detach().double().sum() for p in model.parameters()]).sum().reshape(1)
+        hi, lo = chk.clone(), chk.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        param_spread = float(hi - lo)
 
     if rank == 0:
         tiles = args.batch * world * args.steps
@@ -286,7 +298,8 @@ def main():
                                    f'batch {args.batch}/GPU, train step = fwd + DetLoss + bwd + all-reduce + SGD(nesterov)',
                        'global_batch': args.batch * world, 'parallelism': f'dp{world}',
                        'world_size': dist.get_world_size() if (world > 1 or force_dist) else 1, 'backend': backend,
-                       'allreduce_calls_per_step': (round(net.reducer.calls / (args.steps + args.warmup), 2) if (world > 1 or force_dist) else 0)},
+                       'allreduce_calls_per_step': (round(net.reducer.calls / (args.steps + args.warmup), 2) if (world > 1 or force_dist) else 0),
+                       'param_checksum_spread_over_ranks': param_spread},
             'final_loss': round(final_loss, 4),
         }
         from hd_yolo_amd import bench_util

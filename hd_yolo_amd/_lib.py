@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'build', os.path.basename(os.environ.get('HDY_LIB', 'libhdyolo_hip.so')))
 
 F32, BF16 = 0, 1
+OK, EINVAL, EUNSUPPORTED = 0, -1, -2      # status codes (include/hdyolo.h); positive = hipError_t
 PACK_FWD, PACK_DGRAD, PACK_STEM = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
 
@@ -26,8 +27,6 @@ SIGNATURES = {
     'hdy_dispatch_log': (c_char_p, []),
     'hdy_dispatch_log_reset': (None, []),
     'hdy_set_option': (_I, [c_char_p, _I]),
-    'hdy_wgrad_reduce_mode': (_I, [_I, _P, _I]),
-    'hdy_wgrad_reduce_batch': (_I, [_P, _I, _I, _P]),
     'hdy_get_option': (_I, [c_char_p]),
     'hdy_conv_wgrad_stem_fused_ok': (_I, [_I, _I, _I, _I]),
     'hdy_conv_wgrad_stem_fused': (_I, [_P, _P, _I, _P, _I] + [_P] * 6 + [_I, _I, _I, _I, _P, _I, _P, _I, _I, _P, _Z, _P]),
@@ -45,7 +44,7 @@ SIGNATURES = {
     'hdy_conv_pack': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     'hdy_conv_pack_describe': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I]),
     'hdy_conv_pack_run': (_I, [_P, _I, _I, _P]),
-    'hdy_conv_fwd': (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _I, _P] + [_I] * 14 + [_P]),
+    'hdy_conv_fwd': (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _I, _P] + [_I] * 15 + [_P]),
     'hdy_conv_dgrad': (_I, [_P, _I, _P, _P, _I] + [_I] * 11 + [_P]),
     'hdy_conv_wgrad_workspace_bytes': (_Z, [_I] * 11),
     'hdy_conv_wgrad': (_I, [_P, _I, _P, _I] + [_I] * 9 + [_P, _I, _P, _I, _I, _P, _Z, _I, _I, _P]),
@@ -60,26 +59,28 @@ SIGNATURES = {
     'hdy_conv1x1_bwd_fused_workspace_bytes': (_Z, [_L, _I, _I]),
     'hdy_conv1x1_bwd_fused': (_I, [_P, _I, _P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P, _I, _P, _I, _I, _L, _I, _I, _P, _Z, _I, _P]),
     'hdy_groupnorm_workspace_floats': (_Z, [_I, _I]),
-    'hdy_groupnorm_fwd': (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _F, _I, _I, _P, _P]),
-    'hdy_groupnorm_bwd': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    'hdy_groupnorm_fwd': (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _F, _I, _I, _P, _Z, _P]),
+    'hdy_groupnorm_bwd': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
     'hdy_bilinear_fwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'hdy_bilinear_bwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'hdy_bilinear_bwd_axis': (_I, [_P, _I, _P, _I, _L, _I, _I, _I, _I, _I, _I, _P]),
     'hdy_softdice_workspace_floats': (_Z, [_I, _I]),
-    'hdy_softdice': (_I, [_P, _I, _P, _P, _I, _I, _I, _P, _P, _P, _I, _P, _P]),
+    'hdy_softdice': (_I, [_P, _I, _P, _P, _I, _I, _I, _P, _P, _P, _I, _P, _Z, _P]),
     'hdy_softmax2d': (_I, [_P, _I, _P, _I, _L, _I, _P]),
     'hdy_bn_finalize_workspace_bytes': (_Z, [_I, _I]),
-    'hdy_bn_finalize': (_I, [_P, _I, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P]),
+    'hdy_bn_finalize': (_I, [_P, _I, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _Z, _P]),
     'hdy_bn_eval_coeffs': (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
     'hdy_bn_eval_coeffs_batch': (_I, [_P, _I, _P]),
     'hdy_bn_act_fwd': (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _L, _I, _I, _I, _P]),
     'hdy_bn_bwd_blocks': (_I, [_L]),
-    'hdy_bn_finalize_pair': (_I, [_P, _I, _I, _I, _I, _L] + [_P] * 8 + [_F, _F, _P, _P, _P, _P, _P, _P]),
+    'hdy_bn_bwd_workspace_bytes': (_Z, [_L, _I]),
+    'hdy_colsum_workspace_bytes': (_Z, [_L, _I]),
+    'hdy_bn_finalize_pair': (_I, [_P, _I, _I, _I, _I, _L] + [_P] * 8 + [_F, _F, _P, _P, _P, _P, _P, _Z, _P]),
     'hdy_bn_act_fwd_pair': (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _L, _I, _I, _I, _P]),
-    'hdy_bn_act_bwd_pair': (_I, [_P, _I, _P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P, _P]),
-    'hdy_bn_act_bwd': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _L, _I, _I, _I, _P, _P]),
+    'hdy_bn_act_bwd_pair': (_I, [_P, _I, _P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P, _Z, _P]),
+    'hdy_bn_act_bwd': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _L, _I, _I, _I, _P, _Z, _P]),
     'hdy_add_inplace': (_I, [_P, _I, _P, _I, _L, _I, _I, _P]),
-    'hdy_colsum': (_I, [_P, _I, _L, _I, _P, _I, _I, _P, _P]),
+    'hdy_colsum': (_I, [_P, _I, _L, _I, _P, _I, _I, _P, _Z, _P]),
     'hdy_det_grad_pack': (_I, [_P, _L, _L, _L, _L, _L, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'hdy_det_targets': (_I, [_P, _P, _P, _I, _I, _P, _P, _P]),
     'hdy_det_loss_workspace_bytes': (_Z, [_I, _P, _P, _I, _I, _I, _I]),
@@ -94,7 +95,7 @@ SIGNATURES = {
     'hdy_decode': (_I, [_P, _L, _L, _L, _L, _P, _F, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'hdy_nms_workspace_bytes': (_Z, [_I, _I]),
     'hdy_mask_select': (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _F, _F, _P, _P, _P, _P, _P, _Z, _P]),
-    'hdy_softdice_wgrad': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    'hdy_softdice_wgrad': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _Z, _P]),
     'hdy_det_outputs': (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _F, _I, _P, _P, _P, _P, _P]),
     'hdy_nms_batched': (_I, [_P, _I, _I, _I, _I, _F, _F, _I, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     'hdy_nms_boxes': (_I, [_P, _I, _I, _F, _I, _P, _P, _P, _Z, _P]),
@@ -118,12 +119,6 @@ class BnEvalDesc(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in ('gamma', 'beta', 'running_mean', 'running_var', 'scale', 'shift')] + [('K', c_int), ('eps', c_float)]
 
 
-class ReduceDesc(ctypes.Structure):
-    """mirror of hdy_reduce_desc (include/hdyolo.h)"""
-    _fields_ = [('partial', c_void_p), ('grad', c_void_p), ('slab_stride', ctypes.c_ulonglong)] + [(n, c_int) for n in (
-        'splits', 'K', 'Q', 'mode', 'C', 'R', 'S', 'accumulate', 'vec', 'first_block', 'nblocks', 'pad_')]
-
-
 class SgdDesc(ctypes.Structure):
     """mirror of hdy_sgd_desc (include/hdyolo.h)"""
     _fields_ = [('p', c_void_p), ('g', c_void_p), ('buf', c_void_p), ('n', c_longlong), ('group', c_int), ('first', c_int), ('first_block', c_int),
@@ -133,7 +128,7 @@ class SgdDesc(ctypes.Structure):
 class StatReq(ctypes.Structure):
     """mirror of hdy_stat_req (include/hdyolo.h)"""
     _fields_ = [('y', c_void_p), ('ldy', c_int)] + [(n, c_void_p) for n in ('scale', 'shift', 'slabs')] + \
-               [('c0', c_int), ('c1', c_int), ('act', c_int)]
+               [('c0', c_int), ('c1', c_int), ('act', c_int), ('nslabs', c_int)]
 
 
 _lib = None

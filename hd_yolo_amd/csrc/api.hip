@@ -32,8 +32,8 @@ struct OptDef { const char* name; int def; bool flag; };       // flag: the vari
 const OptDef g_opt_def[HDY_OPT_COUNT] = {
     {"HDY_NO_CLASS_WALK", 0, true}, {"HDY_NO_CONV3X3", 0, true}, {"HDY_C3_GRID", 0, false}, {"HDY_NO_CONV3X3S2", 0, true},
     {"HDY_NO_DGRAD_S2", 0, true}, {"HDY_TILE_INTERLEAVE", 1, false}, {"HDY_NO_BIG_TILES", 0, true}, {"HDY_NO_STEM_KERNEL", 0, true},
-    {"HDY_WGRAD_BLOCKS", 512, false}, {"HDY_NO_STEM_WGRAD", 0, true}, {"HDY_NO_WGRAD3X3", 0, true}, {"HDY_WGRAD3X3_S2", 0, true},
-    {"HDY_LOSS_GRID", 2048, false}, {"HDY_NO_DEEP", 0, true}, {"HDY_NO_WGRAD_S2", 0, true}, {"HDY_NO_WGRAD_DEEP", 0, true}, {"HDY_WGRAD_DEEP_1X1", 0, false}, {"HDY_WGRAD_DEEP_S1", 0, false}, {"HDY_DEEP_BN", 0, false}, {"HDY_DEEP_DEBUG", 0, false}, {"HDY_DEEP_ALL", 1, false}, {"HDY_F1X1_SMALL", 0, false}, {"HDY_DEEP_MIN_TILES", 160, false}, {"HDY_DEEP_WALK", 2, false}, {"HDY_WIDE3", 0, false},
+    {"HDY_WGRAD_BLOCKS", 512, false}, {"HDY_NO_STEM_WGRAD", 0, true}, {"HDY_NO_WGRAD3X3", 0, true}, 
+    {"HDY_LOSS_GRID", 2048, false}, {"HDY_NO_DEEP", 0, true}, {"HDY_NO_WGRAD_S2", 0, true}, {"HDY_NO_WGRAD_DEEP", 0, true}, {"HDY_DEEP_BN", 0, false}, {"HDY_DEEP_DEBUG", 0, false}, {"HDY_DEEP_ALL", 1, false}, {"HDY_DEEP_MIN_TILES", 160, false}, {"HDY_DEEP_WALK", 2, false},
 };
 std::atomic<int> g_opt[HDY_OPT_COUNT];
 std::once_flag g_opt_once;
@@ -162,8 +162,6 @@ int hdy_conv_stat_slabs(int N, int H, int W, int C, int K, int R, int S, int str
         own = hdy_conv_stem_slabs(N, H, W, K, dtype);
         if (own > 0) return own;
     }
-    own = hdy_conv3x3_wide_slabs(N, H, W, C, K, R, S, stride, pad, dtype);
-    if (own > 0) return own;
     const long long M = (long long)N * hdy_conv_out_dim(H, R, stride, pad) * hdy_conv_out_dim(W, S, stride, pad);
     if (!stem) {
         own = hdy_conv_deep_slabs(M, C, K, R * S, R == 1 && S == 1 && stride == 1 && pad == 0, dtype);
@@ -257,12 +255,13 @@ int hdy_conv_pack_run(const hdy_pack_desc* descs_device, int ndesc, int total_bl
 // y = act(scale * conv(x, w) + shift) [+= y]; NHWC with pixel pitches; optional BatchNorm slabs in `stats`.
 // stem != 0: x is the hdy_stem_prep() buffer [N][H+2*pad][W+2*pad][4] and (C,R,S,stride,pad) must be (3,6,6,2,2).
 int hdy_conv_fwd(const void* x, int ldx, const void* w_packed, const float* scale, const float* shift, const void* res, int ldr, void* y,
-                 int ldy, float* stats, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int act, int accumulate,
+                 int ldy, float* stats, int stat_slabs, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int act, int accumulate,
                  int dtype, int out_f32, int stem, void* stream) {
+    HDY_ARG(!stats || stat_slabs > 0, "conv_fwd: stats given with stat_slabs = %d", stat_slabs);
     HDY_ARG(stride >= 1 && R >= 1 && S >= 1 && pad >= 0, "conv_fwd: bad window");
     HDY_ARG(dtype == HDY_BF16 || dtype == HDY_F32, "conv_fwd: unknown dtype %d", dtype);
     ConvArgs a = {};
-    a.x = x; a.w = w_packed; a.y = y; a.scale = scale; a.shift = shift; a.stats = stats; a.res = res; a.ldr = ldr;
+    a.x = x; a.w = w_packed; a.y = y; a.scale = scale; a.shift = shift; a.stats = stats; a.stat_cap = stat_slabs; a.res = res; a.ldr = ldr;
     HDY_ARG(!res || ldr >= K, "conv_fwd: residual pitch %d < K", ldr);
     a.N = N;
     a.Ho = hdy_conv_out_dim(H, R, stride, pad);
@@ -322,7 +321,7 @@ static int dgrad_impl(const void* dy, int lddy, const void* w_packed_dgrad, void
     a.ih_mul = a.iw_mul = 1; a.accumulate = accumulate;
     a.nstat = nstat;
     for (int r = 0; r < nstat; ++r)
-        a.stat[r] = StatReq{stats[r].y, stats[r].ldy, stats[r].scale, stats[r].shift, stats[r].slabs, stats[r].c0, stats[r].c1, stats[r].act};
+        a.stat[r] = StatReq{stats[r].y, stats[r].ldy, stats[r].scale, stats[r].shift, stats[r].slabs, stats[r].c0, stats[r].c1, stats[r].act, stats[r].nslabs};
     if (stride == 1) {
         a.w = w_packed_dgrad;
         a.Ho = H; a.Wo = W; a.oh_mul = a.ow_mul = 1; a.dense_out = 1;
@@ -427,10 +426,7 @@ int hdy_conv_wgrad(const void* x, int ldx, const void* dy, int lddy, int N, int 
     const int Q = a.TH * a.TW * a.C;
     const int stem_grid = stem ? hdy_wgrad_stem_grid(N, a.Ho, a.Wo, K, dtype) : 0;
     int rc;
-    if (!stem && hdy_opt(HDY_OPT_WGRAD_DEEP_S1) &&
-        hdy_wgrad_deep_try(x, ldx, dy, lddy, N, H, W, a.Ho, a.Wo, C, K, R, S, stride, pad, a.partial, dtype, (hipStream_t)stream, &a.splits, &rc)) {
-        // deep-pipelined kernel ahead of the patch-resident one (A/B switch)
-    } else if (!stem && R == 3 && S == 3 && pad == 1 &&
+    if (!stem && R == 3 && S == 3 && pad == 1 &&
         hdy_wgrad3x3_try(x, ldx, dy, lddy, N, H, W, a.Ho, a.Wo, C, K, stride, a.partial, dtype, (hipStream_t)stream, &a.splits, &rc)) {
         // patch-resident kernel launched (conv_wgrad3x3.hip)
     } else if (!stem && hdy_wgrad_deep_try(x, ldx, dy, lddy, N, H, W, a.Ho, a.Wo, C, K, R, S, stride, pad, a.partial, dtype, (hipStream_t)stream, &a.splits, &rc)) {

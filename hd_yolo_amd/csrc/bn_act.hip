@@ -507,8 +507,10 @@ extern "C" {
 size_t hdy_bn_finalize_workspace_bytes(int mtiles, int K) { return mtiles > 1024 ? (size_t)32 * 2 * K * sizeof(double) : 0; }
 
 static int bn_finalize_impl(const float* stats, int stats_ld, int mtiles, int K, long long count, const BnParams& bn, float eps, float momentum,
-                            float* scale, float* shift, float* save_mean, float* save_invstd, void* workspace, void* stream) {
+                            float* scale, float* shift, float* save_mean, float* save_invstd, void* workspace, size_t ws_bytes, void* stream) {
     HDY_ARG(stats && bn.gamma && bn.beta && scale && shift && save_mean && save_invstd, "bn_finalize: null pointer");
+    HDY_ARG(!workspace || ws_bytes >= hdy_bn_finalize_workspace_bytes(mtiles, K), "bn_finalize: workspace of %zu bytes, %zu needed", ws_bytes,
+            hdy_bn_finalize_workspace_bytes(mtiles, K));
     HDY_ARG(mtiles > 0 && K > 0 && count > 0 && stats_ld >= K, "bn_finalize: bad sizes");
     HDY_ARG((bn.rmean == nullptr) == (bn.rvar == nullptr), "bn_finalize: running_mean/var must both be given or both null");
     HDY_ARG(bn.Ka == K || (bn.Ka > 0 && bn.Ka < K && bn.gamma_b && bn.beta_b && (bn.rmean_b == nullptr) == (bn.rvar_b == nullptr)),
@@ -532,17 +534,17 @@ static int bn_finalize_impl(const float* stats, int stats_ld, int mtiles, int K,
 
 int hdy_bn_finalize(const float* stats, int stats_ld, int mtiles, int K, long long count, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float eps, float momentum, float* scale, float* shift, float* save_mean, float* save_invstd,
-                    void* workspace, void* stream) {
+                    void* workspace, size_t ws_bytes, void* stream) {
     const BnParams bn = {gamma, beta, running_mean, running_var, nullptr, nullptr, nullptr, nullptr, K};
-    return bn_finalize_impl(stats, stats_ld, mtiles, K, count, bn, eps, momentum, scale, shift, save_mean, save_invstd, workspace, stream);
+    return bn_finalize_impl(stats, stats_ld, mtiles, K, count, bn, eps, momentum, scale, shift, save_mean, save_invstd, workspace, ws_bytes, stream);
 }
 
 int hdy_bn_finalize_pair(const float* stats, int stats_ld, int mtiles, int K, int Ka, long long count, const float* gamma_a, const float* beta_a,
                          float* running_mean_a, float* running_var_a, const float* gamma_b, const float* beta_b, float* running_mean_b,
                          float* running_var_b, float eps, float momentum, float* scale, float* shift, float* save_mean, float* save_invstd,
-                         void* workspace, void* stream) {
+                         void* workspace, size_t ws_bytes, void* stream) {
     const BnParams bn = {gamma_a, beta_a, running_mean_a, running_var_a, gamma_b, beta_b, running_mean_b, running_var_b, Ka};
-    return bn_finalize_impl(stats, stats_ld, mtiles, K, count, bn, eps, momentum, scale, shift, save_mean, save_invstd, workspace, stream);
+    return bn_finalize_impl(stats, stats_ld, mtiles, K, count, bn, eps, momentum, scale, shift, save_mean, save_invstd, workspace, ws_bytes, stream);
 }
 
 // ---- SyncBatchNorm (reference: train.py:281-283 converts the model with torch.nn.SyncBatchNorm when --sync-bn): the per-rank slabs are
@@ -636,13 +638,17 @@ int hdy_bn_bwd_blocks(long long M) {
     return (int)b;
 }
 
+size_t hdy_bn_bwd_workspace_bytes(long long M, int K) { return ((size_t)hdy_bn_bwd_blocks(M) * 2 * K + 2 * (size_t)K) * sizeof(float); }
+size_t hdy_colsum_workspace_bytes(long long M, int K) { return (size_t)hdy_bn_bwd_blocks(M) * 2 * K * sizeof(float); }
+
 // Full backward of z = act(BN_train(y)) [+ res]:  dy, and dgamma/dbeta (+)=.
-// workspace: (hdy_bn_bwd_blocks(M)*2*K + 2*K) floats.
+// workspace: hdy_bn_bwd_workspace_bytes(M, K) = (hdy_bn_bwd_blocks(M)*2*K + 2*K) floats.
 static int bn_act_bwd_impl(const Split& dz, const void* y, int ldy, const float* scale, const float* shift, const float* mean, const float* invstd,
                            void* dy, int lddy, float* dgamma, float* dbeta, float* dgamma_b, float* dbeta_b, int accumulate, long long M, int K,
-                           int act, int dtype, float* workspace, void* stream) {
+                           int act, int dtype, float* workspace, size_t ws_bytes, void* stream) {
     const int VE = dtype == HDY_BF16 ? 8 : 4;
     HDY_ARG(dz.a && y && scale && shift && workspace && M_OK(M) && K > 0 && (!mean == !invstd), "bn_act_bwd: bad args");
+    HDY_ARG(!mean || ws_bytes >= hdy_bn_bwd_workspace_bytes(M, K), "bn_act_bwd: workspace of %zu bytes, %zu needed", ws_bytes, hdy_bn_bwd_workspace_bytes(M, K));
     HDY_ARG(dy || mean, "bn_act_bwd: dy == NULL (statistics only) needs live BatchNorm statistics");
     HDY_ARG(K % VE == 0 && VEC_OK(dz.a, dz.lda, VE) && VEC_OK(y, ldy, VE) && (!dy || VEC_OK(dy, lddy, VE)), "bn_act_bwd: K/pitch/alignment must be multiples of one 16-byte vector");
     HDY_ARG(dz.Ka == K || (dz.Ka > 0 && dz.Ka < K && dz.Ka % VE == 0 && dz.b && VEC_OK(dz.b, dz.ldb, VE)), "bn_act_bwd_pair: second gradient source missing / unaligned / bad split");
@@ -700,22 +706,23 @@ int hdy_bn_act_bwd_apply(const void* dz, int lddz, const void* dz_b, int lddz_b,
 
 int hdy_bn_act_bwd(const void* dz, int lddz, const void* y, int ldy, const float* scale, const float* shift, const float* mean,
                    const float* invstd, void* dy, int lddy, float* dgamma, float* dbeta, int accumulate, long long M, int K, int act,
-                   int dtype, float* workspace, void* stream) {
+                   int dtype, float* workspace, size_t ws_bytes, void* stream) {
     return bn_act_bwd_impl(Split{dz, lddz, nullptr, 0, K}, y, ldy, scale, shift, mean, invstd, dy, lddy, dgamma, dbeta, nullptr, nullptr, accumulate, M, K,
-                           act, dtype, workspace, stream);
+                           act, dtype, workspace, ws_bytes, stream);
 }
 
 int hdy_bn_act_bwd_pair(const void* dz_a, int lddz_a, const void* dz_b, int lddz_b, int Ka, const void* y, int ldy, const float* scale,
                         const float* shift, const float* mean, const float* invstd, void* dy, int lddy, float* dgamma_a, float* dbeta_a,
-                        float* dgamma_b, float* dbeta_b, int accumulate, long long M, int K, int act, int dtype, float* workspace, void* stream) {
+                        float* dgamma_b, float* dbeta_b, int accumulate, long long M, int K, int act, int dtype, float* workspace, size_t ws_bytes, void* stream) {
     return bn_act_bwd_impl(Split{dz_a, lddz_a, dz_b, lddz_b, Ka}, y, ldy, scale, shift, mean, invstd, dy, lddy, dgamma_a, dbeta_a, dgamma_b, dbeta_b,
-                           accumulate, M, K, act, dtype, workspace, stream);
+                           accumulate, M, K, act, dtype, workspace, ws_bytes, stream);
 }
 
 // out[k] (+)= sum over the M rows of dz[m][k]  (bias gradient of the detection conv).  workspace: hdy_bn_bwd_blocks(M)*2*K floats.
-int hdy_colsum(const void* dz, int lddz, long long M, int K, float* out, int accumulate, int dtype, float* workspace, void* stream) {
+int hdy_colsum(const void* dz, int lddz, long long M, int K, float* out, int accumulate, int dtype, float* workspace, size_t ws_bytes, void* stream) {
     const int VE = dtype == HDY_BF16 ? 8 : 4;
     HDY_ARG(dz && out && workspace && M_OK(M) && K > 0 && K % VE == 0 && VEC_OK(dz, lddz, VE), "colsum: bad args");
+    HDY_ARG(ws_bytes >= hdy_colsum_workspace_bytes(M, K), "colsum: workspace of %zu bytes, %zu needed", ws_bytes, hdy_colsum_workspace_bytes(M, K));
     const int nb = hdy_bn_bwd_blocks(M);
     const int rows = (int)((M + nb - 1) / nb);
     hipStream_t st = (hipStream_t)stream;

@@ -30,20 +30,15 @@ enum HdyOption {
     HDY_OPT_WGRAD_BLOCKS,      // HDY_WGRAD_BLOCKS: workgroups of the generic weight-gradient kernel (default 512)
     HDY_OPT_NO_STEM_WGRAD,     // HDY_NO_STEM_WGRAD: patch-resident stem weight gradient off
     HDY_OPT_NO_WGRAD3X3,       // HDY_NO_WGRAD3X3: patch-resident 3x3 weight gradient off
-    HDY_OPT_WGRAD3X3_S2,       // HDY_WGRAD3X3_S2: patch-resident 3x3 weight gradient also at stride 2 (measured: no gain)
     HDY_OPT_LOSS_GRID,         // HDY_LOSS_GRID: workgroups of the detection loss' dense pass (default 2048)
     HDY_OPT_NO_DEEP,           // HDY_NO_DEEP: deep-pipelined 256-row implicit GEMM off (generic kernel instead)
     HDY_OPT_NO_WGRAD_S2,       // HDY_NO_WGRAD_S2: tap-walking stride-2 3x3 weight gradient off
     HDY_OPT_NO_WGRAD_DEEP,     // HDY_NO_WGRAD_DEEP: deep-pipelined 256 x 256 weight gradient off (generic weight gradient instead)
-    HDY_OPT_WGRAD_DEEP_1X1,    // HDY_WGRAD_DEEP_1X1: the deep-pipelined weight gradient also takes 1x1 layers (measured slower at yolov5s sizes)
-    HDY_OPT_WGRAD_DEEP_S1,     // HDY_WGRAD_DEEP_S1: ... and the 3x3 / stride-1 layers before the patch-resident kernel
     HDY_OPT_DEEP_BN,           // HDY_DEEP_BN: column tile of the deep-pipelined kernel (0 = by shape, 128, 256)
     HDY_OPT_DEEP_DEBUG,        // HDY_DEEP_DEBUG: timing ablations of the deep-pipelined kernel (bit mask, results wrong; measurement only)
     HDY_OPT_DEEP_ALL,          // HDY_DEEP_ALL: 1 (default) the deep-pipelined kernel takes multi-tap (3x3) layers too, 0 the 1x1 layers only
-    HDY_OPT_F1X1_SMALL,        // HDY_F1X1_SMALL: fused 1x1 backward with 64-pixel tiles / four workgroups per CU for the 32- and 64-wide instances
     HDY_OPT_DEEP_MIN_TILES,    // HDY_DEEP_MIN_TILES: fewest 256-row tiles the deep-pipelined kernel takes a layer with (default 160)
     HDY_OPT_DEEP_WALK,         // HDY_DEEP_WALK: stride-2 data gradients (four-class walk) on the deep pipeline: 0 never, 1 always, 2 (default) with >= 256 output channels
-    HDY_OPT_WIDE3,             // HDY_WIDE3=1: patch-resident 3x3 kernel of the wide layers (conv3x3_wide.hip; default 0: measured no faster than conv_deep.hip)
     HDY_OPT_COUNT
 };
 int hdy_opt(int id);

@@ -287,9 +287,20 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_kernel(const FusedArgs p) 
         }
         __syncthreads();                                            // every wave is done reading D and X[cur]
         if (NXB == 1 && p.do_wgrad && t + 1 < tile_end) issue_x(t + 1, 0);
-        // ---- 5. dx tile: accumulators -> bf16 -> staging (D's storage, 8-byte slots XORed with (row & SWM)) -> 16-byte row stores
+        // ---- 5. dx tile: accumulators -> bf16 -> staging (D's storage, 8-byte slots XORed with a row key) -> 16-byte row stores
+        // A ds_write_b64 is served in groups of 16 CONSECUTIVE lanes over 32 banks (MI355X_MICROARCH.md, LDS table): here the 16 pixel rows fr of one
+        // 8-byte slot.  Round 2's key (row & 14) put rows r and r ^ 1 on the same slot: every staging write 2-way conflicted — the 13-21 % of LDS-active
+        // cycles that profiles/r03_layers_pmc_table.txt shows for this kernel (8 such writes per wave and tile among ~230 LDS cycles).  The key now takes
+        // all 16 rows to 16 different slots: row & 15 for rows of 128 bytes or more (the row's own bank offset is 0 mod 32), (row >> 1) & 7 for the 64-byte
+        // rows of the 32-channel instance (two rows per 128 bytes: bit 0 of the row already selects the bank half).  An odd key swaps the two 8-byte
+        // halves of a 16-byte chunk, which the reader undoes in registers.
         if (p.do_dgrad) {
-            constexpr int ROWB = CT * 2, CPR = ROWB / 16, RPI = 256 / CPR, SWM = (2 * CPR - 1) & 14;
+            constexpr int ROWB = CT * 2, CPR = ROWB / 16, RPI = 256 / CPR;
+#ifdef HDY_F1X1_OLDKEY                                                  // A/B build (scripts/build_variant.sh ... -DHDY_F1X1_OLDKEY): round 2's key
+            auto skey = [](int row) { return row & ((2 * CPR - 1) & 14); };
+#else
+            auto skey = [](int row) { return CT >= 64 ? (row & 15) : ((row >> 1) & 7); };
+#endif
 #pragma unroll
             for (int b = 0; b < NT; ++b) {
                 const int slot = wn * (CT / 8) + b * 4 + fq;
@@ -297,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_kernel(const FusedArgs p) 
                 for (int a = 0; a < MT; ++a) {
                     const int row = wm * (BM / 2) + a * 16 + fr;
                     const bf16x4 o = {(bf16_t)acc[a][b][0], (bf16_t)acc[a][b][1], (bf16_t)acc[a][b][2], (bf16_t)acc[a][b][3]};
-                    *(bf16x4*)(sD + row * ROWB + ((slot ^ (row & SWM)) << 3)) = o;
+                    *(bf16x4*)(sD + row * ROWB + ((slot ^ skey(row)) << 3)) = o;
                 }
             }
             __syncthreads();
@@ -349,7 +360,11 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_kernel(const FusedArgs p) 
                 if (m >= p.M) break;
                 V16 v, yv;
                 yv.i = STATS_OK ? yrows[it] : i32x4{0, 0, 0, 0};
-                v.i = *(const i32x4*)(sD + row * ROWB + ((cc ^ ((row & SWM) >> 1)) << 4));
+                {
+                    const int key = skey(row);
+                    const i32x4 w = *(const i32x4*)(sD + row * ROWB + ((cc ^ (key >> 1)) << 4));
+                    v.i = (key & 1) ? i32x4{w[2], w[3], w[0], w[1]} : w;
+                }
                 bf16_t* dst = dx + (size_t)m * p.lddx + cc * 8;
                 if (p.accumulate) {
                     V16 q;
@@ -426,10 +441,9 @@ int fused_launch(const FusedArgs& a, int grid, hipStream_t st) {
     return HDY_OK;
 }
 
-// 128-wide: 64-pixel tiles, so that two workgroups fit a CU's LDS.  HDY_F1X1_SMALL = 1: 64-pixel tiles for the 32- / 64-wide instances too
-// (33 KB of LDS: four workgroups per CU instead of two — the kernel's waves are parked on waits 54-74 % of their cycles, profiles/r03_layers_pmc_table.txt)
-inline bool small_tiles(int K) { return K < 128 && hdy_opt(HDY_OPT_F1X1_SMALL) != 0; }
-inline int tile_rows(int K) { return (K == 128 || small_tiles(K)) ? 64 : 128; }
+// 128-wide: 64-pixel tiles, so that two workgroups fit a CU's LDS.  (64-pixel tiles / four workgroups per CU for the 32- and 64-wide instances were
+// measured in round 3 and are gone: 64<>64 @160x160 265 -> 288 us, 32<>32 207 -> 228 us)
+inline int tile_rows(int K) { return K == 128 ? 64 : 128; }
 
 }  // namespace
 
@@ -447,7 +461,7 @@ int hdy_conv1x1_bwd_fused_ok(int C, int K, int dtype) {
 int hdy_conv1x1_bwd_fused_grid(long long M, int K) {
     const int bm = tile_rows(K);
     const long long tiles = (M + bm - 1) / bm;
-    const long long cap = small_tiles(K) ? 1024 : 512;      // two (four) resident workgroups per CU (768 for the 32-wide instance measured slower: 179 vs 160 us)
+    const long long cap = 512;                              // two resident workgroups per CU (768 for the 32-wide instance measured slower: 179 vs 160 us)
     return (int)(tiles < cap ? tiles : cap);
 }
 
@@ -507,18 +521,19 @@ static int fused_impl(const void* dz_a, int lddz_a, const void* dz_b, int lddz_b
     a.do_dgrad = dx != nullptr; a.do_wgrad = grad_a != nullptr;
     HDY_ARG(nstat >= 0 && nstat <= 2 && (nstat == 0 || (stats && dx)), "conv1x1_bwd_fused: statistics requests need dx");
     a.nstat = nstat;
+    const int grid = hdy_conv1x1_bwd_fused_grid(M, K);      // = slabs every statistics request receives
     for (int r = 0; r < nstat; ++r) {
         const hdy_stat_req& q = stats[r];
+        HDY_ARG(q.nslabs == grid, "conv1x1_bwd_fused: statistics request %d holds %d slabs, this launch writes %d", r, q.nslabs, grid);
         HDY_ARG(q.y && q.scale && q.shift && q.slabs && q.c0 >= 0 && q.c0 < q.c1 && q.c1 <= C && q.c0 % 8 == 0 && q.c1 % 8 == 0 &&
                 q.ldy % 8 == 0 && (((uintptr_t)q.y | (uintptr_t)q.scale | (uintptr_t)q.shift) & 15) == 0 && C <= 64,
                 "conv1x1_bwd_fused: bad statistics request %d (served up to 64 channels)", r);
-        a.stat[r] = StatReq{q.y, q.ldy, q.scale, q.shift, q.slabs, q.c0, q.c1, q.act};
+        a.stat[r] = StatReq{q.y, q.ldy, q.scale, q.shift, q.slabs, q.c0, q.c1, q.act, q.nslabs};
     }
-    const int grid = hdy_conv1x1_bwd_fused_grid(M, K);
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if (K == 32) rc = small_tiles(K) ? fused_launch<32, 32, 64, 2>(a, grid, st) : fused_launch<32, 32, 128, 2>(a, grid, st);
-    else if (K == 64) rc = small_tiles(K) ? fused_launch<64, 64, 64, 2>(a, grid, st) : fused_launch<64, 64, 128, 2>(a, grid, st);
+    if (K == 32) rc = fused_launch<32, 32, 128, 2>(a, grid, st);
+    else if (K == 64) rc = fused_launch<64, 64, 128, 2>(a, grid, st);
     else rc = fused_launch<128, 128, 64, 1>(a, grid, st);
     if (rc || !grad_a) return rc;
     rc = hdy_wgrad_reduce_launch(a.partial, grid, (size_t)K * C, K_a, C, 0, C, 1, 1, grad_a, accumulate_w, st);

@@ -434,6 +434,7 @@ int hdy_conv3x3_c64_try(const ConvArgs& a, int dtype, int out_f32, hipStream_t s
         return 1;
     }
     const int grid = conv3x3_grid(a.N * (a.Ho / TH) * (a.Wo / TW), a.C);
+    HDY_STAT_CAP(a, grid, "conv3x3_c64")
     const int epi = a.act == 1 ? 2 : ((a.scale || a.shift) ? 1 : 0);
     if (a.C == 32) launch_c3_c<32>(a, grid, epi, st);
     else launch_c3_c<64>(a, grid, epi, st);

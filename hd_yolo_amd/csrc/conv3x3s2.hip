@@ -268,6 +268,7 @@ int hdy_conv3x3s2_c32_try(const ConvArgs& a, int dtype, int out_f32, hipStream_t
         return 1;
     }
     const int grid = conv3x3s2_grid(a.N * (a.Ho / TH) * (a.Wo / TW));
+    HDY_STAT_CAP(a, grid, "conv3x3s2_c32")
     const int epi = a.act == 1 ? 2 : ((a.scale || a.shift) ? 1 : 0);
     if (a.stats) {
         if (epi == 2) launch_s2<2, true>(a, grid, st);

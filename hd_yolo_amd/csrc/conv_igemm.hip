@@ -716,12 +716,26 @@ inline bool igemm_big(long long M, int bn, int ntiles, int taps) {
 
 template <typename T, typename OT, int BM, int BN, int NS, bool STAT = false>
 int launch(const ConvArgs& a, hipStream_t st) {
+    const int grid = igemm_grid(a.M, a.ntiles * (a.ncls > 1 ? 4 : 1), BM, BN, NS);
+    if (a.stats) {
+        // the kernel's own rule (wg_stats): one slab per workgroup position when the sums stay in registers across its tiles, else one per 128 rows
+        const bool wg = a.ntiles == 1 || ((a.tile_interleave & 1) && a.ncls <= 1 && grid % a.ntiles == 0);
+        long long writes = (a.M + 127) / 128;
+        if (wg && a.ntiles > 1) writes = grid / a.ntiles;
+        else if (wg) {
+            const long long tiles = (a.M + BM - 1) / BM, tpb = (tiles + grid - 1) / grid;
+            writes = (tiles + tpb - 1) / tpb;
+        }
+        HDY_ARG(a.stat_cap == writes, "conv: the statistics array holds %d slabs, this launch writes %lld (a kernel-selection option changed between "
+                "hdy_conv_stat_slabs and the launch?)", a.stat_cap, writes);
+    }
+    for (int r = 0; r < a.nstat; ++r)
+        HDY_ARG(a.stat[r].nslabs == grid, "conv: statistics request %d holds %d slabs, this launch writes %d", r, a.stat[r].nslabs, grid);
     const size_t smem = (size_t)NS * (BM * 128 + BN * 128) + (BN > 32 ? 2 * BN * sizeof(float) : 0);
     static std::once_flag attr_once;           // first launch of this instance on any thread
     std::call_once(attr_once, [&] {
         (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, OT, BM, BN, NS, STAT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     });
-    const int grid = igemm_grid(a.M, a.ntiles * (a.ncls > 1 ? 4 : 1), BM, BN, NS);
     {
         char what[48];
         snprintf(what, sizeof(what), "igemm_%dx%dx%d%s%s", BM, BN, NS, a.ncls > 1 ? "_walk" : "", STAT ? "_stat" : "");
@@ -834,7 +848,6 @@ int hdy_conv_igemm_launch(ConvArgs a, int dtype, int out_f32, hipStream_t st) {
         if (hdy_conv_stem_try(a, dtype, out_f32, st, &rc)) return rc;         // patch-resident 6x6/s2 stem
         if (hdy_conv3x3_c64_try(a, dtype, out_f32, st, &rc)) return rc;      // filter-resident 3x3 kernel when the shape qualifies
         if (hdy_conv3x3s2_c32_try(a, dtype, out_f32, st, &rc)) return rc;    // patch-resident 3x3 / stride 2 kernel (32 input channels)
-        if (hdy_conv3x3_wide_try(a, dtype, out_f32, st, &rc)) return rc;     // patch-resident 3x3 of the wide layers (C % 64 == 0, C, K >= 128)
         if (hdy_conv_deep_try(a, dtype, out_f32, st, &rc)) return rc;        // deep-pipelined 256-row kernel (C % 64 == 0, K >= 128)
         // the slab count the caller sized its statistics buffer with must be the generic kernel's from here on
         HDY_ARG(!a.stats || a.span_pixels || hdy_conv_deep_slabs(a.M, a.C, a.K, a.TH * a.TW, a.pointwise, dtype) == 0,

@@ -268,6 +268,7 @@ int hdy_conv_stem_try(const ConvArgs& a, int dtype, int out_f32, hipStream_t st,
         return 1;
     }
     const int grid = stem_grid(a.N * (a.Ho / TOH) * (a.Wo / TOW), a.K);
+    HDY_STAT_CAP(a, grid, "conv_stem")
     switch (a.K / 16) {
         case 1: launch_nt<1>(a, grid, st); break;
         case 2: launch_nt<2>(a, grid, st); break;

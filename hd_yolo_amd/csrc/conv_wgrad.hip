@@ -439,65 +439,6 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
     for (int e = 0; e < 4; ++e) wgrad_scatter(sum[e], idx + e, K, Q, mode, C, R, S, grad, accumulate);
 }
 
-// all split reductions of a gradient bucket in ONE launch: block -> descriptor by binary search over first_block, then the body of the
-// single-launch kernels above (same order of additions: bit-identical results)
-__global__ __launch_bounds__(1024) void wgrad_reduce_batch_kernel(const hdy_reduce_desc* __restrict__ table, int ndesc) {
-    __shared__ f32x4 red[16][64];
-    int lo = 0, hi = ndesc - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (table[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
-    }
-    const hdy_reduce_desc d = table[lo];
-    const int blk = (int)blockIdx.x - d.first_block;
-    const int ql = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const float* __restrict__ partial = d.partial;
-    const size_t slab_stride = (size_t)d.slab_stride;
-    const int splits = d.splits;
-    if (d.vec) {
-        const int idx = (blk * 64 + ql) * 4;
-        const bool ok = idx < d.K * d.Q;
-        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
-        if (ok) {
-            const float* src = partial + idx;
-            int sp = sl;
-            for (; sp + 48 < splits; sp += 64) {
-                const f32x4 a = *(const f32x4*)(src + (size_t)sp * slab_stride);
-                const f32x4 b = *(const f32x4*)(src + (size_t)(sp + 16) * slab_stride);
-                const f32x4 c = *(const f32x4*)(src + (size_t)(sp + 32) * slab_stride);
-                const f32x4 e = *(const f32x4*)(src + (size_t)(sp + 48) * slab_stride);
-                s0 += a; s1 += b; s2 += c; s3 += e;
-            }
-            for (; sp < splits; sp += 16) s0 += *(const f32x4*)(src + (size_t)sp * slab_stride);
-        }
-        red[sl][ql] = (s0 + s1) + (s2 + s3);
-        __syncthreads();
-        if (sl != 0 || !ok) return;
-        f32x4 sum = red[0][ql];
-#pragma unroll
-        for (int i = 1; i < 16; ++i) sum += red[i][ql];
-        if (d.mode == 0 && d.R == 1 && d.S == 1) {
-            f32x4* g = (f32x4*)(d.grad + idx);
-            *g = d.accumulate ? *g + sum : sum;
-            return;
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) wgrad_scatter(sum[e], idx + e, d.K, d.Q, d.mode, d.C, d.R, d.S, d.grad, d.accumulate);
-    } else {
-        float* redf = (float*)red;                     // [16][65]
-        const int idx = blk * 64 + ql;
-        const bool ok = idx < d.K * d.Q;
-        float sum = 0.f;
-        if (ok)
-            for (int sp = sl; sp < splits; sp += 16) sum += partial[(size_t)sp * slab_stride + idx];
-        redf[sl * 65 + ql] = sum;
-        __syncthreads();
-        if (sl != 0 || !ok) return;
-#pragma unroll
-        for (int i = 1; i < 16; ++i) sum += redf[i * 65 + ql];
-        wgrad_scatter(sum, idx, d.K, d.Q, d.mode, d.C, d.R, d.S, d.grad, d.accumulate);
-    }
-}
 
 // the same for slabs that are not whole 16-byte columns (K*Q, the slab pitch or the base not a multiple of four floats)
 __global__ __launch_bounds__(1024) void wgrad_reduce_scalar_kernel(const float* __restrict__ partial, int splits, size_t slab_stride, int K, int Q,
@@ -697,44 +638,17 @@ int hdy_wgrad_stem_launch(const WgradArgs& a, int grid, hipStream_t st) {
     return HDY_OK;
 }
 
-// thread-local recorder of the split reductions (include/hdyolo.h hdy_wgrad_reduce_mode): 0 normal, 1 tee, 2 skip
-static thread_local int g_red_mode = 0, g_red_cap = 0, g_red_n = 0;
-static thread_local hdy_reduce_desc* g_red_out = nullptr;
-
-extern "C" int hdy_wgrad_reduce_mode(int mode, hdy_reduce_desc* descs_host, int cap) {
-    const int n = g_red_n;
-    g_red_mode = mode; g_red_out = descs_host; g_red_cap = descs_host ? cap : 0; g_red_n = 0;
-    return n;
-}
-
 // partial points at the first row to reduce; slabs are slab_stride floats apart; K rows of Q are reduced.
 int hdy_wgrad_reduce_launch(const float* partial, int splits, size_t slab_stride, int K, int Q, int mode, int C, int R, int S, float* grad,
                             int accumulate, hipStream_t st) {
     const int n = K * Q;
     const bool vec = n % 4 == 0 && slab_stride % 4 == 0 && ((uintptr_t)partial & 15) == 0 && (!(mode == 0 && R == 1 && S == 1) || ((uintptr_t)grad & 15) == 0);
-    if (g_red_mode != 0) {
-        if (g_red_out && g_red_n < g_red_cap) {
-            hdy_reduce_desc d = {};
-            d.partial = partial; d.grad = grad; d.slab_stride = slab_stride; d.splits = splits; d.K = K; d.Q = Q; d.mode = mode; d.C = C; d.R = R; d.S = S;
-            d.accumulate = accumulate; d.vec = vec ? 1 : 0; d.nblocks = vec ? cdiv(n, 256) : cdiv(n, 64);
-            g_red_out[g_red_n] = d;
-        }
-        ++g_red_n;
-        if (g_red_mode == 2) return HDY_OK;
-    }
     if (vec)
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(n, 256)), dim3(1024), 0, st, partial, splits, slab_stride, K, Q, mode, C, R, S, grad, accumulate);
     else
         hipLaunchKernelGGL(wgrad_reduce_scalar_kernel, dim3(cdiv(n, 64)), dim3(1024), 0, st, partial, splits, slab_stride, K, Q, mode, C, R, S, grad,
                            accumulate);
     HDY_LAUNCH_CHECK("wgrad_reduce");
-    return HDY_OK;
-}
-
-extern "C" int hdy_wgrad_reduce_batch(const hdy_reduce_desc* table_device, int ndesc, int total_blocks, void* stream) {
-    HDY_ARG(table_device && ndesc > 0 && total_blocks > 0, "wgrad_reduce_batch: bad args");
-    hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(total_blocks), dim3(1024), 0, (hipStream_t)stream, table_device, ndesc);
-    HDY_LAUNCH_CHECK("wgrad_reduce_batch");
     return HDY_OK;
 }
 

@@ -230,32 +230,21 @@ __global__ __launch_bounds__(768) void wgrad3x3_kernel(const W3Args p) {
 
 struct W3Plan { int KB, CB, TOH, TOW, tiles_h, tiles_w, nkb, ncb, nsplit; };
 
-// tile shape (output pixels).  stride 1: whole image rows when they are short (W <= 40), 16x16 blocks when W divides by 16, else 8x32;
-// stride 2 (the patch is (2*TOH+1) x (2*TOW+1) input pixels): 8x8 blocks, or whole / half rows of narrow maps
+// tile shape (output pixels): whole image rows when they are short (W <= 40), 16x16 blocks when W divides by 16, else 8x32
 bool w3_plan(int N, int Ho, int Wo, int C, int K, int stride, W3Plan* pl) {
     const bool off = hdy_opt(HDY_OPT_NO_WGRAD3X3) != 0;
-    // Stride 2 is implemented and tested (HDY_WGRAD3X3_S2=1) but not the default: its patch is 4x the output tile, so a tile is 45 KB of
-    // LDS-DMA for two MFMA steps and the kernel is load bound — measured against the generic kernel on yolov5s B=64: 101 vs 100,
-    // 86 vs 75, 177 vs 180, 166 vs 172, 166 vs 152, 238 vs 233 us.  Stride 1: 57 vs 82, 57 vs 75, 67 vs 95, 84 vs 168 us.
-    const bool s2 = hdy_opt(HDY_OPT_WGRAD3X3_S2) != 0;
-    if (off || C % 32 || K % 32 || (stride != 1 && !(stride == 2 && s2))) return false;
+    // Stride 1 only (57 vs 82, 57 vs 75, 67 vs 95, 84 vs 168 us against the generic kernel on yolov5s B=64).  A stride-2 plan was built and measured in
+    // round 2 and is gone from the library: its patch is 4x the output tile, 45 KB of LDS-DMA for two MFMA steps, load bound — 101 vs 100, 86 vs 75,
+    // 177 vs 180, 166 vs 172, 166 vs 152, 238 vs 233 us.
+    if (off || C % 32 || K % 32 || stride != 1) return false;
     pl->KB = K % 64 == 0 ? 64 : 32;
     pl->CB = C % 64 == 0 ? 64 : 32;
     // several 32-wide blocks per split (yolov5m's 96 x 96 = 3 x 3 of them) do too little MFMA work per staged tile: 83 us against 70 us on the
     // generic kernel at 96x96 @80x80, B=32; a single 32 x 32 block (yolov5s' 32->32 @160x160) is 84 against 168 us
     if ((pl->KB == 32 || pl->CB == 32) && (K / pl->KB) * (C / pl->CB) > 1) return false;
-    if (stride == 1) {
-        if (Wo <= 40) { pl->TOW = Wo; pl->TOH = W3_MAXTP / Wo; }
-        else if (Wo % 16 == 0) { pl->TOW = 16; pl->TOH = 16; }
-        else { pl->TOW = 32; pl->TOH = 8; }
-    } else {
-        if (Wo % 8 == 0) pl->TOW = 8;
-        else if (Wo <= 12) pl->TOW = Wo;
-        else if (Wo % 2 == 0 && Wo / 2 <= 12) pl->TOW = Wo / 2;
-        else pl->TOW = 8;
-        pl->TOH = (W3_MAXPP / (2 * pl->TOW + 1) - 1) / 2;
-        if (pl->TOH * pl->TOW > 64) pl->TOH = 64 / pl->TOW;           // two MFMA steps per tile: the patch, not the dy tile, fills the LDS
-    }
+    if (Wo <= 40) { pl->TOW = Wo; pl->TOH = W3_MAXTP / Wo; }
+    else if (Wo % 16 == 0) { pl->TOW = 16; pl->TOH = 16; }
+    else { pl->TOW = 32; pl->TOH = 8; }
     if (pl->TOH > Ho) pl->TOH = Ho;
     if (pl->TOH < 1) return false;
     // fewest rows per tile that need the same number of tiles: no more padding than necessary

@@ -287,8 +287,8 @@ bool deep_ok(int N, int Hin, int Win, int Ho, int Wo, int C, int K, int R, int S
     if (C % 64 != 0 || K % 128 != 0 || K < 256 || ldx % 8 != 0 || lddy % 8 != 0) return false;
     // measured on yolov5s (B = 64): the multi-tap layers 158 -> 85 us (256x512 3x3/s2 @40x40), 158 -> 82 (128x256 @80x80), 96 -> 58 (256x256 s2); the
     // 1x1 layers at 20x20 / 40x40 lose (20 -> 28 us, 35 -> 39 us: a 256 x 256 tile leaves them 4-8 tiles, i.e. 32-64 pixel splits of 7-25 stages,
-    // and twice the slab bytes) — HDY_WGRAD_DEEP_1X1 = 1 sends them here anyway
-    if (R * S == 1 && !hdy_opt(HDY_OPT_WGRAD_DEEP_1X1)) return false;
+    // and twice the slab bytes): multi-tap layers only
+    if (R * S == 1) return false;
     const long long P = (long long)N * Ho * Wo;
     if (P < 8192) return false;                                         // too few pixels to stream
     if ((long long)N * Hin * Win * ldx * 2 >= (1LL << 31) - (1LL << 24)) return false;    // 31-bit x offsets (bit 31 = out of range)

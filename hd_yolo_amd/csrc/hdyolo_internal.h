@@ -12,6 +12,7 @@ struct StatReq {
     const float *scale, *shift;
     float* slabs;
     int c0, c1, act;
+    int nslabs;           // slabs the caller's array holds (hdy_stat_req.nslabs)
 };
 
 struct ConvArgs {
@@ -20,7 +21,10 @@ struct ConvArgs {
     void* y;              // [N][Hout][Wout][ldy]
     const float* scale;   // per-channel epilogue scale (or null = 1)
     const float* shift;   // per-channel epilogue shift / bias (or null = 0)
-    float* stats;         // [mtiles][2][K] BatchNorm partial sums (or null)
+    float* stats;         // [stat_cap][2][K] BatchNorm partial sums (or null)
+    int stat_cap;         // slabs the caller's `stats` array holds (hdy_conv_fwd's stat_slabs): every launcher that writes statistics checks it
+                          // against the slab count of the kernel and grid it is about to start (HDY_STAT_CAP) — the sizing query and the launch
+                          // both read the process-wide option table, which another thread may change in between
     const void* res;      // residual added after the activation, same pixel grid as y, pitch ldr (or null)
     int ldr;
     int N, Hin, Win, C, ldx;
@@ -49,6 +53,15 @@ struct ConvArgs {
     int sh_howo, sh_wo, sh_c, sh_tw[4];
     int dbg;              // conv_deep.hip timing ablations (HDY_DEEP_DEBUG; results are wrong when set): 1 no A loads, 2 no B loads, 4 no MFMAs, 8 no epilogue, 16 no fragment reads
 };
+
+// `writes` = slabs the launch about to start writes; inside a *_try function (error through *rc, return 1 = handled)
+#define HDY_STAT_CAP(a, writes, who)                                                                                                      \
+    if ((a).stats && (a).stat_cap != (writes)) {                                                                                          \
+        hdy_set_error("%s: the statistics array holds %d slabs, this launch writes %d (a kernel-selection option changed between "        \
+                      "hdy_conv_stat_slabs and the launch?)", who, (a).stat_cap, (int)(writes));                                          \
+        *rc = HDY_EINVAL;                                                                                                                 \
+        return 1;                                                                                                                         \
+    }
 
 // reciprocal for n / d, n < 2^31: q = mulhi(2n, *mg) >> *sh (conv_igemm.hip fdiv)
 inline void hdy_magic(unsigned d, unsigned* mg, int* sh) {
@@ -96,7 +109,5 @@ int hdy_conv_igemm_stat_grid(long long M, int K, int taps, int ncls);
 int hdy_dgrad3x3s2_try(const ConvArgs& a, int dtype, hipStream_t st, int* rc);
 int hdy_conv3x3s2_c32_try(const ConvArgs& a, int dtype, int out_f32, hipStream_t st, int* rc);
 int hdy_conv_deep_try(const ConvArgs& a, int dtype, int out_f32, hipStream_t st, int* rc);
-int hdy_conv3x3_wide_try(const ConvArgs& a, int dtype, int out_f32, hipStream_t st, int* rc);
-int hdy_conv3x3_wide_slabs(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dtype);
 int hdy_conv_deep_slabs(long long M, int C, int K, int taps, int pointwise, int dtype);
 int hdy_conv3x3s2_c32_slabs(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dtype);

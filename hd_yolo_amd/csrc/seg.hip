@@ -771,7 +771,8 @@ size_t hdy_groupnorm_workspace_floats(int N, int C) { return (size_t)N * GN_SLIC
 
 // y = relu?(GroupNorm_G(x) * gamma + beta) per image; saves stat [N][G][2] = (mean, rstd) and ab [N][2][C] for the backward.
 int hdy_groupnorm_fwd(const void* x, int ldx, const float* gamma, const float* beta, void* y, int ldy, float* stat, float* ab, int N, int HW,
-                      int C, int G, float eps, int relu, int dtype, float* workspace, void* stream) {
+                      int C, int G, float eps, int relu, int dtype, float* workspace, size_t ws_floats, void* stream) {
+    HDY_ARG(N > 0 && C > 0 && ws_floats >= hdy_groupnorm_workspace_floats(N, C), "groupnorm_fwd: workspace of %zu floats is too small", ws_floats);
     const int VE = dtype == HDY_BF16 ? 8 : 4;
     HDY_ARG(x && gamma && beta && y && stat && ab && workspace && N > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0, "groupnorm_fwd: bad args");
     HDY_ARG(C % VE == 0 && VEC_OK(x, ldx, VE) && VEC_OK(y, ldy, VE) && C <= 4096, "groupnorm_fwd: C/pitch/alignment must be multiples of one 16-byte vector");
@@ -800,8 +801,9 @@ int hdy_groupnorm_fwd(const void* x, int ldx, const float* gamma, const float* b
 // coef: [N][3][C] floats of scratch.
 int hdy_groupnorm_bwd(const void* dout, int lddo, const void* x, int ldx, const float* gamma, const float* stat, const float* ab, void* dx, int lddx,
                       float* dgamma, float* dbeta, int accumulate, float* coef, int N, int HW, int C, int G, int relu, int dtype, float* workspace,
-                      void* stream) {
+                      size_t ws_floats, void* stream) {
     const int VE = dtype == HDY_BF16 ? 8 : 4;
+    HDY_ARG(N > 0 && C > 0 && ws_floats >= hdy_groupnorm_workspace_floats(N, C), "groupnorm_bwd: workspace of %zu floats is too small", ws_floats);
     HDY_ARG(dout && x && gamma && stat && ab && dx && dgamma && dbeta && coef && workspace && N > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0, "groupnorm_bwd: bad args");
     HDY_ARG(C % VE == 0 && VEC_OK(x, ldx, VE) && VEC_OK(dout, lddo, VE) && VEC_OK(dx, lddx, VE) && C <= 4096, "groupnorm_bwd: C/pitch/alignment must be multiples of one 16-byte vector");
     hipStream_t st = (hipStream_t)stream;
@@ -889,7 +891,8 @@ size_t hdy_softdice_workspace_floats(int N, int nc) { return (size_t)N * DICE_SL
 // loss[0] = 1 - SUM_c w_c * mean_n dice(softmax(logits)[n][c], targets[n][c]) / SUM_c w_c, dice = 2*SUM(t*p) / SUM(t + p);
 // when dlogits != NULL also the gradient of loss * upstream[0] (upstream == NULL: 1).
 int hdy_softdice(const float* logits, int ldl, const float* targets, const float* class_weight, int N, int HW, int nc, float* loss,
-                 const float* upstream, float* dlogits, int lddl, float* workspace, void* stream) {
+                 const float* upstream, float* dlogits, int lddl, float* workspace, size_t ws_floats, void* stream) {
+    HDY_ARG(N > 0 && nc > 0 && ws_floats >= hdy_softdice_workspace_floats(N, nc), "softdice: workspace of %zu floats is too small", ws_floats);
     HDY_ARG(logits && targets && loss && workspace && N > 0 && HW > 0 && nc > 0 && nc <= DICE_MAXC && ldl >= nc && N * nc <= 65536, "softdice: bad args (nc <= %d)", DICE_MAXC);
     hipStream_t st = (hipStream_t)stream;
     float* coef = workspace + (size_t)N * DICE_SLICES * 2 * nc;
@@ -916,7 +919,8 @@ int hdy_softdice(const float* logits, int ldl, const float* targets, const float
 // logits fp32 [N][H][W][4] with nc <= 4 classes, dw [N][H][Wi][4] = W pass of d loss / d logits (upstream 1); the caller runs the H pass
 // (hdy_bilinear_bwd_axis(dw, 4, dx, ldx, N, Hi, H, Wi, 4, ...)).  Same results as hdy_softdice + the W pass, bit for bit.
 int hdy_softdice_wgrad(const float* logits, const float* targets, const float* class_weight, int N, int H, int W, int nc, int Wi, float* loss, float* dw,
-                       float* workspace, void* stream) {
+                       float* workspace, size_t ws_floats, void* stream) {
+    HDY_ARG(N > 0 && nc > 0 && ws_floats >= hdy_softdice_workspace_floats(N, nc), "softdice_wgrad: workspace of %zu floats is too small", ws_floats);
     HDY_ARG(logits && targets && loss && dw && workspace && N > 0 && H > 0 && W > 0 && Wi > 0 && nc > 0 && nc <= 4 && N * nc <= 65536, "softdice_wgrad: bad args (nc <= 4)");
     HDY_ARG((size_t)W * 16 <= 64 * 1024 && (long long)N * H < (1LL << 31), "softdice_wgrad: row of %d pixels beyond the LDS stage", W);
     hipStream_t st = (hipStream_t)stream;

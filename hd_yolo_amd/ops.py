@@ -60,6 +60,11 @@ def ptr(t):
     return t.data_ptr()
 
 
+def _nbytes(t):
+    """byte size of a caller-owned workspace tensor (0 for None): every workspace pointer of the C ABI travels with its size"""
+    return 0 if t is None else t.numel() * t.element_size()
+
+
 def stream_ptr():
     return torch.cuda.current_stream().cuda_stream
 
@@ -88,43 +93,6 @@ class SideStream:
             main.wait_event(done)
 
 
-class ReduceSlot:
-    """The split reductions (one or two) a weight-gradient record ends with, described once (hdy_wgrad_reduce_mode tee) so that they can be
-    replayed inside a batched launch.  The record's slab workspace belongs to it alone."""
-
-    def __init__(self):
-        self.arr = (_lib.ReduceDesc * 2)()
-        self.n = 0
-        self.group = None
-
-
-class ReduceGroup:
-    """All split reductions of one gradient bucket as ONE launch (hdy_wgrad_reduce_batch) behind the bucket's last weight-gradient record."""
-
-    def __init__(self, slots, device):
-        self.slots, self.device, self.table, self.n, self.blocks = slots, device, None, 0, 0
-        for s in slots:
-            s.group = self
-
-    @property
-    def ready(self):
-        return self.table is not None
-
-    def build(self):
-        descs, blocks = [], 0
-        for s in self.slots:
-            for i in range(s.n):
-                d = _lib.ReduceDesc.from_buffer_copy(bytes(s.arr[i]))
-                d.first_block = blocks
-                blocks += d.nblocks
-                descs.append(d)
-        self.n, self.blocks = len(descs), blocks
-        if descs:
-            self.table = torch.frombuffer(bytearray(b''.join(bytes(d) for d in descs)), dtype=torch.uint8).to(self.device)
-        else:
-            self.table = torch.empty(0, dtype=torch.uint8, device=self.device)
-
-
 def run(records, stream=None):
     """Execute launch records on `stream` (default: torch's current HIP stream)."""
     lib = _lib.load()
@@ -139,28 +107,6 @@ def run(records, stream=None):
                 side.fork(rec[2], rec[3], torch.cuda.current_stream())
             elif name == '@join':
                 side.join(rec[2], torch.cuda.current_stream())
-            elif name == '@wgrad':
-                # a weight-gradient record whose split reduction is batched: first run = tee (reductions run AND are described), later runs
-                # skip them (the group's one launch does them)
-                inner, slot = rec[1], rec[2]
-                ready = slot.group is not None and slot.group.ready
-                try:
-                    lib.hdy_wgrad_reduce_mode(2 if ready else 1, None if ready else ctypes.cast(slot.arr, ctypes.c_void_p), 2)
-                    rc = getattr(lib, inner[0])(*inner[1], s)
-                finally:
-                    n = lib.hdy_wgrad_reduce_mode(0, None, 0)
-                if rc != 0:
-                    raise _lib.HdyError(f'{inner[0]} failed (status {rc}): {lib.hdy_last_error().decode()}')
-                if not ready:
-                    slot.n = n
-            elif name == '@reduce':
-                group = rec[1]
-                if not group.ready:
-                    group.build()                    # first run: the slots before this record have just been described (and reduced one by one)
-                elif group.n:
-                    rc = lib.hdy_wgrad_reduce_batch(group.table.data_ptr(), group.n, group.blocks, s)
-                    if rc != 0:
-                        raise _lib.HdyError(f'hdy_wgrad_reduce_batch failed (status {rc}): {lib.hdy_last_error().decode()}')
             continue
         rc = getattr(lib, name)(*args, s)
         if rc != 0:
@@ -201,7 +147,7 @@ def rec_conv_fwd(x, wp, y, K, R, S, stride, pad, scale=None, shift=None, stats=N
     if res is not None:
         rp, _, _, _, Kr, ldr = nhwc(res)
         assert Kr == K and res.dtype == y.dtype and res.shape == y.shape
-    return _rec(locals(), 'hdy_conv_fwd', (xp, ldx, ptr(wp), ptr(scale), ptr(shift), rp, ldr, yp, ldy, ptr(stats), N, H, W, C, K, R, S, stride, pad, act,
+    return _rec(locals(), 'hdy_conv_fwd', (xp, ldx, ptr(wp), ptr(scale), ptr(shift), rp, ldr, yp, ldy, ptr(stats), 0 if stats is None else stats.shape[0], N, H, W, C, K, R, S, stride, pad, act,
                              int(accumulate), dcode(x.dtype), out_f32, stem))
 
 
@@ -214,7 +160,7 @@ class StatRequest:
         for t in (scale, shift):
             assert t.dtype == torch.float32 and t.numel() >= K and t.stride(0) == 1
         assert slabs.dtype == torch.float32 and slabs.is_contiguous() and slabs.shape[1:] == (2, K)
-        self.c = _lib.StatReq(yp, ldy, ptr(scale), ptr(shift), ptr(slabs), c0, c0 + K, act)
+        self.c = _lib.StatReq(yp, ldy, ptr(scale), ptr(shift), ptr(slabs), c0, c0 + K, act, slabs.shape[0])
         self.keep = (y, scale, shift, slabs)
 
 
@@ -382,7 +328,7 @@ def rec_bn_finalize(stats, mtiles, K, count, gamma, beta, rmean, rvar, scale, sh
                     eps=BN_EPS, momentum=BN_MOMENTUM, stats_ld=None, ws=None):
     """stats may be a channel slice [.., k0:k0+K] of a wider slab: stats_ld is the slab's channel count."""
     return _rec(locals(), 'hdy_bn_finalize', (ptr(stats), K if stats_ld is None else stats_ld, mtiles, K, count, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), eps, momentum, ptr(scale),
-                                ptr(shift), ptr(save_mean), ptr(save_invstd), ptr(ws)))
+                                ptr(shift), ptr(save_mean), ptr(save_invstd), ptr(ws), _nbytes(ws)))
 
 
 def rec_bn_finalize_pair(stats, mtiles, K, Ka, count, bn_a, bn_b, scale, shift, save_mean, save_invstd, eps=BN_EPS, momentum=BN_MOMENTUM, ws=None):
@@ -390,7 +336,7 @@ def rec_bn_finalize_pair(stats, mtiles, K, Ka, count, bn_a, bn_b, scale, shift, 
     ga, ba, rma, rva = bn_a
     gb, bb, rmb, rvb = bn_b
     return _rec(locals(), 'hdy_bn_finalize_pair', (ptr(stats), K, mtiles, K, Ka, count, ptr(ga), ptr(ba), ptr(rma), ptr(rva), ptr(gb), ptr(bb), ptr(rmb),
-                                     ptr(rvb), eps, momentum, ptr(scale), ptr(shift), ptr(save_mean), ptr(save_invstd), ptr(ws)))
+                                     ptr(rvb), eps, momentum, ptr(scale), ptr(shift), ptr(save_mean), ptr(save_invstd), ptr(ws), _nbytes(ws)))
 
 
 def rec_bn_slab_sums(slabs, nslabs, K, count, sums):
@@ -446,7 +392,7 @@ def rec_bn_act_bwd_pair(dz_a, dz_b, y, scale, shift, mean, invstd, dy, dgamma_a,
         assert y.shape == dy.shape and y.dtype == dy.dtype
     assert Ka + Kb == K and dz_a.dtype == dz_b.dtype == y.dtype and ws.numel() >= bn_bwd_ws_floats(N * H * W, K)
     return _rec(locals(), 'hdy_bn_act_bwd_pair', (dap, ldda, dbp, lddb, Ka, yp, ldy, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), dyp, lddy, ptr(dgamma_a),
-                                    ptr(dbeta_a), ptr(dgamma_b), ptr(dbeta_b), int(accumulate), N * H * W, K, act, dcode(dz_a.dtype), ptr(ws)))
+                                    ptr(dbeta_a), ptr(dgamma_b), ptr(dbeta_b), int(accumulate), N * H * W, K, act, dcode(dz_a.dtype), ptr(ws), _nbytes(ws)))
 
 
 def bn_bwd_blocks(M):
@@ -454,7 +400,7 @@ def bn_bwd_blocks(M):
 
 
 def bn_bwd_ws_floats(M, K):
-    return _lib.query('hdy_bn_bwd_blocks', M) * 2 * K + 2 * K
+    return _lib.query('hdy_bn_bwd_workspace_bytes', M, K) // 4
 
 
 def rec_bn_act_bwd(dz, y, scale, shift, mean, invstd, dy, dgamma, dbeta, ws, accumulate=False, act=ACT_SILU):
@@ -466,7 +412,7 @@ def rec_bn_act_bwd(dz, y, scale, shift, mean, invstd, dy, dgamma, dbeta, ws, acc
         assert y.shape == dy.shape and y.dtype == dy.dtype
     assert dz.shape == y.shape and dz.dtype == y.dtype and ws.numel() >= bn_bwd_ws_floats(N * H * W, K)
     return _rec(locals(), 'hdy_bn_act_bwd', (dzp, lddz, yp, ldy, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), dyp, lddy, ptr(dgamma), ptr(dbeta),
-                               int(accumulate), N * H * W, K, act, dcode(dz.dtype), ptr(ws)))
+                               int(accumulate), N * H * W, K, act, dcode(dz.dtype), ptr(ws), _nbytes(ws)))
 
 
 def bn_bwd_coeffs(ws, M, K):
@@ -513,7 +459,7 @@ def rec_conv1x1_bwd_fused(dz_a, dz_b, y, scale, shift, mean, invstd, c1, c2, x, 
 def rec_colsum(dz, out, ws, accumulate=False):
     dzp, N, H, W, K, lddz = nhwc(dz)
     assert out.dtype == torch.float32 and out.numel() >= K and ws.numel() >= bn_bwd_ws_floats(N * H * W, K)
-    return _rec(locals(), 'hdy_colsum', (dzp, lddz, N * H * W, K, ptr(out), int(accumulate), dcode(dz.dtype), ptr(ws)))
+    return _rec(locals(), 'hdy_colsum', (dzp, lddz, N * H * W, K, ptr(out), int(accumulate), dcode(dz.dtype), ptr(ws), _nbytes(ws)))
 
 
 def rec_det_grad_pack(g, out, na, no):
@@ -811,7 +757,7 @@ def groupnorm_relu_fwd(x, gamma, beta, G, eps=1e-5, relu=True):
     ab = torch.empty((N, 2, C), dtype=torch.float32, device=x.device)
     ws = torch.empty(_lib.query('hdy_groupnorm_workspace_floats', N, C), dtype=torch.float32, device=x.device)
     _lib.call('hdy_groupnorm_fwd', xp, ldx, ptr(gamma), ptr(beta), y.data_ptr(), C, stat.data_ptr(), ab.data_ptr(), N, H * W, C, G, float(eps),
-              int(relu), dcode(x.dtype), ws.data_ptr(), stream_ptr())
+              int(relu), dcode(x.dtype), ws.data_ptr(), ws.numel(), stream_ptr())
     return y, (stat, ab)
 
 
@@ -825,7 +771,7 @@ def groupnorm_relu_bwd(dout, x, gamma, saved, G, dgamma, dbeta, relu=True, accum
     ws = torch.empty(_lib.query('hdy_groupnorm_workspace_floats', N, C), dtype=torch.float32, device=x.device)
     assert dout.dtype == x.dtype and dgamma.dtype == dbeta.dtype == torch.float32 and dgamma.is_contiguous() and dbeta.is_contiguous()
     _lib.call('hdy_groupnorm_bwd', dop, lddo, xp, ldx, ptr(gamma), stat.data_ptr(), ab.data_ptr(), dx.data_ptr(), C, dgamma.data_ptr(),
-              dbeta.data_ptr(), int(accumulate), coef.data_ptr(), N, H * W, C, G, int(relu), dcode(x.dtype), ws.data_ptr(), stream_ptr())
+              dbeta.data_ptr(), int(accumulate), coef.data_ptr(), N, H * W, C, G, int(relu), dcode(x.dtype), ws.data_ptr(), ws.numel(), stream_ptr())
     return dx
 
 
@@ -871,7 +817,7 @@ def softdice(logits, targets, class_weight=None, upstream=None, want_grad=False)
     # 4-float pixels with <= 4 classes: the backward pass writes whole pixels (padding channels as zeros) — no 419 MB memset at 16 x 1280 x 1280
     dl = (torch.empty_like(logits) if ld == 4 and nc <= 4 else torch.zeros_like(logits)) if want_grad else None
     _lib.call('hdy_softdice', logits.data_ptr(), ld, targets.data_ptr(), ptr(class_weight), N, H * W, nc, loss.data_ptr(), ptr(upstream),
-              ptr(dl), ld, ws.data_ptr(), stream_ptr())
+              ptr(dl), ld, ws.data_ptr(), ws.numel(), stream_ptr())
     return loss, dl
 
 
@@ -892,7 +838,7 @@ def softdice_wgrad(logits, targets, class_weight, in_w):
     ws = torch.empty(_lib.query('hdy_softdice_workspace_floats', N, nc), dtype=torch.float32, device=logits.device)
     dw = torch.empty((N, H, in_w, 4), dtype=torch.float32, device=logits.device)
     _lib.call('hdy_softdice_wgrad', logits.data_ptr(), targets.data_ptr(), ptr(class_weight), N, H, W, nc, in_w, loss.data_ptr(), dw.data_ptr(),
-              ws.data_ptr(), stream_ptr())
+              ws.data_ptr(), ws.numel(), stream_ptr())
     return loss, dw
 
 

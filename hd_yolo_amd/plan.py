@@ -35,11 +35,6 @@ SKIP_WGRAD = os.environ.get('HDY_SKIP_WGRAD') == '1'     # measurement only: no 
 PRODUCER_STATS = os.environ.get('HDY_PRODUCER_STATS', 'fused')       # 'fused': statistics served by the fused 1x1 backward kernel only (train step 13.47 vs 13.54 ms off); '1': by dgrad epilogues too (slower); '0': off
 STEM_FUSED = os.environ.get('HDY_STEM_FUSED', '1') == '1'   # the stem's weight gradient applies its unit's BatchNorm / SiLU backward itself (no dy tensor)
 FUSED_1X1 = os.environ.get('HDY_FUSED_1X1', '1') == '1'     # BN-apply + wgrad + dgrad of eligible 1x1 units in one kernel (conv1x1_bwd.hip)
-# Split reductions of the weight gradients as ONE launch per gradient bucket (hdy_wgrad_reduce_batch) instead of one or two per layer.  Built,
-# bit-identical (tests/test_gpu_model.py::test_batched_split_reduction_is_bit_identical) and NOT the default: yolov5s B=64 step 12.20 / 12.23 ms
-# batched against 12.06 / 12.09 ms per layer on one box — deferring the reductions means every layer keeps its own slab workspace (1.5 GB in all)
-# until its bucket ends, and the slabs that a per-layer reduction reads back hot from the Infinity Cache now make a round trip through HBM.
-BATCH_REDUCE = os.environ.get('HDY_BATCH_REDUCE', '0') == '1' and not USE_GRAPHS
 GRAD_BUCKET_BYTES = int(os.environ.get('HDY_GRAD_BUCKET_MB', '6')) << 20      # granularity of the "these gradients are final" marks
 
 
@@ -364,7 +359,6 @@ class Plan:
                         max_f1 = max(max_f1, ops.fused_1x1_ws_bytes(M, u.C, u.K))
                         wgb = ops.fused_1x1_ws_bytes(M, u.C, u.K)
                     # batched split reductions: the slabs of a unit stay untouched until its bucket's one reduction launch has read them
-                    u.own_ws = self._new(wgb // 4 + 16, dtype=f32) if BATCH_REDUCE else None
                     if not u.stem:
                         u.wpd = ops.pack_alloc(u.K, u.C, u.k, u.k, u.s, u.p, ops.PACK_DGRAD, dt, self.device)
             elif isinstance(u, DetUnit):
@@ -377,7 +371,6 @@ class Plan:
                     wgb = ops.wgrad_ws_bytes(x.n, x.h, x.w, x.c, u.Kp, 1, 1, 1, 0, dt)
                     max_wg = max(max_wg, wgb)
                     max_bnws = max(max_bnws, ops.bn_bwd_ws_floats(M, u.Kp))
-                    u.own_ws = self._new(wgb // 4 + 16, dtype=f32) if BATCH_REDUCE else None
             elif isinstance(u, PoolUnit):
                 if self.training:
                     a = u.x
@@ -619,8 +612,6 @@ class Plan:
         def wgrad(rec, reads_dy_slot=None):
             if SKIP_WGRAD:          # timing experiment only (gradients wrong): what the step costs without the weight-gradient stream
                 return
-            if BATCH_REDUCE:
-                rec = ('@wgrad', rec, ops.ReduceSlot())
             if side is None:
                 recs.append(rec)
                 return
@@ -689,7 +680,7 @@ class Plan:
                 gb = self._grad_views(u.conv.bias)
                 recs.append(('@call', (lambda gb=gb, tmp=tmp, K=u.K: gb.copy_(tmp[:K]))))       # Kp-padded column sums -> the bias gradient
                 gw = self._grad_views(u.conv.weight)
-                wgrad(ops.rec_conv_wgrad(x.t(), u.gdet, gw, None, 1, 1, 1, 0, u.own_ws if BATCH_REDUCE else self.wg_ws))
+                wgrad(ops.rec_conv_wgrad(x.t(), u.gdet, gw, None, 1, 1, 1, 0, self.wg_ws))
                 if not up(x):
                     continue
                 self.packs.add(u.conv.weight, None, 1, 0, ops.PACK_DGRAD, u.wpd, K=u.Kp)
@@ -815,7 +806,7 @@ class Plan:
                         gb = self._grad_views(u.mods[1].conv.weight) if want_w and len(u.mods) > 1 else None
                         mk = (lambda st, u=u, x=x, xv=xv, c1=c1, c2=c2, ga=ga, gb=gb, acc=acc, want_x=want_x: ops.rec_conv1x1_bwd_fused(
                             u.outs[0].gread(), u.outs[1].gread() if len(u.mods) > 1 else None, u.yraw, u.scale, u.shift, u.mean, u.invstd, c1, c2, x,
-                            u.wpd if want_x else None, xv.g() if want_x else None, ga, gb, u.own_ws if BATCH_REDUCE else self.f1_ws, accumulate_dx=acc, stats=st))
+                            u.wpd if want_x else None, xv.g() if want_x else None, ga, gb, self.f1_ws, accumulate_dx=acc, stats=st))
                         recs.append(mk(None))
                         if want_x:
                             note_grad(xv, 'fused', len(recs) - 1, mk, ops.fused_1x1_stat_slabs(M, u.C, u.K, self.dtype))
@@ -824,10 +815,10 @@ class Plan:
                 gb = self._grad_views(u.mods[1].conv.weight) if len(u.mods) > 1 else None
                 if stem_fused:
                     wgrad(ops.rec_conv_wgrad_stem_fused(x, u.outs[0].gread(), u.yraw, u.scale, u.shift, u.mean, u.invstd, c1, c2, stem_hw, ga, None,
-                                                        u.own_ws if BATCH_REDUCE else self.wg_ws))
+                                                        self.wg_ws))
                     continue
                 if want_w:
-                    wgrad(ops.rec_conv_wgrad(x, dy, ga, gb, u.k, u.k, u.s, u.p, u.own_ws if BATCH_REDUCE else self.wg_ws, stem_hw=stem_hw), reads_dy_slot=slot)
+                    wgrad(ops.rec_conv_wgrad(x, dy, ga, gb, u.k, u.k, u.s, u.p, self.wg_ws, stem_hw=stem_hw), reads_dy_slot=slot)
                 if want_x:
                     mk = (lambda st, u=u, dy=dy, xv=xv, acc=acc: ops.rec_conv_dgrad(dy, u.wpd, xv.g(), u.k, u.k, u.s, u.p, accumulate=acc, stats=st))
                     recs.append(mk(None))
@@ -836,10 +827,6 @@ class Plan:
         for idx, reqs in pending.items():                   # rebuild the producers with the statistics requests they serve
             recs[idx] = remake[idx](reqs)
         self.producer_stat_units = sum(len(v) for v in pending.values())
-        if BATCH_REDUCE:                                    # the fused 1x1 backward launches (main stream) end with split reductions too
-            for i, r in enumerate(recs):
-                if r[0] in ('hdy_conv1x1_bwd_fused', 'hdy_conv1x1_bwd_fused_stats') and r[1][19] is not None:
-                    recs[i] = ('@wgrad', r, ops.ReduceSlot())
         self._mark_buckets(recs, side, nfork)
         last_fork = next((r[3] for r in reversed(recs) if r[0] == '@fork'), None)      # in LIST order (the reduce forks got their tokens later)
         if side is not None and last_fork is not None:
@@ -869,39 +856,12 @@ class Plan:
         by_pos = {}
         for ready, a, b in marks:
             by_pos.setdefault(ready, []).append((a, b))
-        # batched split reductions: the weight-gradient records up to a mark's position form one group, reduced by ONE launch (on the side
-        # stream, which also waits for the main stream's fused 1x1 launches of the group) right in front of the mark
-        slots = []
-        for i, r in enumerate(recs):
-            if r[0] == '@wgrad':
-                slots.append((i, r[2]))
-            elif r[0] == '@fork':
-                slots += [(i, q[2]) for q in r[2] if q[0] == '@wgrad']
-        groups, prev = {}, -1
-        for pos in sorted(by_pos):
-            groups[pos] = [s for i, s in slots if prev < i <= pos]
-            prev = pos
-        tail = [s for i, s in slots if i > prev]
-        self.reduce_groups = []
-
-        def reduce_rec(members):
-            g = ops.ReduceGroup(members, self.device)
-            self.reduce_groups.append(g)
-            if side is None:
-                return ('@reduce', g)
-            nfork[0] += 1
-            return ('@fork', side, [('@reduce', g)], nfork[0] - 1)
-
         self.grad_marks = []
-        if tail:
-            recs.append(reduce_rec(tail))
         for pos in sorted(by_pos, reverse=True):              # insert from the back so earlier positions stay valid
             for a, b in by_pos[pos]:
                 fn = (lambda a=a, b=b: self.bucket_hook(a, b, side.stream if side is not None else None) if self.bucket_hook else None)
                 recs.insert(pos + 1, ('@call', fn))
                 self.grad_marks.append((pos + 1, a, b))
-            if groups.get(pos):
-                recs.insert(pos + 1, reduce_rec(groups[pos]))
 
     def _det_bias_tmp(self, u):
         if not hasattr(u, 'gbias_pad'):

@@ -172,6 +172,25 @@ def synth_state_dict(shapes, seed=0):
     return out
 
 
+def calibrate_det_logits(model, x, tag='det'):
+    """Random-init deep variants (yolov5l: ~100 convolutions with eval-mode BatchNorm) blow the activations up by orders of magnitude, so the detection
+    logits come out at +-1e5 and every sigmoid is exactly 0 or 1: no objectness spread for a threshold to cut, boxes the size of the anchors' squares.
+    A trained network does not look like that.  This rescales the three detection convs (weights only, in place) so that each level's logits have unit
+    spread around the synthetic biases — one eval forward of `x` (a couple of tiles) measures the spread.  Returns the per-level factors."""
+    import torch
+    head = model.headers[tag]
+    was_training = model.training
+    model.eval()
+    with torch.no_grad():
+        model(x)
+        plan = list(model._eng().plans.values())[-1]
+        stds = [float(d.float().std()) for d in plan.det_views()]
+        for conv, s in zip(head.m, stds):
+            conv.weight.div_(max(s, 1e-6))              # in place under no_grad: bumps the version counter, the eval plans re-pack
+    model.train(was_training)
+    return stds
+
+
 def mask_state_dict(module, seed=0):
     """synth_state_dict with the detection convs damped, so that matched cells predict (almost) their anchor box: IoU >= 0.8 with the
     anchor-shaped truths of synth_mask_targets — otherwise nothing would reach the mask head."""

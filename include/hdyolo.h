@@ -91,11 +91,13 @@ int hdy_conv_pack_describe(const float* w_a, int K_a, const float* w_b, int K_b,
 int hdy_conv_pack_run(const hdy_pack_desc* descs_device, int ndesc, int total_blocks, void* stream);
 
 /* y = act(scale[k] * conv(x, w)[.., k] + shift[k]) + res (+= y when accumulate).  scale/shift/res may be NULL (1 / 0 / none).
- * stats (optional, train-mode BN): [hdy_conv_stat_slabs(...)][2][K] floats, partial sums and sums of squares of
- * the raw convolution (before scale/shift/act).  out_f32: write fp32 even when dtype is bf16 (detection logits).
+ * stats (optional, train-mode BN): [stat_slabs][2][K] floats, partial sums and sums of squares of the raw convolution (before
+ * scale/shift/act); stat_slabs = what hdy_conv_stat_slabs(...) returned when the caller sized the array.  The launcher compares it with the
+ * number of slabs the kernel it is about to start writes and returns HDY_EINVAL on a mismatch (a kernel-selection switch flipped
+ * between the sizing query and the launch would otherwise write past the array or leave stale slabs for hdy_bn_finalize).  out_f32: write fp32 even when dtype is bf16 (detection logits).
  * stem: x is the hdy_stem_prep buffer; requires C=3, R=S=6, stride=2, pad=2, ldx=4. */
 int hdy_conv_fwd(const void* x, int ldx, const void* w_packed, const float* scale, const float* shift, const void* res, int ldr, void* y,
-                 int ldy, float* stats, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int act, int accumulate,
+                 int ldy, float* stats, int stat_slabs, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int act, int accumulate,
                  int dtype, int out_f32, int stem, void* stream);
 
 /* dx[N][H][W][C] (+)= conv_transpose(dy[N][Ho][Wo][K], w); stride 1 or 2. */
@@ -127,6 +129,7 @@ typedef struct {
     const float *scale, *shift;
     float* slabs;
     int c0, c1, act;
+    int nslabs;          /* slabs the caller's array holds (the hdy_*_stat_slabs query it was sized with): HDY_EINVAL unless the launch writes exactly that many */
 } hdy_stat_req;
 int hdy_conv1x1_bwd_fused_stat_slabs(long long M, int C, int K, int dtype);
 /* slabs a stats-serving launch writes (= its workgroups); 0: this shape cannot serve statistics */
@@ -159,11 +162,12 @@ int hdy_conv1x1_bwd_fused(const void* dz_a, int lddz_a, const void* dz_b, int ld
  * Conv.forward (metayolo/models/layers.py:37-38), the shortcut add of Bottleneck.forward (:97), their backward,
  * and the eval-time folding of fuse_conv_and_bn (metayolo/models/utils_torch.py:79-99). */
 /* stats: [mtiles][2][stats_ld] slabs from hdy_conv_fwd (channel slice of K).  workspace (optional, enables the parallel
- * two-stage reduction for mtiles > 1024): hdy_bn_finalize_workspace_bytes(mtiles, K) bytes, 8-byte aligned. */
+ * two-stage reduction for mtiles > 1024): ws_bytes >= hdy_bn_finalize_workspace_bytes(mtiles, K), 8-byte aligned (HDY_EINVAL when a
+ * non-NULL workspace is smaller). */
 size_t hdy_bn_finalize_workspace_bytes(int mtiles, int K);
 int hdy_bn_finalize(const float* stats, int stats_ld, int mtiles, int K, long long count, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float eps, float momentum, float* scale, float* shift, float* save_mean, float* save_invstd,
-                    void* workspace, void* stream);
+                    void* workspace, size_t ws_bytes, void* stream);
 int hdy_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, int K,
                        float* scale, float* shift, void* stream);
 /* The same for every BatchNorm of an inference plan in ONE launch: the caller fills the descriptors on the host, copies them into
@@ -182,12 +186,13 @@ int hdy_bn_eval_coeffs_batch(const hdy_bn_eval_desc* descs_device, int ndesc, vo
 int hdy_bn_act_fwd(const void* y, int ldy, const float* scale, const float* shift, const void* res, int ldr, void* z, int ldz,
                    long long M, int K, int act, int dtype, void* stream);
 int hdy_bn_bwd_blocks(long long M);
-/* workspace: (hdy_bn_bwd_blocks(M) * 2 * K + 2 * K) floats */
+/* workspace: ws_bytes >= hdy_bn_bwd_workspace_bytes(M, K) = (hdy_bn_bwd_blocks(M) * 2 * K + 2 * K) floats (HDY_EINVAL otherwise) */
+size_t hdy_bn_bwd_workspace_bytes(long long M, int K);
 /* mean == invstd == NULL: frozen statistics (FrozenBatchNorm2d, metayolo/models/utils_torch.py:180-203): dy = scale * dz * act'(u),
  * dgamma / dbeta untouched. */
 int hdy_bn_act_bwd(const void* dz, int lddz, const void* y, int ldy, const float* scale, const float* shift, const float* mean,
                    const float* invstd, void* dy, int lddy, float* dgamma, float* dbeta, int accumulate, long long M, int K, int act,
-                   int dtype, float* workspace, void* stream);
+                   int dtype, float* workspace, size_t ws_bytes, void* stream);
 /* dy == NULL: statistics only (reduce + finalize: dgamma, dbeta, and c1 = dbeta/M, c2 = dgamma/M left in
  * workspace[hdy_bn_bwd_blocks(M)*2*K .. +2K)) for a consumer that applies them itself (hdy_conv1x1_bwd_fused). */
 /* The same three passes for the PAIR of BatchNorms behind a C3's cv1 | cv2 (metayolo/models/layers.py:126-131: both read the same
@@ -198,15 +203,16 @@ int hdy_bn_act_bwd(const void* dz, int lddz, const void* y, int ldy, const float
 int hdy_bn_finalize_pair(const float* stats, int stats_ld, int mtiles, int K, int Ka, long long count, const float* gamma_a, const float* beta_a,
                          float* running_mean_a, float* running_var_a, const float* gamma_b, const float* beta_b, float* running_mean_b,
                          float* running_var_b, float eps, float momentum, float* scale, float* shift, float* save_mean, float* save_invstd,
-                         void* workspace, void* stream);
+                         void* workspace, size_t ws_bytes, void* stream);
 int hdy_bn_act_fwd_pair(const void* y, int ldy, const float* scale, const float* shift, void* z_a, int ldz_a, void* z_b, int ldz_b, int Ka,
                         long long M, int K, int act, int dtype, void* stream);
 int hdy_bn_act_bwd_pair(const void* dz_a, int lddz_a, const void* dz_b, int lddz_b, int Ka, const void* y, int ldy, const float* scale,
                         const float* shift, const float* mean, const float* invstd, void* dy, int lddy, float* dgamma_a, float* dbeta_a,
-                        float* dgamma_b, float* dbeta_b, int accumulate, long long M, int K, int act, int dtype, float* workspace, void* stream);
+                        float* dgamma_b, float* dbeta_b, int accumulate, long long M, int K, int act, int dtype, float* workspace, size_t ws_bytes, void* stream);
 int hdy_add_inplace(void* out, int ldo, const void* a, int lda, long long M, int K, int dtype, void* stream);
-/* out[k] (+)= sum_m dz[m][k]: bias gradient of Detect's conv (yolo_head.py:112).  workspace: hdy_bn_bwd_blocks(M)*2*K floats */
-int hdy_colsum(const void* dz, int lddz, long long M, int K, float* out, int accumulate, int dtype, float* workspace, void* stream);
+/* out[k] (+)= sum_m dz[m][k]: bias gradient of Detect's conv (yolo_head.py:112).  workspace: ws_bytes >= hdy_colsum_workspace_bytes(M, K) = hdy_bn_bwd_blocks(M)*2*K floats */
+size_t hdy_colsum_workspace_bytes(long long M, int K);
+int hdy_colsum(const void* dz, int lddz, long long M, int K, float* out, int accumulate, int dtype, float* workspace, size_t ws_bytes, void* stream);
 
 /* ---- SPPF pooling, upsample, layout --------------------------------------------------------------------------
  * Replaces nn.MaxPool2d(5,1,2) x3 of SPPF.forward (metayolo/models/layers.py:181-189), nn.Upsample(None,2,'nearest')
@@ -311,10 +317,10 @@ int hdy_scale_inplace(void* p, long long n, const float* scale_dev, int dtype, v
  * metayolo/models/utils_general.py:268-280).  NHWC, pixel pitches, caller-owned workspaces as everywhere else. */
 size_t hdy_groupnorm_workspace_floats(int N, int C);
 int hdy_groupnorm_fwd(const void* x, int ldx, const float* gamma, const float* beta, void* y, int ldy, float* stat, float* ab, int N, int HW,
-                      int C, int G, float eps, int relu, int dtype, float* workspace, void* stream);
+                      int C, int G, float eps, int relu, int dtype, float* workspace, size_t ws_floats, void* stream);
 int hdy_groupnorm_bwd(const void* dout, int lddo, const void* x, int ldx, const float* gamma, const float* stat, const float* ab, void* dx, int lddx,
                       float* dgamma, float* dbeta, int accumulate, float* coef, int N, int HW, int C, int G, int relu, int dtype, float* workspace,
-                      void* stream);
+                      size_t ws_floats, void* stream);
 int hdy_bilinear_fwd(const void* x, int ldx, void* y, int ldy, int N, int Hi, int Wi, int Ho, int Wo, int C, int accumulate, int dtype, void* stream);
 int hdy_bilinear_bwd(const void* dy, int lddy, void* dx, int lddx, int N, int Hi, int Wi, int Ho, int Wo, int C, int accumulate, int dtype, void* stream);
 /* one axis of the same (the resize is separable): tensors [outer][Ao -> Ai][inner][ld]; W pass outer = N*Ho, inner = 1, then H pass outer = N,
@@ -323,13 +329,13 @@ int hdy_bilinear_bwd_axis(const void* dy, int lddy, void* dx, int lddx, long lon
                           void* stream);
 size_t hdy_softdice_workspace_floats(int N, int nc);
 int hdy_softdice(const float* logits, int ldl, const float* targets, const float* class_weight, int N, int HW, int nc, float* loss,
-                 const float* upstream, float* dlogits, int lddl, float* workspace, void* stream);
+                 const float* upstream, float* dlogits, int lddl, float* workspace, size_t ws_floats, void* stream);
 /* hdy_softdice's loss, and its gradient already reduced along W by the transposed resize (the W pass of hdy_bilinear_bwd_axis) without the
  * full-resolution gradient tensor: logits fp32 [N][H][W][4] with nc <= 4 classes (the segmentation header's resized class logits,
  * hnet/segmentation/panoptic_seg.py:37-40), dw [N][H][Wi][4]; the caller finishes with the H pass.  Bit-identical to the two-call path.
- * workspace: hdy_softdice_workspace_floats(N, nc). */
+ * workspace: ws_floats >= hdy_softdice_workspace_floats(N, nc) (every workspace of this section: HDY_EINVAL when smaller). */
 int hdy_softdice_wgrad(const float* logits, const float* targets, const float* class_weight, int N, int H, int W, int nc, int Wi, float* loss, float* dw,
-                       float* workspace, void* stream);
+                       float* workspace, size_t ws_floats, void* stream);
 int hdy_softmax2d(const float* logits, int ldl, float* probs, int ldp, long long M, int nc, void* stream);
 
 /* The stem's weight gradient (layers.py:31 Conv(3, c, 6, 2, 2), backward of train.py:472) with the BatchNorm / SiLU backward of its unit applied
@@ -358,27 +364,6 @@ int hdy_bn_bwd_coeffs_sums(const double* sums, int K, float* c1, float* c2, void
  * hdy_sgd_blocks(n).  g' = g + wd*p; buf = momentum*buf + (1-dampening)*g'; p -= lr * (nesterov ? g' + momentum*buf : buf).
  * lr / momentum / dampening / weight_decay: HOST arrays of ngroups (<= HDY_SGD_MAX_GROUPS) values, passed by value to the kernel. */
 #define HDY_SGD_MAX_GROUPS 8
-/* ---- batched split reduction of the weight gradients --------------------------------------------------------------------------
- * Every weight-gradient entry point (hdy_conv_wgrad, hdy_conv_wgrad_stem_fused, hdy_conv1x1_bwd_fused[_stats]) ends with one or two
- * "sum the fp32 slabs into the gradient tensor" launches: ~60 launches of ~14 us per yolov5s step.  A caller with a static launch list
- * (hd_yolo_amd/plan.py) records them once and replays them as ONE launch per gradient bucket:
- *   hdy_wgrad_reduce_mode(1, descs_host, cap): TEE  — this thread's reductions run as usual AND are described into descs_host;
- *   hdy_wgrad_reduce_mode(2, NULL, 0):         SKIP — they are not launched (the caller owns the descriptors and runs hdy_wgrad_reduce_batch);
- *   hdy_wgrad_reduce_mode(0, NULL, 0):         back to normal.  Returns the number of descriptors recorded since the mode was entered.
- * The slab workspace of a recorded call must stay untouched until its batch has run (one workspace per call, not a shared one).
- * Same summation order as the single launches: results are bit-identical.  Replaces nothing in the reference (autograd accumulates
- * weight gradients inside ATen's conv backward, train.py:472). */
-typedef struct hdy_reduce_desc {
-    const float* partial;
-    float* grad;
-    unsigned long long slab_stride;
-    int splits, K, Q, mode, C, R, S, accumulate, vec;
-    int first_block, nblocks;
-    int pad_;
-} hdy_reduce_desc;
-int hdy_wgrad_reduce_mode(int mode, hdy_reduce_desc* descs_host, int cap);
-int hdy_wgrad_reduce_batch(const hdy_reduce_desc* table_device, int ndesc, int total_blocks, void* stream);
-
 typedef struct hdy_sgd_desc {
     float* p;
     const float* g;

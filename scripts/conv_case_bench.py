@@ -13,11 +13,14 @@ y = torch.empty((N, H, W, K), dtype=dt, device=dev)
 wp = ops.pack_alloc(K, C, R, R, 1, R // 2, ops.PACK_FWD, dt, dev)
 sc = torch.ones(K, device=dev); sh = torch.zeros(K, device=dev)
 ops.run([ops.rec_pack(w, None, 1, R // 2, ops.PACK_FWD, wp)])
-rec = [ops.rec_conv_fwd(x, wp, y, K, R, R, 1, R // 2, scale=sc, shift=sh, act=ops.ACT_SILU)]
+if os.environ.get('ACT', '1') == '0':      # raw output (train forward / data gradient epilogue)
+    rec = [ops.rec_conv_fwd(x, wp, y, K, R, R, 1, R // 2)]
+else:
+    rec = [ops.rec_conv_fwd(x, wp, y, K, R, R, 1, R // 2, scale=sc, shift=sh, act=ops.ACT_SILU)]
 for _ in range(3): ops.run(rec)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(10): ops.run(rec)
 e1.record(); torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 100
-print(f'{us:.1f} us  {2.0*N*H*W*K*C*R*R/us/1e6:.1f} TF')
+print(f'{us:.1f} us  {2.0*N*H*W*K*C*R*R/us/1e6:.1f} TF  [{_lib.query("hdy_last_dispatch").decode()}] act={os.environ.get("ACT", "1")}')

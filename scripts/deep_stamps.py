@@ -39,6 +39,12 @@ for ph, recs in (('F', plan.fwd), ('B', plan.bwd)):
         print(f'{label:40s} {us:7.1f} us  dbg={os.environ.get("HDY_DEEP_DEBUG")}  wgs {len(rows)} (longest walk: {len(full)} with {big} phases)  '
               f'wave0: loop {avg(0) / big:7.0f} cyc/phase, epilogue {avg(1):8.0f} cyc total, kernel {avg(3):8.0f} cyc   '
               f'wave4: loop {avg(4) / big:7.0f} cyc/phase, kernel {avg(7):8.0f} cyc  -> clock {avg(3) / us / 1e3:5.2f} GHz if the kernel were the whole time', flush=True)
+        if int(os.environ.get('HDY_DEEP_DEBUG', '0')) & 128:
+            kbuf = (ctypes.c_ulonglong * (256 * 8))()
+            assert lib.hdy_deep_debug_read_ktiles(kbuf) == 0
+            tot = [sum(kbuf[w * 8 + i] for w in range(256)) for i in range(8)]
+            print('      K-tile position after an epilogue -> cycles per K-tile: ' + '  '.join(
+                f'{("kt0", "kt1", "kt2", "later")[i]} {tot[i] / max(tot[4 + i], 1):7.0f} (n={tot[4 + i]})' for i in range(4)), flush=True)
         if int(os.environ.get('HDY_DEEP_DEBUG', '0')) & 64:
             assert lib.hdy_deep_debug_read_segments(sbuf) == 0
             idx = [w for w in range(256) if buf[w * 8 + 2] == big]

@@ -41,18 +41,17 @@ __device__ unsigned long long g_deep_dbg[256 * 8];
 __device__ unsigned long long g_deep_seg[256 * 16];
 __device__ unsigned long long g_deep_kt[256 * 8];       // HDY_DEEP_DEBUG bit 128, wave 0: cycles in K-tile 0 / 1 / 2 / later of the tiles that FOLLOW an epilogue, then the four counts     // [wg][wave 0 | wave 4][issue, vmcnt wait, lgkmcnt wait, barrier 1, MFMAs, reads + barrier 2, -, -] cycle sums (BN = 128)
 
-// Tile boundary, measured in round 4 (profiles/r04_deep_tile_boundary.txt, scripts/probes/tile_boundary_fit.py): in the stamped build the first K-tile after an
-// epilogue takes 7.8 k cycles against 2.3-2.6 k for every other one — the two wave groups run one barrier apart, so the group that leads waits at the next
-// tile's second barrier while the other runs its epilogue: two epilogues back to back.  Three remedies were built on this kernel (kept in
-// scripts/probes/retired/conv_deep_tile_boundary.hip): the groups brought level for the epilogue and staggered again (stamped build: 7.3 k -> 3.9 k cycles,
-// kernel -8 %), the next K-tile's loads retired IN FRONT of the epilogue's stores (vmcnt retires in issue order and counts stores) with that K-tile's
-// counted waits skipped, and the rows of an accumulating epilogue all requested before the first store.  In the SHIPPED build (no stamps) none of them moves
-// anything: time = tiles * (K-tiles * 1.70 us + 2.7-3.5 us) + 5.8 us (9.2 us with BatchNorm sums) for 256 x 128 tiles of a 1x1 layer under every variant —
-// the boundary is the 64 KB output tile leaving at the CU's share of HBM (24 GB/s: 2.7 us), which the other CUs' loads overlap; the stamps' serialisation
-// is an artefact of their own `s_waitcnt lgkmcnt(0)`.  The old epilogue stays.
 // -DHDY_DEEP_DBG=1 compiles the timing ablations / stamps in (scripts/ab_deep.sh builds that variant); the shipped kernel has none of their branches
 #ifndef HDY_DEEP_DBG
 #define HDY_DEEP_DBG 0
+#endif
+// A/B switches of the tile boundary (scripts/build_variant.sh): HDY_DEEP_ALIGN = the two wave groups run a tile's epilogue side by side instead of one
+// after the other; HDY_DEEP_PRESTORE = the next K-tile's loads are retired in front of the epilogue's stores and its counted waits skipped
+#ifndef HDY_DEEP_ALIGN
+#define HDY_DEEP_ALIGN 1
+#endif
+#ifndef HDY_DEEP_PRESTORE
+#define HDY_DEEP_PRESTORE 1
 #endif
 
 namespace {
@@ -84,13 +83,15 @@ template <> struct Geo<128> {
 };
 
 // EPI: 0 raw output (train forward, data gradient), 1 scale / shift, 2 scale / shift + SiLU, 3 scale / shift + ReLU
-template <int BN, bool STATS, int EPI>
+// ADD: the epilogue adds a residual (p.res) or accumulates into the output (p.accumulate): one of the two
+template <int BN, bool STATS, int EPI, bool ADD>
 __global__ __launch_bounds__(NTHR, 2) void conv_deep_kernel(const ConvArgs p) {
     using G = Geo<BN>;
     constexpr int MT = G::MT, NTQ = G::NTQ;
     constexpr int NBH = BN == 256 ? 2 : 1;                        // B halves per wave tile
     constexpr int COEF = G::RING;                                 // [2][BN] epilogue coefficients behind the ring
     static_assert(!(STATS && BN == 256), "BatchNorm sums: 128-wide instances only");
+    static_assert(!(STATS && ADD), "a train forward writes its raw output: nothing is added");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned lds0 = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)smem;
 
@@ -314,9 +315,19 @@ __global__ __launch_bounds__(NTHR, 2) void conv_deep_kernel(const ConvArgs p) {
 
     bf16_t* __restrict__ y = (bf16_t*)p.y;
 
+    // Counted waits and the epilogue's stores.  vmcnt retires in issue order and counts stores like loads (MI355X_MICROARCH.md, last section), so a
+    // counted wait behind a tile's output stores is a wait for those stores: ~5 k cycles until a bf16 row store is acknowledged — stamps by K-tile
+    // position (profiles/r04_deep_tile_boundary.txt): the first K-tile after an epilogue took 7.8 k cycles against 2.3-2.6 k for every other
+    // one, more than the four K-tiles of a 256-channel 1x1 layer's whole tile.  So a tile's epilogue first retires, IN FRONT of its stores, every
+    // unit the next K-tile's waits would have waited for (`wait_skip` of them are then skipped), or everything once the loader has run dry
+    // (`drained`: nothing is in flight any more, no later wait is needed at all).
+    int wait_skip = 0;
+    bool drained = false;
 #define DP_WAIT(n)                                             \
-    {                                                          \
-        if (ld_live) { DP_VMCNT(n); } else { DP_VMCNT(0); }    \
+    if (!drained) {                                            \
+        if (wait_skip > 0) --wait_skip;                        \
+        else if (ld_live) { DP_VMCNT(n); }                     \
+        else { DP_VMCNT(0); drained = true; }                  \
     }
 #define DP_MFMA_PHASE(A_, B_, BF)                                                                                                   \
     if (!(dbg & 4)) {                                                                                                             \
@@ -455,15 +466,12 @@ __global__ __launch_bounds__(NTHR, 2) void conv_deep_kernel(const ConvArgs p) {
                 ktc[4 + slot] += 1;
             }
         }
-        // Tile boundary.  The wave groups run one barrier apart and a group that reaches a barrier waits for the other: left staggered, waves 0-3 run their
-        // epilogue while waves 4-7 wait at the barrier behind their last MFMAs, then waves 4-7 run theirs while waves 0-3 wait at the next tile's second barrier
-        // — two epilogues back to back.  With an activation in the epilogue (two quarter-rate transcendentals per output: the eval / inference instances) that
-        // is worth removing: the groups are brought level here (the leading group waits one barrier), run their epilogues side by side and are staggered again
-        // in front of the next tile — C4 shapes with SiLU, one box (profiles/r04_c4_shapes_ab.txt): 512->512 1x1 @64x64 507 -> 461 us, 256->256 1x1 @128x128
-        // 718 -> 644, 1024->1024 1x1 @32x32 397 -> 373, 256->256 3x3 @64x64 729 -> 688.  The raw epilogue of the training instances (EPI = 0) measured
-        // the same or 2-6 % slower with it (see the file header): it keeps the stagger.
-        constexpr bool ALIGN = EPI >= 1;
-        if (ALIGN && grp == 0) __builtin_amdgcn_s_barrier();
+        // Tile boundary.  The wave groups run one barrier apart, and a group that reaches a barrier waits for the other: left staggered, waves 0-3 run their
+        // epilogue while waves 4-7 wait at the barrier behind their last MFMAs, then waves 4-7 run theirs while waves 0-3 wait at the next tile's second
+        // barrier — two epilogues (a chain of conversions, crossbar swaps and stores: latency, not issue slots) back to back, ~7 k cycles per tile boundary
+        // where a K-tile takes 2.3 k (stamps by K-tile position, profiles/r04_deep_tile_boundary.txt).  So the groups are brought level here (the leading
+        // group waits one barrier), run their epilogues side by side, and are staggered again in front of the next tile.
+        if (HDY_DEEP_ALIGN && grp == 0) __builtin_amdgcn_s_barrier();
         const unsigned long long t_b = (dbg & 32) ? __builtin_readcyclecounter() : 0ull;
         t_loop += t_b - t_a;
         n_ph += (unsigned long long)nkt * (BN == 256 ? 4 : 2);
@@ -475,12 +483,14 @@ __global__ __launch_bounds__(NTHR, 2) void conv_deep_kernel(const ConvArgs p) {
         if (!(dbg & 8)) {
             const int odd = fq & 1;
             const int cl = odd ? 16 + (fq - 1) * 4 : fq * 4;       // this lane's first channel inside the 32-channel pass
+            constexpr int NPASS = NBH * NTQ / 2;                   // passes per (a, m): 16 pixels x 32 channels each
+            V16 outv[2 * MT * NPASS];                               // every pass's 16-byte row piece: arithmetic first, then the wait, then the stores
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int np = 0; np < NBH * NTQ / 2; ++np) {   // pass = 16 pixels x 32 channels
+                    for (int np = 0; np < NPASS; ++np) {
                         const int b = BN == 256 ? np : 0, nb = BN == 256 ? 0 : 2 * np;
                         const int cb = BN == 256 ? b * 128 + wc * 32 : wc * 64 + np * 32;      // first channel of the pass inside the column tile
                         unsigned pk[2][2];
@@ -514,46 +524,71 @@ __global__ __launch_bounds__(NTHR, 2) void conv_deep_kernel(const ConvArgs p) {
                         const unsigned s0 = odd ? pk[0][0] : pk[1][0], s1_ = odd ? pk[0][1] : pk[1][1];
                         const unsigned r0_ = (unsigned)__builtin_amdgcn_ds_swizzle((int)s0, 0x401F);       // lane ^ 16
                         const unsigned r1_ = (unsigned)__builtin_amdgcn_ds_swizzle((int)s1_, 0x401F);
-                        V16 o;
-                        o.i = odd ? i32x4{(int)r0_, (int)r1_, (int)pk[1][0], (int)pk[1][1]} : i32x4{(int)pk[0][0], (int)pk[0][1], (int)r0_, (int)r1_};
-                        const int mg = m0 + a * 128 + (BN == 256 ? wr * 64 : wr * 32) + m * 16 + fr;
-                        const int kc = n0 + cb + cl;
-                        size_t opix = (size_t)mg;
-                        if (walk) {                                // class pixel (n, oi, oj) -> its place in the strided output image
-                            const int mc = min(mg, p.M - 1);
-                            const int n = (int)fdiv((unsigned)mc, p.mg_howo, p.sh_howo), rem = mc - n * HoWo;
-                            const int oi = (int)fdiv((unsigned)rem, p.mg_wo, p.sh_wo), oj = rem - oi * p.Wo;
-                            opix = ((size_t)n * p.Hout + (p.c_oh[j & 3] + oi * p.oh_mul)) * p.Wout + (p.c_ow[j & 3] + oj * p.ow_mul);
-                        }
-                        if (mg < p.M && kc < p.K) {
-                            if (p.res || p.accumulate) {
-                                float f[8];
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) f[e] = (float)o.h[e];
-                                if (p.res) {
-                                    V16 q;
-                                    q.i = *(const i32x4*)((const bf16_t*)p.res + opix * p.ldr + kc);
-#pragma unroll
-                                    for (int e = 0; e < 8; ++e) f[e] += (float)q.h[e];
-                                }
-                                if (p.accumulate) {
-                                    V16 q;
-                                    q.i = *(const i32x4*)(y + opix * p.ldy + kc);
-#pragma unroll
-                                    for (int e = 0; e < 8; ++e) f[e] += (float)q.h[e];
-                                }
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) o.h[e] = (bf16_t)f[e];
-                            }
-                            if (!(dbg & 256)) *(i32x4*)(y + opix * p.ldy + kc) = o.i;
-                            else asm volatile("" ::"v"(o.i));          // timing ablation: the epilogue's arithmetic without its stores
-                        }
+                        outv[(a * MT + m) * NPASS + np].i =
+                            odd ? i32x4{(int)r0_, (int)r1_, (int)pk[1][0], (int)pk[1][1]} : i32x4{(int)pk[0][0], (int)pk[0][1], (int)r0_, (int)r1_};
                     }
+            // Row addresses, then (ADD instances) the rows a residual / accumulating epilogue adds — ALL of them requested before the first store: a
+            // load behind a store in the wave's queue returns after it (in-order retirement), one store round trip per pass (256<-256 1x1 @40x40
+            // with accumulate: 47 us against 31 without, scripts/probes/accumulate_cost.py).  A pass's piece sits CS channels behind the row's first.
+            constexpr int CS = BN == 256 ? 128 : 32;
+            const int kc0 = n0 + (BN == 256 ? wc * 32 : wc * 64) + cl;
+            bf16_t* rowp[2 * MT];
+            V16 addv[ADD ? 2 * MT * NPASS : 1];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const int mg = m0 + a * 128 + (BN == 256 ? wr * 64 : wr * 32) + m * 16 + fr;
+                    size_t opix = (size_t)mg;
+                    if (walk) {                                    // class pixel (n, oi, oj) -> its place in the strided output image
+                        const int mc = min(mg, p.M - 1);
+                        const int n = (int)fdiv((unsigned)mc, p.mg_howo, p.sh_howo), rem = mc - n * HoWo;
+                        const int oi = (int)fdiv((unsigned)rem, p.mg_wo, p.sh_wo), oj = rem - oi * p.Wo;
+                        opix = ((size_t)n * p.Hout + (p.c_oh[j & 3] + oi * p.oh_mul)) * p.Wout + (p.c_ow[j & 3] + oj * p.ow_mul);
+                    }
+                    rowp[a * MT + m] = mg < p.M ? y + opix * p.ldy + kc0 : nullptr;
+                    if constexpr (ADD) {
+                        // one source per launch: the residual (eval epilogues) or the output itself (gradient accumulation); hdy_conv_deep_try keeps
+                        // launches that ask for both on the generic kernel
+                        const bf16_t* src = p.res ? (const bf16_t*)p.res + opix * p.ldr + kc0 : rowp[a * MT + m];
+#pragma unroll
+                        for (int np = 0; np < NPASS; ++np)
+                            addv[(a * MT + m) * NPASS + np].i = (mg < p.M && kc0 + np * CS < p.K) ? *(const i32x4*)(src + np * CS) : i32x4{0, 0, 0, 0};
+                    }
+                }
+            // retire the loads the next K-tile waits for BEFORE the stores enter the queue (see DP_WAIT): BN = 128 leaves A-lo, B of K-tile t + 3 in
+            // flight (covers both waits of K-tile t + 1), BN = 256 nothing (its three waits); with added rows everything (they are needed now); a dry
+            // loader drains once and for all
+            __builtin_amdgcn_sched_barrier(0);
+            if (HDY_DEEP_PRESTORE && j + 1 < my_tiles && !drained) {
+                if (ld_live) {
+                    if (BN == 256 || ADD) { DP_VMCNT(0); } else { DP_VMCNT(4); }
+                    wait_skip = BN == 256 ? 3 : 2;
+                } else {
+                    DP_VMCNT(0);
+                    drained = true;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int am = 0; am < 2 * MT; ++am)
+#pragma unroll
+                for (int np = 0; np < NPASS; ++np) {
+                    V16 o = outv[am * NPASS + np];
+                    if (rowp[am] && kc0 + np * CS < p.K) {
+                        if constexpr (ADD) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) o.h[e] = (bf16_t)((float)o.h[e] + (float)addv[am * NPASS + np].h[e]);
+                        }
+                        if (!(dbg & 256)) *(i32x4*)(rowp[am] + np * CS) = o.i;
+                        else asm volatile("" ::"v"(o.i));          // timing ablation: the epilogue's arithmetic without its stores
+                    }
+                }
         }
 #pragma unroll
         for (int i = 0; i < G::NACC; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (dbg & 32) t_epi += __builtin_readcyclecounter() - t_b;
-        if (ALIGN && grp == 1 && j + 1 < my_tiles) __builtin_amdgcn_s_barrier();      // stagger again
+        if (HDY_DEEP_ALIGN && grp == 1 && j + 1 < my_tiles) __builtin_amdgcn_s_barrier();      // stagger again
     }
     if ((dbg & 32) && lane == 0 && (wave & 3) == 0 && blockIdx.x < 256) {
         unsigned long long* o = g_deep_dbg + blockIdx.x * 8 + (wave >> 2) * 4;
@@ -561,7 +596,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_deep_kernel(const ConvArgs p) {
         for (int i = 0; i < 6; ++i) g_deep_seg[blockIdx.x * 16 + (wave >> 2) * 8 + i] = seg[i];
         if (wave == 0) for (int i = 0; i < 8; ++i) g_deep_kt[blockIdx.x * 8 + i] = ktc[i];
     }
-    if (EPI == 0 && grp == 0) __builtin_amdgcn_s_barrier();       // re-align the two wave groups (EPI >= 1: level since the last tile's epilogue)
+    if (!HDY_DEEP_ALIGN && grp == 0) __builtin_amdgcn_s_barrier();       // re-align the two wave groups
 #undef DP_WAIT
 #undef DP_MFMA_PHASE
 #undef DP_READ_A
@@ -569,13 +604,9 @@ __global__ __launch_bounds__(NTHR, 2) void conv_deep_kernel(const ConvArgs p) {
 #undef DP_LGKM0_A
 
     if (STATS) {
-        // one slab row per workgroup position (mt0): lane-local sums -> 16 pixel lanes (shuffles) -> the wr waves that share the channels (LDS).
-        // No LDS-DMA is in flight here (the loader ran dry and its last units were waited for with vmcnt(0) inside the K loop), so the barriers below wait
-        // for LDS traffic only — raw barriers: `__syncthreads()` would also wait (vmcnt(0)) for the last tile's output stores, ~2.5 us of acknowledgement
-        // latency in front of a reduction that does not depend on them (scripts/probes/tile_boundary_fit.py: 9.2 us of launch + prologue + tail with the
-        // sums against 5.8 us without)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        // one slab row per workgroup position (mt0): lane-local sums -> 16 pixel lanes (shuffles) -> the wr waves that share the channels (LDS)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
         float* red = (float*)smem;                                // [WM][BN][2]; the ring is free
 #pragma unroll
         for (int n = 0; n < NTQ; ++n)
@@ -593,8 +624,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_deep_kernel(const ConvArgs p) {
                     red[(wr * BN + col) * 2 + 1] = q;
                 }
             }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        __syncthreads();
         for (int j = tid; j < 2 * BN; j += NTHR) {
             const int which = j / BN, c = j - which * BN;
             if (n0 + c < p.K) {
@@ -630,17 +660,25 @@ inline int deep_grid(long long M, int ntiles) {
     return (int)g;
 }
 
-template <int BN, bool STATS, int EPI>
-int deep_launch(const ConvArgs& a, int grid, hipStream_t st) {
+template <int BN, bool STATS, int EPI, bool ADD>
+int deep_launch_add(const ConvArgs& a, int grid, hipStream_t st) {
     constexpr size_t smem = deep_smem<BN>();
     static_assert(smem <= 160 * 1024, "LDS budget");
     static std::once_flag attr_once;
     std::call_once(attr_once, [&] {
-        (void)hipFuncSetAttribute((const void*)conv_deep_kernel<BN, STATS, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)conv_deep_kernel<BN, STATS, EPI, ADD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     });
-    hipLaunchKernelGGL((conv_deep_kernel<BN, STATS, EPI>), dim3(grid), dim3(NTHR), smem, st, a);
+    hipLaunchKernelGGL((conv_deep_kernel<BN, STATS, EPI, ADD>), dim3(grid), dim3(NTHR), smem, st, a);
     HDY_LAUNCH_CHECK("conv_deep");
     return HDY_OK;
+}
+
+template <int BN, bool STATS, int EPI>
+int deep_launch(const ConvArgs& a, int grid, hipStream_t st) {
+    if constexpr (!STATS) {
+        if (a.res || a.accumulate) return deep_launch_add<BN, STATS, EPI, true>(a, grid, st);
+    }
+    return deep_launch_add<BN, STATS, EPI, false>(a, grid, st);
 }
 
 template <int BN, bool STATS>
@@ -692,6 +730,7 @@ int hdy_conv_deep_slabs(long long M, int C, int K, int taps, int pointwise, int 
 int hdy_conv_deep_try(const ConvArgs& a_in, int dtype, int out_f32, hipStream_t st, int* rc) {
     const bool walk = a_in.ncls > 1;                               // the four-class stride-2 data gradient (validated by the caller)
     if (dtype != HDY_BF16 || out_f32 || a_in.nstat > 0 || (!a_in.dense_out && !walk) || a_in.span_pixels || !a_in.vec_out || !a_in.utap) return 0;
+    if ((a_in.res && a_in.accumulate) || (a_in.stats && (a_in.res || a_in.accumulate))) return 0;      // one added row source per launch, none beside statistics
     // measured at the yolov5s bench shapes (B = 64, scripts/probes/dgrad_walk.py): 105 / 80 / 62 / 48 us here against 94 / 86 / 59 / 51 us for
     // conv_igemm.hip's 128-row walk, and 12.37-12.45 against 12.30 ms in the train step.  Opt-in.
     // HDY_DEEP_WALK: 0 never, 1 always, 2 (default) where it measured faster: 256 or more gradient channels out (256<-512 @40x40 80.5 vs 85.9 us, 256<-256 47.5 vs 51.1)

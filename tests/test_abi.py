@@ -70,10 +70,63 @@ def test_options_and_dispatch_log_are_host_state(lib):
 
 
 def test_invalid_arguments_return_status_not_crash(lib):
-    rc = lib.hdy_conv_fwd(None, 8, None, None, None, None, 0, None, 8, None, 1, 4, 4, 8, 8, 1, 1, 1, 0, 0, 0, _lib.BF16, 0, 0, None)
+    rc = lib.hdy_conv_fwd(None, 8, None, None, None, None, 0, None, 8, None, 0, 1, 4, 4, 8, 8, 1, 1, 1, 0, 0, 0, _lib.BF16, 0, 0, None)
     assert rc < 0 and b'null' in lib.hdy_last_error()
     rc = lib.hdy_nms_batched(None, 1, 4, 7, 1, 0.1, 2.0, 10, 2.0, 0, None, None, None, None, None, None, None, None, 0, None)
     assert rc < 0
+
+
+FAKE = 0x10000      # a 16-byte aligned non-NULL "device pointer": the calls below must fail validation before anything dereferences or launches
+
+
+def _conv_fwd_with_stats(lib, slabs, N=64, H=20, W=20, C=128, K=256):
+    return lib.hdy_conv_fwd(FAKE, C, FAKE, None, None, None, 0, FAKE, K, FAKE, slabs, N, H, W, C, K, 1, 1, 1, 0, 0, 0, _lib.BF16, 0, 0, None)
+
+
+def test_statistic_slab_count_is_checked_against_the_kernel_about_to_run(lib):
+    """VERDICT r03 'ABI hole': hdy_conv_fwd took `float* stats` without a size and decided the slab count at launch from the process-wide
+    option table.  Now the caller passes the count it sized the array with; a switch flipped between hdy_conv_stat_slabs and the launch
+    gives HDY_EINVAL (no launch, no out-of-bounds slab) — checked here on the host, in both directions."""
+    shape = (64, 20, 20, 128, 256, 1, 1, 1, 0, _lib.BF16)
+    deep = lib.hdy_conv_stat_slabs(*shape)
+    with _lib.option('HDY_NO_DEEP', 1):
+        generic = lib.hdy_conv_stat_slabs(*shape)
+        assert (deep, generic) == (100, 200)
+        # sized for the deep-pipelined kernel, launched after the switch: the generic kernel would write 200 slabs into room for 100
+        rc = _conv_fwd_with_stats(lib, deep)
+        assert rc == _lib.EINVAL and b'holds 100 slabs' in lib.hdy_last_error() and b'writes 200' in lib.hdy_last_error()
+    # sized for the generic kernel, launched on the deep-pipelined one: 100 of the 200 slabs hdy_bn_finalize reads would be stale
+    rc = _conv_fwd_with_stats(lib, generic)
+    assert rc == _lib.EINVAL and b'holds 200 slabs' in lib.hdy_last_error() and b'writes 100' in lib.hdy_last_error()
+    # the filter-resident 3x3 kernel (one slab per workgroup) against its switch
+    s3 = (64, 80, 80, 64, 64, 3, 3, 1, 1, _lib.BF16)
+    own = lib.hdy_conv_stat_slabs(*s3)
+    with _lib.option('HDY_NO_CONV3X3', 1):
+        rc = lib.hdy_conv_fwd(FAKE, 64, FAKE, None, None, None, 0, FAKE, 64, FAKE, own, 64, 80, 80, 64, 64, 3, 3, 1, 1, 0, 0, _lib.BF16, 0, 0, None)
+        assert rc == _lib.EINVAL and b'slabs' in lib.hdy_last_error()
+    assert lib.hdy_conv_fwd(FAKE, 64, FAKE, None, None, None, 0, FAKE, 64, FAKE, 0, 64, 80, 80, 64, 64, 3, 3, 1, 1, 0, 0, _lib.BF16, 0, 0, None) == _lib.EINVAL
+
+
+def test_workspace_sizes_are_checked(lib):
+    """every workspace pointer of the ABI travels with its size: a buffer smaller than the matching *_workspace_* query is HDY_EINVAL"""
+    M, K = 64 * 20 * 20, 256
+    need = lib.hdy_bn_bwd_workspace_bytes(M, K)
+    assert need == (lib.hdy_bn_bwd_blocks(M) * 2 * K + 2 * K) * 4
+    rc = lib.hdy_bn_act_bwd(FAKE, K, FAKE, K, FAKE, FAKE, FAKE, FAKE, FAKE, K, FAKE, FAKE, 0, M, K, 1, _lib.BF16, FAKE, need - 4, None)
+    assert rc == _lib.EINVAL and b'workspace' in lib.hdy_last_error()
+    rc = lib.hdy_bn_act_bwd_pair(FAKE, 128, FAKE, 128, 128, FAKE, K, FAKE, FAKE, FAKE, FAKE, FAKE, K, FAKE, FAKE, FAKE, FAKE, 0, M, K, 1, _lib.BF16, FAKE, need - 4, None)
+    assert rc == _lib.EINVAL and b'workspace' in lib.hdy_last_error()
+    assert lib.hdy_colsum(FAKE, 40, M, 40, FAKE, 0, _lib.BF16, FAKE, lib.hdy_colsum_workspace_bytes(M, 40) - 4, None) == _lib.EINVAL
+    mt = 2000
+    fin = lib.hdy_bn_finalize_workspace_bytes(mt, K)
+    assert fin > 0
+    rc = lib.hdy_bn_finalize(FAKE, K, mt, K, M, FAKE, FAKE, FAKE, FAKE, 1e-3, 0.03, FAKE, FAKE, FAKE, FAKE, FAKE, fin - 8, None)
+    assert rc == _lib.EINVAL and b'workspace' in lib.hdy_last_error()
+    gn = lib.hdy_groupnorm_workspace_floats(2, 64)
+    assert lib.hdy_groupnorm_fwd(FAKE, 64, FAKE, FAKE, FAKE, 64, FAKE, FAKE, 2, 100, 64, 32, 1e-5, 1, _lib.BF16, FAKE, gn - 1, None) == _lib.EINVAL
+    sd = lib.hdy_softdice_workspace_floats(2, 3)
+    assert lib.hdy_softdice(FAKE, 4, FAKE, None, 2, 100, 3, FAKE, None, None, 4, FAKE, sd - 1, None) == _lib.EINVAL
+    assert lib.hdy_softdice_wgrad(FAKE, FAKE, None, 2, 10, 10, 3, 5, FAKE, FAKE, FAKE, sd - 1, None) == _lib.EINVAL
 
 
 def test_fastdiv_reciprocal_is_exact(lib):

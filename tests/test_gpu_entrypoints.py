@@ -63,6 +63,25 @@ def test_bench_py_spawns_its_own_ranks():
     assert line['config']['allreduce_calls_per_step'] >= 4, line['config']
 
 
+def test_bench_py_four_ranks_share_one_gpu_over_gloo():
+    """Rehearsal of the driver's `python bench.py --gpus N` beyond two ranks.  A one-GPU box allows six processes on its card,
+    so four ranks (+ the launcher, which never touches the GPU) are what fits: world size, the overlapped all-reduce calls and — the property the
+    scaling run depends on — identical parameters on every rank after three SUM-all-reduced steps.  The eight-rank case itself is the driver's to
+    start; tests/test_parallel_gloo.py runs the collective layer with eight CPU ranks."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    p = subprocess.run([sys.executable, 'bench.py', '--gpus', '4', '--steps', '3', '--warmup', '1', '--batch', '2', '--variant', 's', '--size', '128',
+                        '--no-roofline', '--no-cpu-baseline', '--no-infer'], cwd=ROOT, env=dict(env, YOLOv5_VERBOSE='false', OMP_NUM_THREADS='2'),
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][-1])
+    cfg = line['config']
+    assert line['n_gpus'] == 4 and cfg['world_size'] == 4 and cfg['global_batch'] == 8 and cfg['parallelism'] == 'dp4'
+    assert cfg['allreduce_calls_per_step'] >= 4, cfg
+    assert cfg['param_checksum_spread_over_ranks'] == 0.0, cfg
+    assert line['value'] > 0 and line['final_loss'] == line['final_loss']
+
+
 def test_train_py_cfg_hyp_freeze_masks_save_period(tmp_path):
     import yaml
     sys.path.insert(0, ROOT)

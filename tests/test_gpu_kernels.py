@@ -186,38 +186,23 @@ DEEP_CASES = [
     (1, 20, 20, 64, 136, 3, 1, 1),       # K not a multiple of 16: ragged last column tile
     (8, 96, 96, 64, 128, 1, 1, 0),       # 288 row tiles on 256 workgroups: some walk two tiles, one K-tile each
     (5, 96, 96, 64, 128, 3, 1, 1),       # 180 row tiles, nine K-tiles each
-    # the patch-resident 3x3 kernel of the wide layers (conv3x3_wide.hip: C % 64 == 0, C >= 128) beyond the three 3x3 rows above
-    (1, 64, 64, 128, 128, 3, 1, 1),      # 8 x 32 blocks, two across
-    (1, 32, 80, 128, 128, 3, 1, 1),      # 16 x 16 blocks (fewer tiles than 8 x 32), ragged right edge
-    (2, 37, 70, 192, 136, 3, 1, 1),      # blocks ragged on both edges, three channel blocks, K not a multiple of 16
-    (8, 96, 96, 128, 128, 3, 1, 1),      # 288 blocks on 256 workgroups: some walk two tiles (the patch stream crosses tiles)
-    (70, 20, 20, 128, 256, 3, 1, 1),     # flattened 256-pixel tiles: two per image (the second 144 pixels), two column tiles, 280 tiles
+    (2, 37, 70, 192, 136, 3, 1, 1),      # three channel blocks per tap, K not a multiple of 16, ragged last row tile
+    (70, 20, 20, 128, 256, 3, 1, 1),     # 110 row tiles of 18 K-tiles, two 128-wide column tiles: 220 tiles, every workgroup's stream crosses none / one boundary
 ]
 
 
-def deep_family(C, K, R, stride, pad):
-    """kernel family that takes a bf16 conv with C input / K output channels among the two deep-pipelined kernels"""
-    if R == 3 and stride == 1 and pad == 1 and C % 64 == 0 and C >= 128 and K >= 128:
-        return 'wide3x3_256x128'
-    return 'deep_256x'
-
-
-@pytest.mark.parametrize('bn', [0, 128, 256, 'wide'])
+@pytest.mark.parametrize('bn', [0, 128, 256])
 @pytest.mark.parametrize('case', DEEP_CASES)
 def test_deep_pipelined_conv(case, bn):
     """conv_deep.hip (256-row tiles, loads in flight across barriers) on shapes the plan would give to the generic kernel at test size:
     HDY_DEEP_MIN_TILES = 1 sends them to it; both column tiles (HDY_DEEP_BN); forward with BatchNorm sums, epilogue with scale / shift /
     SiLU / accumulate, stride-1 data gradient with accumulate — against torch fp32 on the CPU, and the dispatch log must name the kernel"""
     N, H, W, C, K, R, stride, pad = case
-    wide = 1 if bn == 'wide' else 0                              # the opt-in patch-resident 3x3 kernel (conv3x3_wide.hip) takes the 3x3 rows with C >= 128
-    bn = 0 if bn == 'wide' else bn
-    with _lib.option('HDY_DEEP_MIN_TILES', 1), _lib.option('HDY_DEEP_BN', bn), _lib.option('HDY_DEEP_ALL', 1), _lib.option('HDY_DEEP_WALK', 1), \
-            _lib.option('HDY_WIDE3', wide):
+    with _lib.option('HDY_DEEP_MIN_TILES', 1), _lib.option('HDY_DEEP_BN', bn), _lib.option('HDY_DEEP_ALL', 1), _lib.option('HDY_DEEP_WALK', 1):
         log_fwd, log_dgrad, _ = conv_case(case, torch.bfloat16)
-    fam = deep_family(C, K, R, stride, pad) if wide else 'deep_256x'
-    assert log_fwd == [fam if fam.startswith('wide') else 'deep_256x128'], log_fwd                  # statistics: 128-wide instances
+    assert log_fwd == ['deep_256x128'], log_fwd                  # statistics: 128-wide instances
     if stride == 1 and K % 64 == 0 and C >= 128:
-        assert log_dgrad and log_dgrad[0].startswith(deep_family(K, C, R, stride, pad) if wide else 'deep_256x'), log_dgrad
+        assert log_dgrad and log_dgrad[0].startswith('deep_256x'), log_dgrad
     if stride == 2 and K % 64 == 0 and C >= 128:
         assert log_dgrad and log_dgrad[0].startswith('deep_256x') and log_dgrad[0].endswith('_walk'), log_dgrad
         with _lib.option('HDY_DEEP_MIN_TILES', 1):                 # default (HDY_DEEP_WALK = 2): the deep pipeline from 256 gradient channels out, else the generic kernel's walk
@@ -233,11 +218,10 @@ def test_deep_pipelined_conv(case, bn):
     outs = []
     for off in (0, 1):
         y = torch.zeros((N, Ho, Wo, K), dtype=torch.bfloat16, device=DEV)
-        with _lib.option('HDY_DEEP_MIN_TILES', 1), _lib.option('HDY_DEEP_BN', bn), _lib.option('HDY_DEEP_ALL', 1), _lib.option('HDY_NO_DEEP', off), \
-                _lib.option('HDY_WIDE3', wide if off == 0 else 0):
+        with _lib.option('HDY_DEEP_MIN_TILES', 1), _lib.option('HDY_DEEP_BN', bn), _lib.option('HDY_DEEP_ALL', 1), _lib.option('HDY_NO_DEEP', off):
             _lib.dispatch_log(reset=True)
             ops.run([ops.rec_pack(w, None, stride, pad, ops.PACK_FWD, wp), ops.rec_conv_fwd(xd, wp, y, K, R, R, stride, pad)])
-            assert any(n.startswith(('deep_', 'wide3x3')) for n in _lib.dispatch_log()) == (off == 0)
+            assert any(n.startswith('deep_') for n in _lib.dispatch_log()) == (off == 0)
         outs.append(y.float())
     d = (outs[0] - outs[1]).abs().max().item()
     assert d <= 2.0 ** -7 * outs[1].abs().max().item(), f'deep vs generic kernel differ by {d}'
@@ -650,21 +634,6 @@ def test_fused_1x1_backward_matches_reference_and_the_three_launch_path(K, M, pa
     assert dx_f._base[..., :8].float().eq(7.0).all()
 
 
-def test_patch_resident_wgrad_stride2_variant():
-    """conv_wgrad3x3.hip also has a stride-2 path that is off by default (measured load bound): the bf16 stride-2 cases of
-    test_conv_fwd_dgrad_wgrad re-run in a child process with HDY_WGRAD3X3_S2=1 keep it correct."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, HDY_WGRAD3X3_S2='1', HDY_WGRAD3X3_CHILD='1')
-    if os.environ.get('HDY_WGRAD3X3_CHILD'):
-        return
-    p = subprocess.run([sys.executable, '-m', 'pytest', 'tests/test_gpu_kernels.py', '-q', '-x', '-k', 'test_conv_fwd_dgrad_wgrad and dtype1'], cwd=root, env=env,
-                       capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0, p.stdout[-3000:]
-    assert ' passed' in p.stdout
-
-
 @pytest.mark.parametrize('case', [(2, 24, 20, 64, 32, 1, 1, 0, False), (3, 16, 16, 32, 64, 3, 1, 1, True), (2, 16, 24, 64, 128, 3, 2, 1, False),
                                   (2, 40, 40, 64, 128, 3, 1, 1, False), (5, 128, 128, 32, 64, 3, 2, 1, True)])
 def test_dgrad_serves_batchnorm_backward_statistics(case):
@@ -880,11 +849,9 @@ def test_specialised_kernel_agrees_with_generic_beyond_one_grid(case):
 
 WGRAD_DEEP_CASES = [
     # N, H, W, C, K, R, stride, pad — shapes of the deep-pipelined weight gradient (C % 64 == 0, K % 128 == 0, K >= 256, >= 8192 output pixels)
-    (8, 40, 40, 256, 256, 1, 1, 0),      # one 256 x 256 tile, 50 pixel splits
     (4, 96, 96, 128, 256, 3, 2, 1),      # 3x3 / stride 2: Q = 1152 = 4.5 column tiles, taps that leave the image
     (4, 96, 96, 64, 256, 3, 2, 1),       # C = 64: one tap per 64-column sub-tile, Q = 576
-    (8, 32, 32, 128, 384, 1, 1, 0),      # K = 1.5 row tiles, Q = 128: half a column tile
-    (3, 53, 53, 64, 256, 1, 1, 0),       # pixel count not a multiple of 64: the last stage of the last split is ragged
+    (12, 53, 53, 64, 384, 3, 2, 1),      # K = 1.5 row tiles; 27 x 27 output pixels per image (8748 in all): the last stage of the last split is ragged
     (2, 72, 72, 64, 256, 5, 1, 2),       # 25 taps (Q = 1600), stride 1 (3x3 / stride 1 belongs to the patch-resident kernel)
 ]
 
@@ -896,8 +863,7 @@ def test_deep_pipelined_weight_gradient(case):
     the same operands (same products, different summation order: 1e-3 of the gradient's scale)."""
     N, H, W, C, K, R, stride, pad = case
     dt = torch.bfloat16
-    with _lib.option('HDY_WGRAD_DEEP_1X1', 1):
-        _, _, log_w = conv_case(case, dt)
+    _, _, log_w = conv_case(case, dt)
     assert 'wgrad_deep' in log_w, log_w
     x = q(rnd((N, C, H, W), 21), dt)
     Ho, Wo = ops.out_dim(H, R, stride, pad), ops.out_dim(W, R, stride, pad)
@@ -905,7 +871,7 @@ def test_deep_pipelined_weight_gradient(case):
     xd, dyd = to_dev_nhwc(x, dt), to_dev_nhwc(dy, dt)
     res = []
     for off in (0, 1):
-        with _lib.option('HDY_NO_WGRAD_DEEP', off), _lib.option('HDY_WGRAD_DEEP_1X1', 1):
+        with _lib.option('HDY_NO_WGRAD_DEEP', off):
             ws = torch.empty(ops.wgrad_ws_bytes(N, H, W, C, K, R, R, stride, pad, dt) // 4 + 1, dtype=torch.float32, device=DEV)
             g = torch.zeros((K, C, R, R), dtype=torch.float32, device=DEV)
             _lib.dispatch_log(reset=True)

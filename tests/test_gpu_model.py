@@ -644,39 +644,6 @@ def test_class_counts_other_than_the_fixtures_match_oracle(nc, fused, monkeypatc
         assert relmax(params[k].grad, sd[k].grad) < 2e-3, k
 
 
-def test_batched_split_reduction_is_bit_identical():
-    """HDY_BATCH_REDUCE: the ~60 per-layer split reductions of the weight gradients replayed as one hdy_wgrad_reduce_batch launch per gradient
-    bucket (descriptors recorded by the first, tee'd backward pass) — same additions in the same order, so every gradient must be bit-identical
-    to the per-layer launches, on the recording step and on the replaying ones."""
-    from hd_yolo_amd import plan as planmod
-    nc = 8
-
-    def grads(batched):
-        saved = planmod.BATCH_REDUCE
-        planmod.BATCH_REDUCE = batched
-        try:
-            model = build('s', nc).train().half()
-            x = synth.synth_images(4, 128, seed=11).to(DEV)
-            out = []
-            for step in range(3):
-                for p in model.parameters():
-                    p.grad = None
-                losses, _ = model(x, synth.synth_targets(4, 128, nc, nmin=5, nmax=20, seed=5))
-                losses['det']['det_loss'].backward()
-                torch.cuda.synchronize()
-                out.append(torch.cat([p.grad.flatten() for p in model.parameters()]).clone())
-            plan = next(iter(model._eng().plans.values()))
-            return out, plan
-        finally:
-            planmod.BATCH_REDUCE = saved
-
-    ref, _ = grads(False)
-    got, plan = grads(True)
-    assert len(plan.reduce_groups) >= 1 and sum(g.n for g in plan.reduce_groups) >= 60 and all(g.ready for g in plan.reduce_groups)
-    for a, b in zip(ref, got):
-        assert torch.equal(a, b)
-
-
 def test_multi_scale_sizes_reuse_their_cached_plans():
     """train.py --multi-scale (reference train.py:447-452): the tile size changes between steps; every size gets ONE static plan that is found
     again when the size comes back (no re-trace, same device buffers), and the losses of a size do not depend on which sizes ran in between."""

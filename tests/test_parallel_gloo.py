@@ -1,4 +1,4 @@
-"""Data-parallel plumbing on CPU: two processes over gloo (the N > 1 path of bench.py / train.py without a GPU).
+"""Data-parallel plumbing on CPU: two and eight processes over gloo (the N > 1 path of bench.py / train.py without a GPU).
 
 Checks the properties the 8-GPU run relies on: rank 0's state is what every rank starts from; the flat-gradient
 all-reduce is a SUM (no division: DDP's mean of the WORLD_SIZE-prescaled loss) and is identical on all
@@ -41,7 +41,7 @@ def _worker(rank, world, port, q):
 
         # per-rank shard of a global batch; loss = sum over images (like DetLoss * bs)
         g = torch.Generator().manual_seed(7)
-        x_all = torch.randn((4, 3, 8, 8), generator=g)
+        x_all = torch.randn((2 * world, 3, 8, 8), generator=g)
         net.eval()                                          # BN statistics are per rank in training; keep the check linear
         shard = x_all[rank * 2:(rank + 1) * 2]
         net.zero_grad()
@@ -81,15 +81,17 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(120)
-def test_two_rank_broadcast_and_sum_allreduce():
-    world, port = 2, _free_port()
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize('world', [2, 8])
+def test_broadcast_and_sum_allreduce(world):
+    """world 8 = the rank count of the SCALE run (one node of eight MI355X): same plumbing, gloo instead of RCCL, CPU tensors"""
+    port = _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    out = [q.get(timeout=100) for _ in range(world)]
+    out = [q.get(timeout=240) for _ in range(world)]
     for p in procs:
         p.join(30)
         assert p.exitcode == 0
@@ -101,7 +103,8 @@ def test_two_rank_broadcast_and_sum_allreduce():
             torch.testing.assert_close(r, ref, rtol=1e-5, atol=1e-6)       # SUM of shards == full-batch gradient
             assert torch.equal(r, results[0])                              # independent of bucket count
         assert torch.equal(tail, torch.zeros_like(tail))
-    assert torch.equal(out[0][2][0], out[1][2][0]), 'ranks disagree after the all-reduce'
+    for k in range(len(out[0][2])):
+        assert all(torch.equal(out[0][2][k], o[2][k]) for o in out[1:]), 'ranks disagree after the all-reduce'
 
 
 def test_bucket_bounds_cover_exactly():
