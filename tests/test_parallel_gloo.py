@@ -101,7 +101,10 @@ def test_broadcast_and_sum_allreduce(world):
         assert same_start, 'ranks did not start from rank 0 state'
         for r in results:
             torch.testing.assert_close(r, ref, rtol=1e-5, atol=1e-6)       # SUM of shards == full-batch gradient
-            assert torch.equal(r, results[0])                              # independent of bucket count
+            if world == 2:
+                assert torch.equal(r, results[0])                          # a + b: bit-identical whatever the bucket count
+            else:                                                          # eight addends: the ring's summation order moves with the chunking
+                torch.testing.assert_close(r, results[0], rtol=1e-6, atol=1e-6)
         assert torch.equal(tail, torch.zeros_like(tail))
     for k in range(len(out[0][2])):
         assert all(torch.equal(out[0][2][k], o[2][k]) for o in out[1:]), 'ranks disagree after the all-reduce'
