@@ -160,8 +160,7 @@ def infer_benchmark(variant='l', B=128, S=1024, iters=3, device=None, nc=8, surv
         preds = head.decode_all(dets)
         # Random-init logits leave next to nothing above the reference's default confidence (0.15): the NMS would be timed on empty tiles.  Histology tiles
         # hold 10^3 - 10^4 nuclei, so the threshold is set where tile 0 keeps ~1024 candidates: the filter, sort and greedy pass all have work.
-        obj = preds[0, :, 4].float()
-        conf_used = float(torch.kthvalue(obj, max(obj.numel() - survivors, 1)).values)
+        conf_used = synth.dense_conf_thres(preds[0], survivors)
         head.nms_params = dict(head.nms_params, conf_thres=conf_used)
         ms_all = timed(lambda: m(x), iters)                                  # end to end at that threshold
         ms_out = timed(lambda: head.compute_outputs(preds), iters)
@@ -172,7 +171,7 @@ def infer_benchmark(variant='l', B=128, S=1024, iters=3, device=None, nc=8, surv
         assert all(bool(torch.isfinite(o['boxes']).all()) for o in outs), 'inference benchmark: non-finite boxes'
         p = head.nms_params
         ms_nms = timed(lambda: ops.nms_batched(preds, head.nc, p['conf_thres'], p['iou_thres'], int(p['max_det'])), iters)
-        n_surv = int((preds[:, :, 4] > conf_used).sum()) / B
+        n_surv = int(((preds[:, :, 4] > conf_used) & (preds[:, :, 2] >= 2) & (preds[:, :, 3] >= 2)).sum()) / B
     ncand = preds.shape[1]
     dec_bytes = B * ncand * (head.no + head.no + 1) * 4        # logits read + rows written (108 B per candidate at nc = 8)
     gf = {'n': 4.13, 's': 15.81, 'm': 47.94, 'l': 107.76}[variant[0]] * (S / 640) ** 2

@@ -191,6 +191,17 @@ def calibrate_det_logits(model, x, tag='det'):
     return stds
 
 
+def dense_conf_thres(preds_tile, survivors=1024):
+    """confidence threshold at which one tile's decoded predictions (N, 5 + nc + 1) keep ~`survivors` candidates that also pass the 2-pixel size filter of
+    nms_per_image (utils_general.py:332): the NMS load of a dense histology tile (10^3 - 10^4 nuclei) on a random-init network"""
+    import torch
+    ok = (preds_tile[:, 2] >= 2) & (preds_tile[:, 3] >= 2)
+    obj = preds_tile[ok, 4].float()
+    if obj.numel() <= survivors:
+        return float(obj.min()) * 0.5 if obj.numel() else 0.0
+    return float(torch.kthvalue(obj, obj.numel() - survivors).values)
+
+
 def mask_state_dict(module, seed=0):
     """synth_state_dict with the detection convs damped, so that matched cells predict (almost) their anchor box: IoU >= 0.8 with the
     anchor-shaped truths of synth_mask_targets — otherwise nothing would reach the mask head."""

@@ -12,9 +12,12 @@ model.load_state_dict(synth.synth_state_dict(synth.shapes_of(model), seed=0), st
 model = model.to(DEV).eval().half()
 x = synth.synth_images(B, 1024, seed=0).to(DEV)
 head = model.headers['det']
+if os.environ.get('CAL', '1') == '1':
+    print('calibration factors', synth.calibrate_det_logits(model, x[:2].contiguous()))
 with torch.no_grad():
     _, outs = model(x)
-    plan = next(iter(model._eng().plans.values()))
+    plan = [pl for pl in model._eng().plans.values() if pl.det_views()[0].shape[0] == B][-1]
+    print('plans', [tuple(pl.det_views()[0].shape) for pl in model._eng().plans.values()])
     for i, d in enumerate(plan.det_views()):
         print('level', i, tuple(d.shape), d.dtype, 'finite', bool(torch.isfinite(d).all()), 'min/max', float(d.min()), float(d.max()), 'obj logit mean', float(d[..., 4].mean()))
     preds = head.decode_all(plan.det_views())
