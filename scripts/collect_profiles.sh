@@ -1,9 +1,9 @@
 #!/bin/bash
 # Collect the round's rocprofv3 summaries on a GPU box (run through gpurun from the repo root):
-#   gpurun --timeout 1100 -- 'bash scripts/collect_profiles.sh r03'
+#   gpurun --timeout 1100 -- 'bash scripts/collect_profiles.sh r04'
 # Each counter set is its own run; programs are started directly after `--` (no shell hop between rocprofv3 and python).
 set -o pipefail
-R=${1:-r03}
+R=${1:-r04}
 OUT=gpurun_out/prof_$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
