@@ -20,6 +20,8 @@
 // Reference semantics replaced: nn.BatchNorm2d (eps 1e-3, momentum 0.03: metayolo/models/utils_torch.py:47-49)
 // and nn.SiLU inside Conv.forward (metayolo/models/layers.py:37-38), the Bottleneck residual add (:97),
 // and their autograd backward.
+#include <type_traits>
+
 #include "common.h"
 #include "hdyolo.h"
 
@@ -314,6 +316,88 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restr
     }
 }
 
+// The same pass with FOUR channels per lane (bf16: 8-byte loads) — round 4.  The kernel above needs 120 VGPRs (8 channels x 4 coefficients, 16 sums, 8 rows
+// in flight) and shares the chip with the weight-gradient stream: beside wgrad_kernel<2, 2> (2 waves x 152 registers per SIMD) ONE such wave fits per SIMD,
+// beside wgrad3x3_kernel (3 x 144) and wgrad_deep_kernel (2 x 209) none — in the step the pass runs at 1.9 TB/s where it reaches 3.2-5 alone
+// (profiles/r04_step_kernel_stats.txt: 2.57 ms for 4.95 GB).  Half the channels per lane is half the coefficients and sums: ~60 registers, three waves per SIMD
+// beside the generic weight gradient, one beside the 3x3 one.  Same slab layout, same finalize.
+template <int MODE, int VE, int U>
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce4_kernel(const bf16_t* __restrict__ dz, int lddz, const bf16_t* __restrict__ dz_b, int lddz_b, int Ka,
+                                                                 const bf16_t* __restrict__ y, int ldy,
+                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                 int M, int K, int rows_per_block, float* __restrict__ partial) {
+    static_assert(VE == 4 || VE == 2, "channels per lane");
+    typedef int ivec __attribute__((ext_vector_type(VE / 2)));       // VE bf16 values
+    __shared__ float red[256 * VE];
+    const int VCt = K / VE;
+    const Lane L = lane_map(VCt, blockIdx.y);
+    const int VC = min(256, VCt - blockIdx.y * 256);
+    const int c = L.vc * VE;
+    float a1[VE], a2[VE], sc[VE], sh[VE], is[VE], nm[VE];          // xhat = y * invstd + (-mean * invstd)
+#pragma unroll
+    for (int i = 0; i < VE; ++i) {
+        a1[i] = 0.f; a2[i] = 0.f;
+        sc[i] = L.live ? scale[c + i] : 1.f;
+        sh[i] = L.live ? shift[c + i] : 0.f;
+        is[i] = L.live ? invstd[c + i] : 0.f;
+        nm[i] = L.live ? -mean[c + i] * is[i] : 0.f;
+    }
+    const int mbeg = blockIdx.x * rows_per_block;
+    const int mend = min(mbeg + rows_per_block, M);
+    const bf16_t* const dzc = c < Ka ? dz + c : dz_b + (c - Ka);
+    const int lddzc = c < Ka ? lddz : lddz_b;
+    if (L.live) {
+        auto accumulate = [&](const ivec& gq, const ivec& vq) {
+#pragma unroll
+            for (int h = 0; h < VE / 2; ++h) {
+                int gw, vw;
+                gw = gq[h]; vw = vq[h];
+                const float g[2] = {__uint_as_float((unsigned)gw << 16), __uint_as_float((unsigned)gw & 0xFFFF0000u)};
+                const float v[2] = {__uint_as_float((unsigned)vw << 16), __uint_as_float((unsigned)vw & 0xFFFF0000u)};
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int i = 2 * h + e;
+                    float du = g[e];
+                    if (MODE == 2) du *= dsilu_f(v[e] * sc[i] + sh[i]);
+                    a1[i] += du;
+                    a2[i] += du * (v[e] * is[i] + nm[i]);
+                }
+            }
+        };
+        int m = mbeg + L.rl;
+        for (; m + (U - 1) * L.RL < mend; m += U * L.RL) {
+            ivec gq[U], vq[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                gq[u] = *(const ivec*)(dzc + (size_t)(m + u * L.RL) * lddzc);
+                vq[u] = *(const ivec*)(y + (size_t)(m + u * L.RL) * ldy + c);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) accumulate(gq[u], vq[u]);
+        }
+        for (; m < mend; m += L.RL) {
+            const ivec gq = *(const ivec*)(dzc + (size_t)m * lddzc);
+            const ivec vq = *(const ivec*)(y + (size_t)m * ldy + c);
+            accumulate(gq, vq);
+        }
+    }
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        if (L.live) {
+#pragma unroll
+            for (int i = 0; i < VE; ++i) red[(L.rl * VC + (L.vc - blockIdx.y * 256)) * VE + i] = which ? a2[i] : a1[i];
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < VC * VE; j += 256) {
+            float s = 0.f;
+            for (int r = 0; r < L.RL; ++r) s += red[r * VC * VE + j];
+            partial[((size_t)blockIdx.x * 2 + which) * K + blockIdx.y * 256 * VE + j] = s;
+        }
+        __syncthreads();
+    }
+}
+
 // dbeta/dgamma (+)=, c1 = dbeta/M, c2 = dgamma/M
 // (Measured and not adopted: dropping this launch by letting the reduce pass add its sums into fp64 accumulators with
 // global_atomic_add_f64 and deriving c1 / c2 in the apply pass — up to 1024 device-scope atomics per address cost ~100 us per
@@ -456,6 +540,22 @@ struct Split {
 template <typename T>
 void bn_bwd_reduce_launch(dim3 grid, hipStream_t st, const Split& dz, const void* y, int ldy, const float* scale, const float* shift,
                           const float* mean, const float* invstd, int M, int K, int act, int rows, float* partial) {
+    if constexpr (std::is_same<T, bf16_t>::value) {
+        // four channels per lane (see bn_act_bwd_reduce4_kernel): every BatchNorm of the path (K % 8 == 0, 8-element pitches); HDY_NO_BN_REDUCE4 keeps the
+        // eight-channel form (A/B)
+        if (y && !hdy_opt(HDY_OPT_NO_BN_REDUCE4) && dz.Ka % 4 == 0) {
+            const dim3 g4(grid.x, cdiv(K / 4, 256));
+            // rows in flight per lane: 4 (72 VGPRs) — 3 (60) and 2 (54) fit one more wave per SIMD beside the generic weight gradient and measured the same /
+            // 0.1 ms slower in the step (11.94-11.96 | 11.92-11.99 | 12.06-12.08 ms; 8 channels per lane: 12.19-12.24)
+            if (act == 1)
+                hipLaunchKernelGGL((bn_act_bwd_reduce4_kernel<2, 4, 4>), g4, dim3(256), 0, st, (const bf16_t*)dz.a, dz.lda, (const bf16_t*)dz.b, dz.ldb, dz.Ka,
+                                   (const bf16_t*)y, ldy, scale, shift, mean, invstd, M, K, rows, partial);
+            else
+                hipLaunchKernelGGL((bn_act_bwd_reduce4_kernel<1, 4, 4>), g4, dim3(256), 0, st, (const bf16_t*)dz.a, dz.lda, (const bf16_t*)dz.b, dz.ldb, dz.Ka,
+                                   (const bf16_t*)y, ldy, scale, shift, mean, invstd, M, K, rows, partial);
+            return;
+        }
+    }
     if (act == 1)
         hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, 2>), grid, dim3(256), 0, st, (const T*)dz.a, dz.lda, (const T*)dz.b, dz.ldb, dz.Ka, (const T*)y, ldy,
                            scale, shift, mean, invstd, M, K, act, rows, partial);

@@ -39,6 +39,7 @@ enum HdyOption {
     HDY_OPT_DEEP_ALL,          // HDY_DEEP_ALL: 1 (default) the deep-pipelined kernel takes multi-tap (3x3) layers too, 0 the 1x1 layers only
     HDY_OPT_DEEP_MIN_TILES,    // HDY_DEEP_MIN_TILES: fewest 256-row tiles the deep-pipelined kernel takes a layer with (default 160)
     HDY_OPT_DEEP_WALK,         // HDY_DEEP_WALK: stride-2 data gradients (four-class walk) on the deep pipeline: 0 never, 1 always, 2 (default) with >= 256 output channels
+    HDY_OPT_NO_BN_REDUCE4,     // HDY_NO_BN_REDUCE4: BatchNorm-backward statistics pass with 8 channels per lane (the generic form, 120 VGPRs) instead of 4 (72)
     HDY_OPT_COUNT
 };
 int hdy_opt(int id);
