@@ -229,7 +229,11 @@ __global__ __launch_bounds__(NTHR, C == 32 ? 3 : 2) void conv3x3_c64_kernel(cons
     const long long st_step = (long long)2 * p.Wo * p.ldy;
     const long long rs_off = ((long long)(st_rr >> 4) * p.Wo + (st_rr & 15)) * p.ldr + st_ch * 8;
     const long long rs_step = (long long)2 * p.Wo * p.ldr;
-    const int ep_off = fr * 128 + (((wave * 4 + fq) ^ (fr & 14)) << 3);
+    // staging write: 8-byte slot (wave * 4 + fq) of pixel row fr, keyed by the row.  A ds_write_b64 is served in groups of 16 CONSECUTIVE lanes over 32 banks
+    // (MI355X_MICROARCH.md, LDS table) — the 16 rows fr of one slot — so the key must take 16 rows to 16 slots: fr & 15 (rounds 1-3 used fr & 14: rows r and
+    // r ^ 1 on one slot, every staging write 2-way conflicted, the 9 % LDS conflict cycles of profiles/r0[1-3]_conv3x3_counters.json).  An odd key swaps the
+    // halves of a 16-byte chunk; the reader (whose rows all have the parity of st_rr) swaps them back in registers.
+    const int ep_off = fr * 128 + (((wave * 4 + fq) ^ (fr & 15)) << 3);
 
     // ---- one item of AR rows (every wave covers all rows for its 16 channels)
     auto compute = [&](auto ar_c, const Item& it, int cur) {
@@ -311,6 +315,7 @@ __global__ __launch_bounds__(NTHR, C == 32 ? 3 : 2) void conv3x3_c64_kernel(cons
             for (int j = 0; j < AR / 2; ++j) {             // 32 pixel rows of 128 bytes per pass
                 V16 v;
                 v.i = *(const i32x4*)(sS + st_lds + j * 32 * 128);
+                if (st_rr & 1) v.i = i32x4{v.i[2], v.i[3], v.i[0], v.i[1]};
                 if (p.res || p.accumulate) {
                     float f[8];
 #pragma unroll

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(NTHR, 3) void conv3x3s2_c32_kernel(const ConvArgs p
     const long long st_step = (long long)2 * p.Wo * p.ldy;
     const long long rs_off = ((long long)(st_rr >> 4) * p.Wo + (st_rr & 15)) * p.ldr + st_ch * 8;
     const long long rs_step = (long long)2 * p.Wo * p.ldr;
-    const int ep_off = fr * 128 + (((wave * 4 + fq) ^ (fr & 14)) << 3);
+    const int ep_off = fr * 128 + (((wave * 4 + fq) ^ (fr & 15)) << 3);      // key fr & 15: 16 rows -> 16 slots (see conv3x3.hip); odd rows swap a chunk's halves
 
     auto compute = [&](int t, int cur) {
         f32x4 acc[TH];
@@ -171,6 +171,7 @@ __global__ __launch_bounds__(NTHR, 3) void conv3x3s2_c32_kernel(const ConvArgs p
             for (int j = 0; j < TH / 2; ++j) {             // 32 pixel rows of 128 bytes per pass
                 V16 v;
                 v.i = *(const i32x4*)(sS + st_lds + j * 32 * 128);
+                if (st_rr & 1) v.i = i32x4{v.i[2], v.i[3], v.i[0], v.i[1]};
                 if (p.res || p.accumulate) {
                     float g[8];
 #pragma unroll

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(NTHR, 2) void dgrad3x3s2_k64c32_kernel(const ConvAr
                 const int R = (2 * (wp * 4 + a) + ca) * 16 + fr;
                 const int slot = cb * 8 + wc * 4 + fq;
                 bf16x4 o = {(bf16_t)acc[c][a][0], (bf16_t)acc[c][a][1], (bf16_t)acc[c][a][2], (bf16_t)acc[c][a][3]};
-                *(bf16x4*)(sS + R * 128 + ((slot ^ (fr & 14)) << 3)) = o;
+                *(bf16x4*)(sS + R * 128 + ((slot ^ (fr & 15)) << 3)) = o;        // key fr & 15: 16 rows -> 16 slots (see conv3x3.hip); odd rows swap a chunk's halves
             }
         __syncthreads();                                   // staging complete; every wave is done with patch `cur`
         {
@@ -153,6 +153,7 @@ __global__ __launch_bounds__(NTHR, 2) void dgrad3x3s2_k64c32_kernel(const ConvAr
             for (int j = 0; j < 8; ++j) {
                 V16 v;
                 v.i = *(const i32x4*)(sS + st_lds + j * 32 * 128);
+                if (st_rr & 1) v.i = i32x4{v.i[2], v.i[3], v.i[0], v.i[1]};
                 if (p.accumulate) {
                     V16 u;
                     u.i = *(const i32x4*)(yb + j * st_step);
