@@ -404,14 +404,16 @@ __global__ __launch_bounds__(2 * BM, (BM == 256 || BN == 128 || STAT) ? 2 : (BN 
         }
         OT* __restrict__ y = (OT*)p.y;
         if (VEC_OUT && p.vec_out) {
-            // stage RPP rows of the bf16 tile at a time in the A part of the finished stage; 8-byte slots XORed with (row & 14) keep
-            // the 16 pixel lanes of a write on different slots; then full rows leave with 16-byte stores
+            // stage RPP rows of the bf16 tile at a time in the A part of the finished stage; 8-byte slots XORed with a row key keep the 16 pixel lanes of a
+            // write on different slots (a ds_write_b64 is banked over 16 consecutive lanes and 32 banks: the key takes all 16 rows apart — row & 15, or
+            // (row >> 1) & 7 for 64-byte rows whose parity already picks the bank half; rounds 1-3 keyed with row & 14: 2-way conflicts, see conv3x3.hip);
+            // then full rows leave with 16-byte stores (an odd key swaps the halves of a chunk: swapped back in registers)
             constexpr int ROWB = BN * 2;                  // bytes per staged row
             constexpr int CPR = ROWB / 16;                // 16-byte chunks per row
             constexpr int RPI = NTHR / CPR;               // rows per store instruction of the workgroup
             constexpr int RPP = ASZ / ROWB >= 128 ? 128 : ASZ / ROWB;      // rows per pass
             static_assert(RPP % 64 == 0 && BM % RPP == 0, "epilogue passes must be whole wave row groups");
-            constexpr int SWM = (2 * CPR - 1) & 14;       // slot swizzle mask (even bits only: 16-byte pairs stay together)
+            auto skey = [](int row) { return BN == 32 ? ((row >> 1) & 7) : (row & 15); };
 #pragma unroll
             for (int pass = 0; pass < BM / RPP; ++pass) {
                 if ((wm * 64) / RPP == pass) {
@@ -441,7 +443,7 @@ __global__ __launch_bounds__(2 * BM, (BM == 256 || BN == 128 || STAT) ? 2 : (BN 
                                     else if (ACT == 2) v[r] = fmaxf(v[r], 0.0f);
                                 }
                                 bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-                                *(bf16x4*)(scratch + row * ROWB + ((slot ^ (row & SWM)) << 3)) = o;
+                                *(bf16x4*)(scratch + row * ROWB + ((slot ^ skey(row)) << 3)) = o;
                             }
                         }
                     };
@@ -493,9 +495,10 @@ __global__ __launch_bounds__(2 * BM, (BM == 256 || BN == 128 || STAT) ? 2 : (BN 
                         if constexpr (STAT) {
                             if (st_y && row + RPI < RPP && m + RPI < p.M) ynext = *(const i32x4*)(st_y + pixel(m + RPI) * st_ldy);
                         }
-                        const int chunk = ch ^ ((row & SWM) >> 1);
+                        const int key = skey(row), chunk = ch ^ (key >> 1);
                         V16 v;
                         v.i = *(const i32x4*)(scratch + row * ROWB + chunk * 16);
+                        if (key & 1) v.i = i32x4{v.i[2], v.i[3], v.i[0], v.i[1]};
                         if (p.res || p.accumulate) {
                             float f[8];
 #pragma unroll

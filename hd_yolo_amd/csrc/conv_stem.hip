@@ -106,8 +106,9 @@ __global__ __launch_bounds__(NTHR) void conv_stem_kernel(const ConvArgs p) {
             s1[b][r] = 0.f;
             s2[b][r] = 0.f;
         }
-    // staging tile: pixel row of ROWB bytes in 8-byte slots; slot XOR keeps the 16 pixel lanes of a write on distinct banks
-    const int sw_fr = K == 64 ? (fr & 14) : (K == 32 ? (((fr >> 2) & 3) << 1) : 0);
+    // staging tile: pixel row of ROWB bytes in 8-byte slots; slot XOR keeps the 16 pixel lanes of a write (ds_write_b64: 16 consecutive lanes over 32 banks)
+    // on distinct banks: all four row bits for 128-byte rows, (row >> 1) & 7 for 64-byte rows (see conv3x3.hip; odd keys swap a chunk's halves)
+    const int sw_fr = K == 64 ? (fr & 15) : (K == 32 ? ((fr >> 1) & 7) : 0);
     int ep_off[NT];
 #pragma unroll
     for (int b = 0; b < NT; ++b) ep_off[b] = fr * ROWB + (((b * 4 + fq) ^ sw_fr) << 3);
@@ -175,8 +176,9 @@ __global__ __launch_bounds__(NTHR) void conv_stem_kernel(const ConvArgs p) {
                 const int c = tid + NTHR * j;
                 const int px = c / CPR, ch = c - px * CPR;
                 const int oy = px / TOW, ox = px - oy * TOW;
-                const int sw = K == 64 ? ((px & 14) >> 1) : (K == 32 ? ((px >> 2) & 3) : 0);
-                const i32x4 v = *(const i32x4*)(sS + px * ROWB + ((ch ^ sw) << 4));
+                const int key = K == 64 ? (px & 15) : (K == 32 ? ((px >> 1) & 7) : 0);
+                i32x4 v = *(const i32x4*)(sS + px * ROWB + ((ch ^ (key >> 1)) << 4));
+                if (key & 1) v = i32x4{v[2], v[3], v[0], v[1]};
                 *(i32x4*)(yb + ((long long)oy * p.Wo + ox) * p.ldy + ch * 8) = v;
             }
         }
