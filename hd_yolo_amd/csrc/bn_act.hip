@@ -545,7 +545,6 @@ void bn_bwd_reduce_launch(dim3 grid, hipStream_t st, const Split& dz, const void
         // eight-channel form (A/B)
         if (y && !hdy_opt(HDY_OPT_NO_BN_REDUCE4) && dz.Ka % 4 == 0) {
             const dim3 g4(grid.x, cdiv(K / 4, 256));
-            // single source whose rows a 32-bit offset can address from the block's first row: the buffer-load form, 8 rows in flight (HDY_BN_REDUCE_BUF = 0: off)
             // rows in flight per lane: 4 (72 VGPRs) — 3 (60) and 2 (54) fit one more wave per SIMD beside the generic weight gradient and measured the same /
             // 0.1 ms slower in the step (11.94-11.96 | 11.92-11.99 | 12.06-12.08 ms; 8 channels per lane: 12.19-12.24).  A buffer-load form (one descriptor per
             // block, 32-bit lane offsets, scalar row offsets: no 64-bit address per load) with 4 / 6 / 8 rows in flight at 60 / 72 / 90 VGPRs measured
