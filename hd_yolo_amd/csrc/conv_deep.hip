@@ -476,13 +476,24 @@ __global__ __launch_bounds__(NTHR, 2) void conv_deep_kernel(const ConvArgs p) {
             const int odd = fq & 1;
             const int cl = odd ? 16 + (fq - 1) * 4 : fq * 4;       // this lane's first channel inside the 32-channel pass
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int np = 0; np < NBH * NTQ / 2; ++np) {           // 32 channels of the wave tile at a time; pass = 16 pixels x 32 channels
+                const int b = BN == 256 ? np : 0, nb = BN == 256 ? 0 : 2 * np;
+                const int cb = BN == 256 ? b * 128 + wc * 32 : wc * 64 + np * 32;      // first channel of the pass inside the column tile
+                // the 32 channels' coefficients once, not once per pass (as first written every pass paid an LDS round trip with its own wait:
+                // 64 of them per wave and 256 x 256 tile)
+                f32x4 csc[2], csh[2];
+                if (EPI >= 1) {
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
+                    for (int q = 0; q < 2; ++q) {
+                        const unsigned ca = lds0 + (unsigned)(COEF + (cb + q * 16 + fq * 4) * 4);
+                        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:%3" : "=&v"(csc[q]), "=&v"(csh[q]) : "v"(ca), "n"(BN * 4));
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(csc[0]), "+v"(csh[0]), "+v"(csc[1]), "+v"(csh[1]));
+                }
 #pragma unroll
-                    for (int np = 0; np < NBH * NTQ / 2; ++np) {   // pass = 16 pixels x 32 channels
-                        const int b = BN == 256 ? np : 0, nb = BN == 256 ? 0 : 2 * np;
-                        const int cb = BN == 256 ? b * 128 + wc * 32 : wc * 64 + np * 32;      // first channel of the pass inside the column tile
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
                         unsigned pk[2][2];
 #pragma unroll
                         for (int q = 0; q < 2; ++q) {
@@ -495,9 +506,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_deep_kernel(const ConvArgs p) {
                                 }
                             }
                             if (EPI >= 1) {
-                                f32x4 sc, sh;
-                                const unsigned ca = lds0 + (unsigned)(COEF + (cb + q * 16 + fq * 4) * 4);
-                                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:%3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(sc), "=&v"(sh) : "v"(ca), "n"(BN * 4));
+                                const f32x4 sc = csc[q], sh = csh[q];
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) {
                                     v[r] = v[r] * sc[r] + sh[r];
@@ -549,6 +558,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_deep_kernel(const ConvArgs p) {
                             else asm volatile("" ::"v"(o.i));          // timing ablation: the epilogue's arithmetic without its stores
                         }
                     }
+            }
         }
 #pragma unroll
         for (int i = 0; i < G::NACC; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};

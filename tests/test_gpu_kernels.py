@@ -558,25 +558,31 @@ def test_errors_are_loud():
 
 # ---------------------------------------------------------------------------------------------- fused 1x1 backward (conv1x1_bwd.hip)
 @pytest.mark.parametrize('K,M,pair,acc', [(32, 128 * 3 + 37, False, False), (64, 128 * 5 + 1, True, True), (64, 90, False, True),
-                                          (128, 128 * 4 + 77, True, False), (128, 128 * 150 + 5, False, True), (64, 128 * 180, True, False)])
+                                          (128, 128 * 4 + 77, True, False), (128, 128 * 150 + 5, False, True), (64, 128 * 180, True, False),
+                                          # more than 512 tiles: workgroups walk 2-3 tiles (requests in flight across tiles), partial last tile
+                                          (64, (7, 18839), True, True), (32, (5, 17921), False, False), (64, (4, 19200), False, False),
+                                          (32, (10, 19210), True, True), (128, (7, 10057), True, True)])
 def test_fused_1x1_backward_matches_reference_and_the_three_launch_path(K, M, pair, acc):
     """hdy_conv1x1_bwd_fused (BatchNorm/SiLU backward apply + wgrad + dgrad in one pass) against (a) plain torch fp32 on the bf16-rounded
     operands and (b) the three-launch path (hdy_bn_act_bwd -> dy, hdy_conv_wgrad, hdy_conv_dgrad) it replaces: same dy bits, so dx / dW
     differ by accumulation order only.  Operands are channel slices of wider buffers; the pair case splits dz over two tensors."""
     dt = torch.bfloat16
     C = K
-    dz = rnd((1, K, 1, M), 1)
-    y = rnd((1, K, 1, M), 2, 2.0) + rnd((1, K, 1, 1), 3)                  # per-channel offsets: non-trivial mean / invstd
-    x = rnd((1, C, 1, M), 4)
+    Nb, Wd = M if isinstance(M, tuple) else (1, M)                         # pixels as Nb rows of Wd (the generic kernels address 16-bit image sides)
+    M = Nb * Wd
+    flat = lambda t: t.permute(0, 2, 3, 1).reshape(M, t.shape[1])          # (Nb, ch, 1, Wd) -> (M, ch)
+    dz = rnd((Nb, K, 1, Wd), 1)
+    y = rnd((Nb, K, 1, Wd), 2, 2.0) + rnd((1, K, 1, 1), 3)                # per-channel offsets: non-trivial mean / invstd
+    x = rnd((Nb, C, 1, Wd), 4)
     w = rnd((K, C, 1, 1), 5, 0.3)
-    dx0 = rnd((1, C, 1, M), 6, 0.5)
+    dx0 = rnd((Nb, C, 1, Wd), 6, 0.5)
     gamma, beta = rnd((K,), 7) + 1.5, rnd((K,), 8, 0.3)
     Ka = K // 2 if pair else K
     dz_a = to_dev_nhwc(dz[:, :Ka], dt, ld=Ka + 16, off=8)
     dz_b = to_dev_nhwc(dz[:, Ka:], dt, ld=K + 8, off=0) if pair else None
     yd = to_dev_nhwc(y, dt)
     xd = to_dev_nhwc(x, dt, ld=C + 24, off=16)
-    dzq, yq, xq, wq = q(dz, dt)[0, :, 0].T, q(y, dt)[0, :, 0].T, q(x, dt)[0, :, 0].T, q(w, dt)[:, :, 0, 0]          # (M, K) (M, K) (M, C) (K, C)
+    dzq, yq, xq, wq = flat(q(dz, dt)), flat(q(y, dt)), flat(q(x, dt)), q(w, dt)[:, :, 0, 0]                          # (M, K) (M, K) (M, C) (K, C)
     # BatchNorm coefficients as the forward pass would have left them (batch statistics of y)
     mean, var = yq.mean(0), yq.var(0, unbiased=False)
     invstd = 1.0 / torch.sqrt(var + 1e-3)
@@ -587,7 +593,7 @@ def test_fused_1x1_backward_matches_reference_and_the_three_launch_path(K, M, pa
     xh = (yq - mean) * invstd
     c1, c2 = du.mean(0), (du * xh).mean(0)
     dy = q(scale * (du - c1 - xh * c2), dt)
-    ref_dx = dy @ wq + (q(dx0, dt)[0, :, 0].T if acc else 0.0)
+    ref_dx = dy @ wq + (flat(q(dx0, dt)) if acc else 0.0)
     ref_dw = dy.T @ xq
     dev = lambda t: t.float().contiguous().to(DEV)
     sc_d, sh_d, mu_d, is_d = dev(scale), dev(shift), dev(mean), dev(invstd)
@@ -602,7 +608,7 @@ def test_fused_1x1_backward_matches_reference_and_the_three_launch_path(K, M, pa
         return ops.rec_bn_act_bwd(dz_a, yd, sc_d, sh_d, mu_d, is_d, dy_out, dgam, dbet, ws)
 
     # (b) three launches
-    dy_d = torch.empty((1, 1, M, K), dtype=dt, device=DEV)
+    dy_d = torch.empty((Nb, 1, Wd, K), dtype=dt, device=DEV)
     dx_b = to_dev_nhwc(dx0, dt, ld=C + 8, off=8)
     gw_b = torch.zeros((K, C, 1, 1), device=DEV)
     wgws = torch.empty(ops.wgrad_ws_bytes(1, 1, M, C, K, 1, 1, 1, 0, dt) // 4 + 16, dtype=torch.float32, device=DEV)
@@ -618,10 +624,10 @@ def test_fused_1x1_backward_matches_reference_and_the_three_launch_path(K, M, pa
                                        accumulate_dx=acc)])
     torch.cuda.synchronize()
     assert_close(c1_d.cpu(), c1, 2e-3, 'c1')
-    got_dx, got_dw = dx_f.float().cpu()[0, 0], gw_f.cpu()[:, :, 0, 0]
+    got_dx, got_dw = dx_f.float().cpu().reshape(M, C), gw_f.cpu()[:, :, 0, 0]
     assert_close(got_dx, ref_dx, 1.5e-2, 'dx vs torch')
     assert_close(got_dw, ref_dw, 1.5e-2, 'dW vs torch')
-    assert_close(got_dx, dx_b.float().cpu()[0, 0], 8e-3, 'dx vs three launches')         # one bf16 rounding of the output apart at most
+    assert_close(got_dx, dx_b.float().cpu().reshape(M, C), 8e-3, 'dx vs three launches')         # one bf16 rounding of the output apart at most
     assert_close(got_dw, gw_b.cpu()[:, :, 0, 0], 2e-4, 'dW vs three launches')           # fp32 sums in a different order
     # dgrad only / wgrad only
     dx_o = to_dev_nhwc(dx0, dt, ld=C + 8, off=8)
@@ -681,6 +687,63 @@ def test_dgrad_serves_batchnorm_backward_statistics(case):
         torch.cuda.synchronize()
         for got, ref, what in ((dg, dg2, 'dgamma'), (db, db2, 'dbeta'), (c1, r1, 'c1'), (c2, r2, 'c2')):
             assert_close(got.cpu(), ref.cpu(), 1e-4, what)       # SUM du*xhat as invstd*(SUM du*y - mean*SUM du): mild cancellation
+    assert dx._base[..., :8].float().eq(7.0).all()
+
+
+@pytest.mark.parametrize('K,M,acc', [(64, 128 * 3 + 50, False), (32, 128 * 1100 + 33, True), (64, 128 * 1100 + 33, False), (64, 128 * 700, True)])
+def test_fused_1x1_backward_serves_batchnorm_backward_statistics(K, M, acc):
+    """hdy_conv1x1_bwd_fused_stats: the fused launch that completes dx also leaves, for the two Conv+BN+SiLU units whose output gradient dx is,
+    per-workgroup slabs of (SUM du, SUM du*y); dx itself is bit-identical to the launch without requests, and hdy_bn_bwd_finalize_slabs gives the
+    dgamma / dbeta / c1 / c2 of each unit's own reduce pass over the finished dx.  The long cases walk several tiles per workgroup."""
+    dt = torch.bfloat16
+    C = K
+    dz = to_dev_nhwc(rnd((1, K, 1, M), 1), dt)
+    yd = to_dev_nhwc(rnd((1, K, 1, M), 2, 2.0) + rnd((1, K, 1, 1), 3), dt)
+    xd = to_dev_nhwc(rnd((1, C, 1, M), 4), dt)
+    w = rnd((K, C, 1, 1), 5, 0.3)
+    dx0 = rnd((1, C, 1, M), 6, 0.5)
+    yq = yd.float()[0, 0]
+    mean, var = yq.mean(0), yq.var(0, unbiased=False)
+    invstd = (1.0 / torch.sqrt(var + 1e-3)).contiguous()
+    gamma, beta = (rnd((K,), 7) + 1.5).to(DEV), rnd((K,), 8, 0.3).to(DEV)
+    scale, shift = (gamma * invstd).contiguous(), (beta - mean * gamma * invstd).contiguous()
+    ws = torch.empty(ops.bn_bwd_ws_floats(M, K), dtype=torch.float32, device=DEV)
+    dgam, dbet = torch.zeros(K, device=DEV), torch.zeros(K, device=DEV)
+    wpd = ops.pack_alloc(K, C, 1, 1, 1, 0, ops.PACK_DGRAD, dt, DEV)
+    ops.run([ops.rec_pack(w.to(DEV), None, 1, 0, ops.PACK_DGRAD, wpd), ops.rec_bn_act_bwd(dz, yd, scale, shift, mean.contiguous(), invstd, None, dgam, dbet, ws)])
+    c1_d, c2_d = ops.bn_bwd_coeffs(ws, M, K)
+    nslabs = ops.fused_1x1_stat_slabs(M, C, K, dt)
+    assert nslabs > 0 and ops.fused_1x1_stat_slabs(M, 128, 128, dt) == 0
+    Ca = C // 2
+    units = []
+    for i, (c0, c1) in enumerate([(0, Ca), (Ca, C)]):
+        y = to_dev_nhwc(rnd((1, c1 - c0, 1, M), 10 + i, 2.0) + rnd((1, c1 - c0, 1, 1), 20 + i), dt, ld=c1 - c0 + 8, off=8 * i)
+        uq = y.float()
+        um, uv = uq.mean((0, 1, 2)), uq.var((0, 1, 2), unbiased=False)
+        uis = (1.0 / torch.sqrt(uv + 1e-3)).contiguous()
+        g2, b2 = (rnd((c1 - c0,), 30 + i) + 1.5).to(DEV), rnd((c1 - c0,), 40 + i, 0.3).to(DEV)
+        units.append(dict(y=y, scale=(g2 * uis).contiguous(), shift=(b2 - um * g2 * uis).contiguous(), mean=um.contiguous(), invstd=uis,
+                          slabs=torch.zeros((nslabs, 2, c1 - c0), device=DEV), c0=c0, c1=c1))
+    reqs = [ops.StatRequest(u['y'], u['scale'], u['shift'], u['slabs'], u['c0'], ops.ACT_SILU) for u in units]
+    f1ws = torch.empty(ops.fused_1x1_ws_bytes(M, C, K) // 4 + 16, dtype=torch.float32, device=DEV)
+    dx, dx_plain = to_dev_nhwc(dx0, dt, ld=C + 16, off=8), to_dev_nhwc(dx0, dt, ld=C + 16, off=8)
+    gw, gw_plain = torch.zeros((K, C, 1, 1), device=DEV), torch.zeros((K, C, 1, 1), device=DEV)
+    mu = mean.contiguous()
+    ops.run([ops.rec_conv1x1_bwd_fused(dz, None, yd, scale, shift, mu, invstd, c1_d, c2_d, xd, wpd, dx, gw, None, f1ws, accumulate_dx=acc, stats=reqs),
+             ops.rec_conv1x1_bwd_fused(dz, None, yd, scale, shift, mu, invstd, c1_d, c2_d, xd, wpd, dx_plain, gw_plain, None, f1ws, accumulate_dx=acc)])
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dx_plain) and torch.equal(gw, gw_plain)
+    for u in units:
+        Kc = u['c1'] - u['c0']
+        dg, db, c1, c2 = (torch.zeros(Kc, device=DEV) for _ in range(4))
+        ops.run([ops.rec_bn_bwd_finalize_slabs(u['slabs'], M, u['mean'], u['invstd'], dg, db, c1, c2)])
+        ws2 = torch.empty(ops.bn_bwd_ws_floats(M, Kc), dtype=torch.float32, device=DEV)
+        dg2, db2 = torch.zeros(Kc, device=DEV), torch.zeros(Kc, device=DEV)
+        ops.run([ops.rec_bn_act_bwd(dx[..., u['c0']:u['c1']], u['y'], u['scale'], u['shift'], u['mean'], u['invstd'], None, dg2, db2, ws2)])
+        r1, r2 = ops.bn_bwd_coeffs(ws2, M, Kc)
+        torch.cuda.synchronize()
+        for got, ref, what in ((dg, dg2, 'dgamma'), (db, db2, 'dbeta'), (c1, r1, 'c1'), (c2, r2, 'c2')):
+            assert_close(got.cpu(), ref.cpu(), 1e-4, what)
     assert dx._base[..., :8].float().eq(7.0).all()
 
 
