@@ -57,6 +57,10 @@ SIGNATURES = {
     'hdy_conv1x1_bwd_fused_ok': (_I, [_I, _I, _I]),
     'hdy_conv1x1_bwd_fused_grid': (_I, [_L, _I]),
     'hdy_conv1x1_bwd_fused_workspace_bytes': (_Z, [_L, _I, _I]),
+    'hdy_exec_op': (_I, [c_char_p]),
+    'hdy_exec_run': (_I, [_P, _Z, _P, _P]),
+    'hdy_exec_join': (_I, [ctypes.c_ulonglong, _P]),
+    'hdy_copy_f32': (_I, [_P, _P, _L, _P]),
     'hdy_conv1x1_bwd_fused': (_I, [_P, _I, _P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P, _I, _P, _I, _I, _L, _I, _I, _P, _Z, _I, _P]),
     'hdy_groupnorm_workspace_floats': (_Z, [_I, _I]),
     'hdy_groupnorm_fwd': (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _F, _I, _I, _P, _Z, _P]),

@@ -7,6 +7,7 @@ device addresses.  Records are either executed at once (`run`) or stored in a st
 (hd_yolo_amd/plan.py) and replayed every step with no further Python-side work.
 """
 import ctypes
+import struct
 import os
 
 import torch
@@ -91,6 +92,84 @@ class SideStream:
         done = self.done.pop(token, None)
         if done is not None:
             main.wait_event(done)
+        # (a fork and its join always sit in ONE list, and a list runs either here or, compiled, through hdy_exec_run, whose events live in the
+        # library: a token unknown here was never forked through this object)
+
+
+# ------------------------------------------------------------------------------------------ compiled launch lists (csrc/exec.hip)
+EXEC_FORK, EXEC_JOIN = 0xF0F0F0F0, 0xF0F0F0F1
+USE_EXEC = os.environ.get('HDY_EXEC', '1') != '0'        # HDY_EXEC=0: every list through the Python loop below (A/B, debugging)
+_M64 = (1 << 64) - 1
+
+
+def _word(v, ctype):
+    """one launch argument widened to the 64-bit word hdy_exec_run expects for a parameter of ctypes type `ctype`"""
+    if ctype is ctypes.c_float:
+        return struct.unpack('<I', struct.pack('<f', float(v)))[0]
+    if ctype is ctypes.c_double:
+        return struct.unpack('<Q', struct.pack('<d', float(v)))[0]
+    if v is None:
+        return 0
+    if isinstance(v, int):
+        return v & _M64
+    if isinstance(v, ctypes._SimpleCData):
+        return (v.value or 0) & _M64
+    return ctypes.cast(v, ctypes.c_void_p).value or 0       # ctypes array / pointer / structure reference
+
+
+class Program:
+    """A launch list compiled for hdy_exec_run: segments of 64-bit words (one C call each) between the list's host callbacks.  It keeps the
+    records (and through them every tensor and host array whose address the words hold) alive."""
+
+    def __init__(self, records):
+        lib = _lib.load()
+        self.records = records
+        self.side = None
+        self.segments = []              # ('words', ctypes array, count) | ('call', fn)
+        words = []
+
+        def item(rec):
+            name, args = rec[0], rec[1]
+            op = lib.hdy_exec_op(name.encode())
+            types = _lib.SIGNATURES[name][1]
+            if op < 0 or len(args) != len(types) - 1:
+                raise _lib.HdyError(f'{name} cannot be listed for hdy_exec_run ({len(args)} arguments recorded, {len(types) - 1} expected)')
+            return [op, len(args)] + [_word(v, t) for v, t in zip(args, types)]
+
+        def flush():
+            if words:
+                self.segments.append(('words', (ctypes.c_ulonglong * len(words))(*words), len(words)))
+                del words[:]
+
+        for rec in records:
+            name = rec[0]
+            if name == '@call':
+                flush()
+                self.segments.append(('call', rec[1]))
+            elif name in ('@fork', '@join'):
+                if self.side is not None and self.side is not rec[1]:
+                    raise _lib.HdyError('a launch list forks onto one side stream')
+                self.side = rec[1]
+                if name == '@join':
+                    words.extend([EXEC_JOIN, 1, rec[2]])
+                else:
+                    body = [w for r in rec[2] for w in item(r)]       # (a host callback inside a fork: not a launch record -> KeyError above)
+                    words.extend([EXEC_FORK, 2, rec[3], len(body)] + body)
+            else:
+                words.extend(item(rec))
+        flush()
+
+    def run(self):
+        lib = _lib.load()
+        main = stream_ptr()
+        side = self.side.stream.cuda_stream if self.side is not None else None
+        for seg in self.segments:
+            if seg[0] == 'call':
+                seg[1]()
+                continue
+            rc = lib.hdy_exec_run(seg[1], seg[2], main, side)
+            if rc != 0:
+                raise _lib.HdyError(f'hdy_exec_run failed (status {rc}): {lib.hdy_last_error().decode()}')
 
 
 def run(records, stream=None):
@@ -454,6 +533,12 @@ def rec_conv1x1_bwd_fused(dz_a, dz_b, y, scale, shift, mean, invstd, c1, c2, x, 
         keep = [t for q in stats for t in q.keep]
         return _rec(locals(), 'hdy_conv1x1_bwd_fused_stats', args + (arrp, len(stats))) + ((arr,),)
     return _rec(locals(), 'hdy_conv1x1_bwd_fused', args)
+
+
+def rec_copy_f32(src, dst):
+    """dst[:] = src[:] (contiguous fp32, same length) as a list item: a host-side tensor copy would split a compiled launch list"""
+    assert src.dtype == dst.dtype == torch.float32 and src.is_contiguous() and dst.is_contiguous() and src.numel() == dst.numel() > 0
+    return _rec(locals(), 'hdy_copy_f32', (ptr(src), ptr(dst), src.numel()))
 
 
 def rec_colsum(dz, out, ws, accumulate=False):

@@ -507,7 +507,14 @@ class Plan:
 
     def _replay(self, key, recs):
         if not USE_GRAPHS:
-            return ops.run(recs)
+            if not ops.USE_EXEC:
+                return ops.run(recs)
+            # the list is static: compiled once into words for hdy_exec_run (one C call per stretch between host callbacks) and replayed
+            progs = self.__dict__.setdefault('_progs', {})
+            prog = progs.get(key)
+            if prog is None or prog.records is not recs:
+                prog = progs[key] = ops.Program(recs)
+            return prog.run()
         g = self._graphs[key]
         if g is None:
             self._runs[key] += 1
@@ -678,7 +685,7 @@ class Plan:
                 tmp = self._det_bias_tmp(u)
                 recs.append(ops.rec_colsum(u.gdet, tmp, self.bn_ws))
                 gb = self._grad_views(u.conv.bias)
-                recs.append(('@call', (lambda gb=gb, tmp=tmp, K=u.K: gb.copy_(tmp[:K]))))       # Kp-padded column sums -> the bias gradient
+                recs.append(ops.rec_copy_f32(tmp[:u.K], gb))                                    # Kp-padded column sums -> the bias gradient
                 gw = self._grad_views(u.conv.weight)
                 wgrad(ops.rec_conv_wgrad(x.t(), u.gdet, gw, None, 1, 1, 1, 0, self.wg_ws))
                 if not up(x):

@@ -375,6 +375,23 @@ int hdy_sgd_blocks(long long n);
 int hdy_sgd_step(const hdy_sgd_desc* table_device, int ndesc, int total_blocks, const float* lr, const float* momentum, const float* dampening,
                  const float* weight_decay, int ngroups, int nesterov, void* stream);
 
+/* ---- launch-list executor (csrc/exec.hip): one call issues a whole precomputed list of launches on two streams — a plan's forward or backward
+ * list, whose pointers, shapes and order are fixed (no reference counterpart: the order is the one PyTorch's autograd engine gives the same work,
+ * train.py:472).  program = 64-bit words, per item [op][nargs][arg 0]..[arg nargs-1]:
+ *   op = hdy_exec_op("hdy_...") (>= 0; -1: that entry point cannot be listed): the entry point's parameters in order WITHOUT the trailing
+ *        stream, each widened to 64 bits (pointers / integers by value, float / double by bit pattern);
+ *   op = HDY_EXEC_FORK, args {token, words}: the next `words` words run on side_stream once everything issued so far on main_stream is done;
+ *   op = HDY_EXEC_JOIN, args {token}: main_stream waits for the launches of that fork (a token never forked: no wait).
+ * Tokens are < 65536; their events live per device for the life of the process.  Returns the first non-zero status of a listed entry point
+ * (hdy_last_error names it), HDY_EINVAL for a malformed program.  hdy_exec_join: the join alone, for a caller that runs the rest of a
+ * list itself.  hdy_copy_f32: dst[0..n) = src[0..n) on the stream (a list item in place of a host-side tensor copy). */
+#define HDY_EXEC_FORK 0xF0F0F0F0ull
+#define HDY_EXEC_JOIN 0xF0F0F0F1ull
+int hdy_exec_op(const char* name);
+int hdy_exec_run(const unsigned long long* program, size_t nwords, void* main_stream, void* side_stream);
+int hdy_exec_join(unsigned long long token, void* main_stream);
+int hdy_copy_f32(const float* src, float* dst, long long n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

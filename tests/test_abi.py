@@ -147,3 +147,34 @@ def test_fastdiv_reciprocal_is_exact(lib):
             if 0 <= n < (1 << 31):
                 assert ((2 * n * mg.value) >> 32) >> sh.value == n // d, (n, d)
     assert lib.hdy_fastdiv_magic(0, ctypes.byref(mg), ctypes.byref(sh)) < 0
+
+
+def test_launch_list_executor_table_and_malformed_programs(lib):
+    """hdy_exec_run (csrc/exec.hip): every entry point of the header whose last parameter is the stream can be listed, nothing else can; a
+    malformed program is a status (decided on the host, before any launch), not a crash."""
+    import ctypes
+    text = re.sub(r'/\*.*?\*/', '', open(os.path.join(ROOT, 'include', 'hdyolo.h')).read(), flags=re.S)
+    decls = re.findall(r'\b(hdy_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;', text, flags=re.S)
+    assert len(decls) >= 80
+    for name, params in decls:
+        takes_stream = re.search(r'void\s*\*\s*stream\s*$', params.strip()) is not None
+        if name in ('hdy_exec_run', 'hdy_exec_join'):          # the executor itself is not a list item
+            takes_stream = False
+        assert (lib.hdy_exec_op(name.encode()) >= 0) == takes_stream, name
+        if takes_stream:
+            assert _lib.SIGNATURES[name][0] is ctypes.c_int and _lib.SIGNATURES[name][1][-1] is ctypes.c_void_p, name
+    assert lib.hdy_exec_op(b'hdy_no_such_entry') == -1
+
+    def run(words):
+        arr = (ctypes.c_ulonglong * max(1, len(words)))(*words)
+        return lib.hdy_exec_run(arr, len(words), None, None)
+
+    assert run([]) == _lib.OK
+    op = lib.hdy_exec_op(b'hdy_scale_inplace')
+    assert run([op]) == _lib.EINVAL and b'truncated' in lib.hdy_last_error()
+    assert run([op, 9, 0, 0]) == _lib.EINVAL                                   # more arguments than words
+    assert run([op, 2, 0, 0]) == _lib.EINVAL and b'hdy_scale_inplace takes 4' in lib.hdy_last_error()
+    assert run([12345, 0]) == _lib.EINVAL and b'unknown op' in lib.hdy_last_error()
+    assert run([0xF0F0F0F0, 2, 1, 0]) == _lib.EINVAL                           # a fork without a side stream
+    assert run([0xF0F0F0F1, 2, 1, 1]) == _lib.EINVAL                           # a join takes one argument
+    assert run([op, 4, 0, 16, 0, _lib.BF16]) == _lib.EINVAL                    # well formed: the entry point's own argument check answers (null pointer)

@@ -942,3 +942,55 @@ def test_deep_pipelined_weight_gradient(case):
             assert ('wgrad_deep' in _lib.dispatch_log(reset=True)) == (off == 0)
             res.append(g.cpu())
     assert_close(res[0], res[1], 1e-3, 'deep vs generic weight gradient')
+
+
+# ---------------------------------------------------------------------------------------------- compiled launch lists (csrc/exec.hip)
+def test_compiled_launch_list_equals_the_python_loop():
+    """ops.Program (hdy_exec_run: the whole list issued from C, forks onto the side stream and joins by the library's events) against ops.run
+    (the Python loop) on a list with a fork whose result the main stream needs behind the join and a host callback in the middle (two
+    segments); a failing item raises with the entry point's own message.  (float arguments — bit-pattern words — travel through the model tests:
+    hdy_bn_finalize's eps / momentum against the reference goldens.)"""
+    dt = torch.bfloat16
+    M, K = 4096, 64
+
+    def build(side):
+        g = torch.Generator().manual_seed(5)
+        a = torch.randn((1, 1, M, K), generator=g).to(DEV, dt)
+        b = torch.randn((1, 1, M, K), generator=g).to(DEV, dt)
+        c = torch.randn((1, 1, M, K), generator=g).to(DEV, dt)
+        src = torch.arange(K, dtype=torch.float32, device=DEV)
+        dst = torch.zeros(K, device=DEV)
+        half = torch.full((1,), 0.5, device=DEV)
+        seen = []
+        recs = [ops.rec_add_inplace(a, b),                                               # a += b
+                ('@fork', side, [ops.rec_add_inplace(c, a), ops.rec_add_inplace(c, a)], 3),   # side: c += 2a (needs the a of the line above)
+                ('hdy_scale_inplace', (b.data_ptr(), b.numel(), half.data_ptr(), ops.dcode(dt)), (b, half)),      # main meanwhile: b *= 0.5
+                ('@call', lambda: seen.append(1)),
+                ops.rec_copy_f32(src, dst),
+                ('@join', side, 3),
+                ops.rec_add_inplace(b, c)]                                               # b += c: needs the fork's result
+        return recs, (a, b, c, dst), seen
+
+    results = []
+    for compiled in (False, True):
+        side = ops.SideStream(DEV)
+        recs, tensors, seen = build(side)
+        for _ in range(3):                       # replayed like a plan's list (events re-recorded every time)
+            if compiled:
+                prog = ops.Program(recs)
+                assert [s[0] for s in prog.segments] == ['words', 'call', 'words']
+                prog.run()
+            else:
+                ops.run(recs)
+        torch.cuda.synchronize()
+        assert len(seen) == 3
+        results.append([t.float().cpu() for t in tensors])
+    for x, y in zip(*results):
+        assert torch.equal(x, y)
+    assert results[0][3].tolist() == list(range(K))
+    bad = ops.Program([ops.rec_add_inplace(tensors[0], tensors[1])])
+    bad.segments[0][1][4] = 0                                                            # null second operand
+    with pytest.raises(_lib.HdyError, match='add_inplace'):
+        bad.run()
+    with pytest.raises(_lib.HdyError, match='cannot be listed'):
+        ops.Program([('hdy_version', ())])
