@@ -16,6 +16,7 @@
 // launches.  Reference: the order PyTorch's autograd engine gives the same work on its streams (train.py:472); nothing in the reference
 // corresponds to the list itself.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -110,8 +111,10 @@ int events_for(u64 token, TokenEvents* out) {
     if (v.size() <= token) v.resize(token + 1);
     TokenEvents& t = v[token];
     if (!t.start) {
-        if (hipEventCreateWithFlags(&t.start, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&t.done, hipEventDisableTiming) != hipSuccess)
-            return HDY_EINVAL;
+        // both streams are queues of ONE device: a device-scope release is all a record has to do (the default releases to the system — the
+        // marker packet then costs the main queue ~8 us per fork, 34 forks per yolov5s step: profiles/r04_fork_markers.txt)
+        static const unsigned flags = hipEventDisableTiming | (getenv("HDY_EVENT_SYSTEM_SCOPE") ? 0u : (unsigned)hipEventReleaseToDevice);
+        if (hipEventCreateWithFlags(&t.start, flags) != hipSuccess || hipEventCreateWithFlags(&t.done, flags) != hipSuccess) return HDY_EINVAL;
     }
     *out = t;
     return HDY_OK;
