@@ -23,6 +23,7 @@ python3 scripts/bench_latency.py 2>/dev/null | tail -3 >> $OUT/variants.log
 PYTHONPATH=. python3 scripts/probes/seg_kernels.py > $OUT/seg_kernels.txt 2>/dev/null
 PYTHONPATH=. python3 scripts/probes/dgrad_walk.py > $OUT/dgrad_walk.txt 2>/dev/null
 python3 scripts/trace_gaps.py $OUT/bench/bench_kernel_trace.csv 6 > $OUT/trace_gaps.txt 2>&1
+python3 scripts/trace_idle.py $OUT/bench/bench_kernel_trace.csv 12 > $OUT/trace_idle.txt 2>&1
 python3 scripts/pmc_summary.py $OUT/fetch/fetch_counter_collection.csv $OUT/write/write_counter_collection.csv conv3x3_c64_kernel $OUT/conv3x3_pmc.json > /dev/null 2>&1
 python3 scripts/counters_summary.py $OUT/mfma/mfma_counter_collection.csv $OUT/lds/lds_counter_collection.csv conv3x3_c64_kernel $OUT/roof/roof_kernel_stats.csv $OUT/conv3x3_counters.json > /dev/null 2>&1
 bash scripts/step_traffic.sh $R > /dev/null 2>&1 && cp gpurun_out/traffic_$R/step_traffic.json $OUT/step_traffic.json
