@@ -178,3 +178,30 @@ def test_launch_list_executor_table_and_malformed_programs(lib):
     assert run([0xF0F0F0F0, 2, 1, 0]) == _lib.EINVAL                           # a fork without a side stream
     assert run([0xF0F0F0F1, 2, 1, 1]) == _lib.EINVAL                           # a join takes one argument
     assert run([op, 4, 0, 16, 0, _lib.BF16]) == _lib.EINVAL                    # well formed: the entry point's own argument check answers (null pointer)
+
+
+def test_program_words_follow_the_record_list(lib):
+    """ops.Program (the Python side of hdy_exec_run) on a hand-made record list, no GPU: one segment per stretch between host callbacks, fork bodies
+    inline behind their length, arguments widened by the ctypes type of the parameter (negative ints, floats by bit pattern, None -> 0)."""
+    import struct
+    from hd_yolo_amd import ops
+
+    class Side:                                    # stands in for ops.SideStream (never run here)
+        pass
+
+    side = Side()
+    scale = ('hdy_scale_inplace', (0x1000, 7, 0x2000, _lib.BF16), ())
+    addi = ('hdy_add_inplace', (0x3000, 64, 0x4000, 64, -5, 64, _lib.BF16), ())
+    fin = ('hdy_bn_finalize_sums', (0x10, 8, 0x20, 8, 8) + (None,) * 8 + (1e-3, 0.03) + (0x30,) * 4, ())
+    seen = []
+    prog = ops.Program([scale, ('@fork', side, [addi, scale], 9), ('@call', lambda: seen.append(1)), fin, ('@join', side, 9)])
+    assert [s[0] for s in prog.segments] == ['words', 'call', 'words'] and prog.side is side
+    w0, w1 = list(prog.segments[0][1]), list(prog.segments[2][1])
+    op_s, op_a, op_f = (lib.hdy_exec_op(n) for n in (b'hdy_scale_inplace', b'hdy_add_inplace', b'hdy_bn_finalize_sums'))
+    item_s = [op_s, 4, 0x1000, 7, 0x2000, _lib.BF16]
+    item_a = [op_a, 7, 0x3000, 64, 0x4000, 64, (1 << 64) - 5, 64, _lib.BF16]
+    assert w0 == item_s + [ops.EXEC_FORK, 2, 9, len(item_a) + len(item_s)] + item_a + item_s
+    f32 = lambda v: struct.unpack('<I', struct.pack('<f', v))[0]
+    assert w1 == [op_f, 19, 0x10, 8, 0x20, 8, 8] + [0] * 8 + [f32(1e-3), f32(0.03)] + [0x30] * 4 + [ops.EXEC_JOIN, 1, 9]
+    with pytest.raises(_lib.HdyError, match='cannot be listed'):
+        ops.Program([('hdy_scale_inplace', (1, 2, 3), ())])              # one argument short
