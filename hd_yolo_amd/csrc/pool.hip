@@ -4,6 +4,8 @@
 // Reference semantics replaced: nn.MaxPool2d(5,1,2) x3 + torch.cat in SPPF.forward
 // (metayolo/models/layers.py:181-189), nn.Upsample(None, 2, 'nearest') (hub yaml `fpn` rows), and the
 // host-side `torch.stack(imgs).to(device)` hand-off (train.py:432).
+#include <mutex>
+
 #include "common.h"
 
 namespace {
@@ -27,10 +29,12 @@ constexpr int PB = 2;                                    // border pixels
 
 // thread -> (pixel, 4-channel group) walk over the interior of the padded plane without divisions: 256 / (CG/4) pixels per trip.
 // Four channels per lane: one 16-byte LDS read serves a tap for all four (and one dword the four stored window positions).
-constexpr int QPP = CG / 4;                              // 4-channel groups per pixel
-struct PlaneWalk {
+// CGK channels per workgroup, NT threads: CGK / 4 four-channel groups per pixel, NT / (CGK / 4) pixels per trip.
+template <int CGK, int NT>
+struct PlaneWalkT {
+    static constexpr int QPP = CGK / 4;
     int pix, h, w;
-    __device__ PlaneWalk(int W) : pix(threadIdx.x / QPP), h(0), w(threadIdx.x / QPP) { wrap(W); }
+    __device__ PlaneWalkT(int W) : pix(threadIdx.x / QPP), h(0), w(threadIdx.x / QPP) { wrap(W); }
     __device__ void wrap(int W) {
         while (w >= W) {
             w -= W;
@@ -38,8 +42,8 @@ struct PlaneWalk {
         }
     }
     __device__ void next(int W) {
-        pix += 256 / QPP;
-        w += 256 / QPP;
+        pix += NT / QPP;
+        w += NT / QPP;
         wrap(W);
     }
 };
@@ -58,21 +62,36 @@ __device__ __forceinline__ void store4(T* p, const f32x4& v) {
     *(typename Quad<T>::type*)p = o;
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void sppf_pool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y1, T* __restrict__ y2, T* __restrict__ y3,
+// plane elements in LDS: fp32, or bf16 for the forward pass of bf16 tensors (a maximum of bf16 values is one of them: same outputs, half the LDS,
+// so that a workgroup can own 32 channels = 64 contiguous bytes per pixel instead of 8 = 16 bytes)
+__device__ __forceinline__ f32x4 ldp(const float* p) { return *(const f32x4*)p; }
+__device__ __forceinline__ f32x4 ldp(const bf16_t* p) {
+    const bf16x4 v = *(const bf16x4*)p;
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+__device__ __forceinline__ void stp(float* p, const f32x4& v) { *(f32x4*)p = v; }
+__device__ __forceinline__ void stp(bf16_t* p, const f32x4& v) { *(bf16x4*)p = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]}; }
+
+// Access granularity is what the first form of these kernels (8 channels per workgroup, fp32 planes, 256 threads) paid for: 16 contiguous bytes per
+// pixel in every load and store — 85 / 102 us forward / backward alone for a 13 MB tensor (64 x 20 x 20 x 256), 7-8 x their HBM time.
+template <typename T, typename PT, int CGK, int NT>
+__global__ __launch_bounds__(NT) void sppf_pool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y1, T* __restrict__ y2, T* __restrict__ y3,
                                                             int ld, unsigned char* __restrict__ i1, unsigned char* __restrict__ i2,
                                                             unsigned char* __restrict__ i3, int H, int W, int C) {
-    extern __shared__ __attribute__((aligned(16))) float pl[];          // [2][(H+4)*(W+4)][CG]
+    extern __shared__ __attribute__((aligned(16))) unsigned char pl_raw[];
+    PT* const pl = (PT*)pl_raw;                                       // [2][(H+4)*(W+4)][CGK]
+    constexpr int CG = CGK, QPP = CGK / 4;
+    typedef PlaneWalkT<CGK, NT> PlaneWalk;
     const int HW = H * W, WP = W + 2 * PB, PP = (H + 2 * PB) * WP;
-    float* a = pl;
-    float* b = pl + PP * CG;
+    PT* a = pl;
+    PT* b = pl + PP * CG;
     const int cgs = C / CG;
     const int n = blockIdx.x / cgs, c0 = (blockIdx.x - n * cgs) * CG + (threadIdx.x % QPP) * 4;
     const int cl = (threadIdx.x % QPP) * 4;
     const size_t base = (size_t)n * HW;
-    for (int e = threadIdx.x; e < 2 * PP * CG; e += 256) pl[e] = -INFINITY;        // both planes, borders included
+    for (int e = threadIdx.x; e < 2 * PP * CG; e += NT) pl[e] = (PT)(-INFINITY);   // both planes, borders included
     __syncthreads();
-    for (PlaneWalk q(W); q.pix < HW; q.next(W)) *(f32x4*)(a + ((q.h + PB) * WP + q.w + PB) * CG + cl) = load4<T>(x + (base + q.pix) * ld + c0);
+    for (PlaneWalk q(W); q.pix < HW; q.next(W)) stp(a + ((q.h + PB) * WP + q.w + PB) * CG + cl, load4<T>(x + (base + q.pix) * ld + c0));
     __syncthreads();
     T* outs[3] = {y1, y2, y3};
     unsigned char* idxs[3] = {i1, i2, i3};
@@ -88,19 +107,19 @@ __global__ __launch_bounds__(256) void sppf_pool_fwd_kernel(const T* __restrict_
 #pragma unroll
         for (int pass = 0; pass < 3; ++pass) {
             for (PlaneWalk q(W); q.pix < HW; q.next(W)) {          // rows: a -> b
-                const float* ctr = a + ((q.h + PB) * WP + q.w + PB) * CG + cl;
+                const PT* ctr = a + ((q.h + PB) * WP + q.w + PB) * CG + cl;
                 f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
-                for (int dx = -2; dx <= 2; ++dx) m = vmax(m, *(const f32x4*)(ctr + dx * CG));
-                *(f32x4*)(b + ((q.h + PB) * WP + q.w + PB) * CG + cl) = m;
+                for (int dx = -2; dx <= 2; ++dx) m = vmax(m, ldp(ctr + dx * CG));
+                stp(b + ((q.h + PB) * WP + q.w + PB) * CG + cl, m);
             }
             __syncthreads();
             for (PlaneWalk q(W); q.pix < HW; q.next(W)) {          // columns: b -> a (the next pool's source)
-                const float* ctr = b + ((q.h + PB) * WP + q.w + PB) * CG + cl;
+                const PT* ctr = b + ((q.h + PB) * WP + q.w + PB) * CG + cl;
                 f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
-                for (int dy = -2; dy <= 2; ++dy) m = vmax(m, *(const f32x4*)(ctr + dy * WP * CG));
-                *(f32x4*)(a + ((q.h + PB) * WP + q.w + PB) * CG + cl) = m;
+                for (int dy = -2; dy <= 2; ++dy) m = vmax(m, ldp(ctr + dy * WP * CG));
+                stp(a + ((q.h + PB) * WP + q.w + PB) * CG + cl, m);
                 store4<T>(outs[pass] + (base + q.pix) * ld + c0, m);
             }
             __syncthreads();
@@ -116,12 +135,12 @@ __global__ __launch_bounds__(256) void sppf_pool_fwd_kernel(const T* __restrict_
             unsigned bi[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int dx = 0; dx < 5; ++dx) {
-                const f32x4 v = *(const f32x4*)(a + o + (dx - 2) * CG);
+                const f32x4 v = ldp(a + o + (dx - 2) * CG);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     if (v[i] > best[i] || v[i] != v[i]) { best[i] = v[i]; bi[i] = dx; }               // border taps are -inf: never selected
             }
-            *(f32x4*)(b + o) = best;
+            stp(b + o, best);
             *(unsigned*)(rx + o) = bi[0] | bi[1] << 8 | bi[2] << 16 | bi[3] << 24;
         }
         __syncthreads();
@@ -131,12 +150,12 @@ __global__ __launch_bounds__(256) void sppf_pool_fwd_kernel(const T* __restrict_
             unsigned bj[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int dy = 0; dy < 5; ++dy) {
-                const f32x4 v = *(const f32x4*)(b + o + (dy - 2) * WP * CG);
+                const f32x4 v = ldp(b + o + (dy - 2) * WP * CG);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     if (v[i] > best[i] || v[i] != v[i]) { best[i] = v[i]; bj[i] = dy; }
             }
-            *(f32x4*)(a + o) = best;
+            stp(a + o, best);
             store4<T>(outs[pass] + (base + q.pix) * ld + c0, best);
             *(unsigned*)(idxs[pass] + (base + q.pix) * C + c0) = (bj[0] | bj[1] << 8 | bj[2] << 16 | bj[3] << 24) | (*(const unsigned*)(rx + o) << 4);
         }
@@ -146,14 +165,16 @@ __global__ __launch_bounds__(256) void sppf_pool_fwd_kernel(const T* __restrict_
 
 // dx = g0 + P1^T( g1 + P2^T( g2 + P3^T g3 ) ), P^T = scatter-to-argmax written as two 5-tap gathers (deterministic):
 // column stage  r[h'][w] = SUM_dy [dy(h' - dy + 2, w) == dy] t[h' - dy + 2][w],  row stage  s[h][w'] = SUM_dx [dx'(h, w' - dx + 2) == dx] r[h][w' - dx + 2].
-template <typename T>
-__global__ __launch_bounds__(256) void sppf_pool_bwd_kernel(const T* __restrict__ g0, const T* __restrict__ g1, const T* __restrict__ g2,
+template <typename T, int CGK, int NT>
+__global__ __launch_bounds__(NT) void sppf_pool_bwd_kernel(const T* __restrict__ g0, const T* __restrict__ g1, const T* __restrict__ g2,
                                                             const T* __restrict__ g3, int ldg, const unsigned char* __restrict__ i1,
                                                             const unsigned char* __restrict__ i2, const unsigned char* __restrict__ i3,
                                                             T* __restrict__ dx, int lddx, int H, int W, int C, int two_ix) {
     // two_ix: a second position plane, so that the next level's positions are fetched during the row stage instead of between two extra
     // barriers (planes up to 38 x 38; a 40 x 40 plane — 1280 x 1280 tiles at stride 32 — only fits with one)
-    extern __shared__ __attribute__((aligned(16))) float pl[];          // [2][(H+4)*(W+4)][CG] floats + [1 or 2][(H+4)*(W+4)][CG] bytes
+    extern __shared__ __attribute__((aligned(16))) float pl[];          // [2][(H+4)*(W+4)][CGK] floats + [1 or 2][(H+4)*(W+4)][CGK] bytes
+    constexpr int CG = CGK, QPP = CGK / 4;
+    typedef PlaneWalkT<CGK, NT> PlaneWalk;
     const int HW = H * W, WP = W + 2 * PB, PP = (H + 2 * PB) * WP;
     float* a = pl;
     float* b = pl + PP * CG;
@@ -164,8 +185,8 @@ __global__ __launch_bounds__(256) void sppf_pool_bwd_kernel(const T* __restrict_
     const size_t base = (size_t)n * HW;
     const T* gs[3] = {g2, g1, g0};
     const unsigned char* idxs[3] = {i3, i2, i1};
-    for (int e = threadIdx.x; e < (two_ix ? 2 : 1) * PP * CG / 4; e += 256) ((unsigned*)ixb)[e] = 0xffffffffu;   // border: positions that never match
-    for (int e = threadIdx.x; e < 2 * PP * CG; e += 256) pl[e] = 0.f;              // border sources are read (and discarded) below
+    for (int e = threadIdx.x; e < (two_ix ? 2 : 1) * PP * CG / 4; e += NT) ((unsigned*)ixb)[e] = 0xffffffffu;   // border: positions that never match
+    for (int e = threadIdx.x; e < 2 * PP * CG; e += NT) pl[e] = 0.f;              // border sources are read (and discarded) below
     __syncthreads();
     for (PlaneWalk q(W); q.pix < HW; q.next(W)) {
         const int o = ((q.h + PB) * WP + q.w + PB) * CG + cl;
@@ -327,6 +348,29 @@ inline int sgrid(long long total) {
     return (int)g;
 }
 
+// configuration of an SPPF launch: the widest channel group whose planes fit the LDS (64 / 32 contiguous bytes per pixel instead of 16), more threads
+// for the larger groups; CG = 8 with 256 threads is the form that fits every plane up to 40 x 40
+template <typename T, typename PT, int CGK, int NT>
+int sppf_fwd_launch(const void* x, void* y1, void* y2, void* y3, int ld, unsigned char* i1, unsigned char* i2, unsigned char* i3, int N, int H, int W,
+                           int C, size_t smem, hipStream_t st) {
+    static std::once_flag once;
+    std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)sppf_pool_fwd_kernel<T, PT, CGK, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); });
+    hipLaunchKernelGGL((sppf_pool_fwd_kernel<T, PT, CGK, NT>), dim3(N * (C / CGK)), dim3(NT), smem, st, (const T*)x, (T*)y1, (T*)y2, (T*)y3, ld, i1, i2, i3, H, W, C);
+    HDY_LAUNCH_CHECK("sppf_pool_fwd");
+    return HDY_OK;
+}
+
+template <typename T, int CGK, int NT>
+int sppf_bwd_launch(const void* g0, const void* g1, const void* g2, const void* g3, int ldg, const unsigned char* i1, const unsigned char* i2,
+                           const unsigned char* i3, void* dx, int lddx, int N, int H, int W, int C, int two_ix, size_t smem, hipStream_t st) {
+    static std::once_flag once;
+    std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)sppf_pool_bwd_kernel<T, CGK, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); });
+    hipLaunchKernelGGL((sppf_pool_bwd_kernel<T, CGK, NT>), dim3(N * (C / CGK)), dim3(NT), smem, st, (const T*)g0, (const T*)g1, (const T*)g2, (const T*)g3, ldg, i1, i2,
+                       i3, (T*)dx, lddx, H, W, C, two_ix);
+    HDY_LAUNCH_CHECK("sppf_pool_bwd");
+    return HDY_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -336,20 +380,20 @@ int hdy_sppf_pool_fwd(const void* x, void* y1, void* y2, void* y3, int ld, unsig
     HDY_ARG(x && y1 && y2 && y3 && N > 0 && H > 0 && W > 0 && C > 0, "sppf_pool_fwd: bad args");
     HDY_ARG(C % CG == 0 && ld >= C && ld % 4 == 0, "sppf_pool_fwd: C=%d must be a multiple of %d, ld >= C and a multiple of 4", C, CG);
     HDY_ARG((idx1 == nullptr) == (idx2 == nullptr) && (idx1 == nullptr) == (idx3 == nullptr), "sppf_pool_fwd: idx buffers all or none");
-    const size_t smem = (size_t)(H + 2 * PB) * (W + 2 * PB) * CG * (2 * sizeof(float) + (idx1 ? 1 : 0));
-    HDY_ARG(smem <= 150 * 1024, "sppf_pool_fwd: plane %dx%d does not fit LDS", H, W);
+    const size_t pix = (size_t)(H + 2 * PB) * (W + 2 * PB);
+    const size_t ix = idx1 ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == HDY_BF16) {
-        (void)hipFuncSetAttribute((const void*)sppf_pool_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        hipLaunchKernelGGL(sppf_pool_fwd_kernel<bf16_t>, dim3(N * (C / CG)), dim3(256), smem, st, (const bf16_t*)x, (bf16_t*)y1, (bf16_t*)y2,
-                           (bf16_t*)y3, ld, idx1, idx2, idx3, H, W, C);
-    } else {
-        (void)hipFuncSetAttribute((const void*)sppf_pool_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        hipLaunchKernelGGL(sppf_pool_fwd_kernel<float>, dim3(N * (C / CG)), dim3(256), smem, st, (const float*)x, (float*)y1, (float*)y2,
-                           (float*)y3, ld, idx1, idx2, idx3, H, W, C);
+        // bf16 planes, 32 channels per workgroup when they fit (20 x 20: 92 KB with the position plane)
+        if (C % 32 == 0 && pix * 32 * (2 * sizeof(bf16_t) + ix) <= 150 * 1024)
+            return sppf_fwd_launch<bf16_t, bf16_t, 32, 1024>(x, y1, y2, y3, ld, idx1, idx2, idx3, N, H, W, C, pix * 32 * (2 * sizeof(bf16_t) + ix), st);
+        const size_t smem = pix * CG * (2 * sizeof(float) + ix);
+        HDY_ARG(smem <= 150 * 1024, "sppf_pool_fwd: plane %dx%d does not fit LDS", H, W);
+        return sppf_fwd_launch<bf16_t, float, CG, 256>(x, y1, y2, y3, ld, idx1, idx2, idx3, N, H, W, C, smem, st);
     }
-    HDY_LAUNCH_CHECK("sppf_pool_fwd");
-    return HDY_OK;
+    const size_t smem = pix * CG * (2 * sizeof(float) + ix);
+    HDY_ARG(smem <= 150 * 1024, "sppf_pool_fwd: plane %dx%d does not fit LDS", H, W);
+    return sppf_fwd_launch<float, float, CG, 256>(x, y1, y2, y3, ld, idx1, idx2, idx3, N, H, W, C, smem, st);
 }
 
 int hdy_sppf_pool_bwd(const void* g0, const void* g1, const void* g2, const void* g3, int ldg, const unsigned char* idx1,
@@ -357,22 +401,17 @@ int hdy_sppf_pool_bwd(const void* g0, const void* g1, const void* g2, const void
                       void* stream) {
     HDY_ARG(g0 && g1 && g2 && g3 && idx1 && idx2 && idx3 && dx && N > 0 && H > 0 && W > 0, "sppf_pool_bwd: bad args");
     HDY_ARG(C % CG == 0 && ldg >= C && lddx >= C && ldg % 4 == 0 && lddx % 4 == 0, "sppf_pool_bwd: bad channel count / pitch");
-    const size_t plane = (size_t)(H + 2 * PB) * (W + 2 * PB) * CG;
+    const size_t pix = (size_t)(H + 2 * PB) * (W + 2 * PB);
+    hipStream_t st = (hipStream_t)stream;
+    // fp32 planes (the sums of the three levels are rounded once, at the end): 16 channels per workgroup when two position planes fit beside them
+    if (dtype == HDY_BF16 && C % 16 == 0 && pix * 16 * (2 * sizeof(float) + 2) <= 150 * 1024)
+        return sppf_bwd_launch<bf16_t, 16, 512>(g0, g1, g2, g3, ldg, idx1, idx2, idx3, dx, lddx, N, H, W, C, 1, pix * 16 * (2 * sizeof(float) + 2), st);
+    const size_t plane = pix * CG;
     const int two_ix = plane * (2 * sizeof(float) + 2) <= 150 * 1024;
     const size_t smem = plane * (2 * sizeof(float) + (two_ix ? 2 : 1));
     HDY_ARG(smem <= 150 * 1024, "sppf_pool_bwd: plane %dx%d does not fit LDS", H, W);
-    hipStream_t st = (hipStream_t)stream;
-    if (dtype == HDY_BF16) {
-        (void)hipFuncSetAttribute((const void*)sppf_pool_bwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        hipLaunchKernelGGL(sppf_pool_bwd_kernel<bf16_t>, dim3(N * (C / CG)), dim3(256), smem, st, (const bf16_t*)g0, (const bf16_t*)g1,
-                           (const bf16_t*)g2, (const bf16_t*)g3, ldg, idx1, idx2, idx3, (bf16_t*)dx, lddx, H, W, C, two_ix);
-    } else {
-        (void)hipFuncSetAttribute((const void*)sppf_pool_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        hipLaunchKernelGGL(sppf_pool_bwd_kernel<float>, dim3(N * (C / CG)), dim3(256), smem, st, (const float*)g0, (const float*)g1,
-                           (const float*)g2, (const float*)g3, ldg, idx1, idx2, idx3, (float*)dx, lddx, H, W, C, two_ix);
-    }
-    HDY_LAUNCH_CHECK("sppf_pool_bwd");
-    return HDY_OK;
+    if (dtype == HDY_BF16) return sppf_bwd_launch<bf16_t, CG, 256>(g0, g1, g2, g3, ldg, idx1, idx2, idx3, dx, lddx, N, H, W, C, two_ix, smem, st);
+    return sppf_bwd_launch<float, CG, 256>(g0, g1, g2, g3, ldg, idx1, idx2, idx3, dx, lddx, N, H, W, C, two_ix, smem, st);
 }
 
 int hdy_upsample2x_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, int dtype, void* stream) {
