@@ -121,12 +121,19 @@ class Program:
     """A launch list compiled for hdy_exec_run: segments of 64-bit words (one C call each) between the list's host callbacks.  It keeps the
     records (and through them every tensor and host array whose address the words hold) alive."""
 
+    _next_token = 0                     # the library's fork events are per (device, token): every program gets its own range of tokens
+
     def __init__(self, records):
         lib = _lib.load()
         self.records = records
         self.side = None
         self.segments = []              # ('words', ctypes array, count) | ('call', fn)
         words = []
+        ntok = 1 + max([r[3] for r in records if r[0] == '@fork'] + [r[2] for r in records if r[0] == '@join'] + [0])
+        if Program._next_token + ntok > 65536:
+            Program._next_token = 0     # (wrap: thousands of programs later, the first ones' lists are long gone or at worst share events in stream order)
+        self.token_base = Program._next_token
+        Program._next_token += ntok
 
         def item(rec):
             name, args = rec[0], rec[1]
@@ -151,10 +158,10 @@ class Program:
                     raise _lib.HdyError('a launch list forks onto one side stream')
                 self.side = rec[1]
                 if name == '@join':
-                    words.extend([EXEC_JOIN, 1, rec[2]])
+                    words.extend([EXEC_JOIN, 1, self.token_base + rec[2]])
                 else:
                     body = [w for r in rec[2] for w in item(r)]       # (a host callback inside a fork: not a launch record -> KeyError above)
-                    words.extend([EXEC_FORK, 2, rec[3], len(body)] + body)
+                    words.extend([EXEC_FORK, 2, self.token_base + rec[3], len(body)] + body)
             else:
                 words.extend(item(rec))
         flush()

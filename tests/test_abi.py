@@ -200,8 +200,10 @@ def test_program_words_follow_the_record_list(lib):
     op_s, op_a, op_f = (lib.hdy_exec_op(n) for n in (b'hdy_scale_inplace', b'hdy_add_inplace', b'hdy_bn_finalize_sums'))
     item_s = [op_s, 4, 0x1000, 7, 0x2000, _lib.BF16]
     item_a = [op_a, 7, 0x3000, 64, 0x4000, 64, (1 << 64) - 5, 64, _lib.BF16]
-    assert w0 == item_s + [ops.EXEC_FORK, 2, 9, len(item_a) + len(item_s)] + item_a + item_s
+    tb = prog.token_base                                                   # each program owns a range of the library's fork tokens
+    assert ops.Program([scale]).token_base == tb + 10
+    assert w0 == item_s + [ops.EXEC_FORK, 2, tb + 9, len(item_a) + len(item_s)] + item_a + item_s
     f32 = lambda v: struct.unpack('<I', struct.pack('<f', v))[0]
-    assert w1 == [op_f, 19, 0x10, 8, 0x20, 8, 8] + [0] * 8 + [f32(1e-3), f32(0.03)] + [0x30] * 4 + [ops.EXEC_JOIN, 1, 9]
+    assert w1 == [op_f, 19, 0x10, 8, 0x20, 8, 8] + [0] * 8 + [f32(1e-3), f32(0.03)] + [0x30] * 4 + [ops.EXEC_JOIN, 1, tb + 9]
     with pytest.raises(_lib.HdyError, match='cannot be listed'):
         ops.Program([('hdy_scale_inplace', (1, 2, 3), ())])              # one argument short
