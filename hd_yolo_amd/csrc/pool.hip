@@ -405,7 +405,7 @@ int hdy_sppf_pool_bwd(const void* g0, const void* g1, const void* g2, const void
     hipStream_t st = (hipStream_t)stream;
     // fp32 planes (the sums of the three levels are rounded once, at the end): 16 channels per workgroup when two position planes fit beside them
     if (dtype == HDY_BF16 && C % 16 == 0 && pix * 16 * (2 * sizeof(float) + 2) <= 150 * 1024)
-        return sppf_bwd_launch<bf16_t, 16, 512>(g0, g1, g2, g3, ldg, idx1, idx2, idx3, dx, lddx, N, H, W, C, 1, pix * 16 * (2 * sizeof(float) + 2), st);
+        return sppf_bwd_launch<bf16_t, 16, 1024>(g0, g1, g2, g3, ldg, idx1, idx2, idx3, dx, lddx, N, H, W, C, 1, pix * 16 * (2 * sizeof(float) + 2), st);
     const size_t plane = pix * CG;
     const int two_ix = plane * (2 * sizeof(float) + 2) <= 150 * 1024;
     const size_t smem = plane * (2 * sizeof(float) + (two_ix ? 2 : 1));
