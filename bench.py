@@ -159,6 +159,31 @@ def cpu_baseline(variant, nc, size, tiles=8, iters=16):
                       f'{tiles} tiles {size}x{size}, fwd+DetLoss+bwd, median of {iters} after 1 warm-up'}
 
 
+def cpu_nms_baseline(preds, nc, conf_thres, iou_thres, max_det):
+    """CPU leg of BASELINE configs[3] ("decode+NMS HIP path vs CPU torchvision.nms"): oracle/nms_ref.c — the scalar C restatement of the filter +
+    torchvision greedy NMS the reference calls (utils_general.py:299-356) — on a sample of the tiles the HIP kernel just processed (same decoded
+    candidates, same threshold).  One thread: the reference's per-image loop is serial too."""
+    from oracle import nms_ref
+    nms_ref.build()
+    nms_ref.nms_batched_c(preds[:1], nc, conf_thres, iou_thres, max_det)                  # load the library, touch the pages
+    t0 = time.perf_counter()
+    _, n_keep, _ = nms_ref.nms_batched_c(preds, nc, conf_thres, iou_thres, max_det)
+    dt = time.perf_counter() - t0
+    return {'us_per_tile': round(dt / len(preds) * 1e6, 1), 'cores': 1, 'kind': 'port', 'tiles': int(len(preds)), 'kept_per_tile': round(float(n_keep.mean()), 1),
+            'sample': f'oracle/nms_ref.c (filter + greedy NMS, scalar C), the first {len(preds)} of the batch\'s decoded tiles, {preds.shape[1]} candidates each'}
+
+
+def reference_c1():
+    """The reference's OWN code timed on BASELINE configs[0] (yolov5n, 2 classes, batch 4, 640x640, fp32, CPU) by scripts/time_reference_cpu.py in the
+    build container — /root/reference cannot travel to the GPU box, its JSON summary does."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'ref_cpu_c1.json')) as f:
+            r = json.load(f)
+        return {k: r[k] for k in ('train_tiles_per_s', 'eval_tiles_per_s', 'threads', 'torch', 'host') if k in r}
+    except (OSError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -238,7 +263,10 @@ def main():
                 g['momentum'] = hyp['warmup_momentum'] + (hyp['momentum'] - hyp['warmup_momentum']) * ni / nw
         it[0] += 1
 
+    nsteps_run = [0]
+
     def step():
+        nsteps_run[0] += 1
         warm()
         losses, _ = net(x, targets, compute_masks=False)
         loss = losses['det']['det_loss']
@@ -252,6 +280,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Pre-warm (not counted, not timed): a fresh box starts with cold clocks, cold caches and unbuilt plans, and the driver's command line fixes
+    # --warmup at a handful of steps (62 ms of GPU work in round 4: the timed region then saw 12.49 ms per step where the same build held 11.8-12.1 in
+    # longer runs).  Untimed steps run until >= PREWARM_S seconds of GPU work have gone by; they are the SAME step (forward + loss + backward + SGD
+    # launch) with the warm-up schedule held at iteration 0, where every learning rate is 0: the weights do not move, the counted warm-up and the
+    # timed steps that follow are what they would have been without it.  `steps` / `warmup` on the JSON line stay the requested values.
+    prewarm_target = float(os.environ.get('HDY_BENCH_PREWARM_S', '1.0'))
+    prewarm_s, prewarm_steps = 0.0, 0
+    if prewarm_target > 0:
+        step()                                    # builds the plans, loads the code objects: not counted towards the target
+        it[0] = 0
+        torch.cuda.synchronize()
+        while prewarm_s < prewarm_target and prewarm_steps < 2000:
+            tp = time.perf_counter()
+            for _ in range(10):
+                step()
+                it[0] = 0
+            torch.cuda.synchronize()
+            prewarm_s += time.perf_counter() - tp
+            prewarm_steps += 10
     for _ in range(args.warmup):
         step()
     fence()
@@ -298,12 +345,20 @@ def main():
                                    f'batch {args.batch}/GPU, train step = fwd + DetLoss + bwd + all-reduce + SGD(nesterov)',
                        'global_batch': args.batch * world, 'parallelism': f'dp{world}',
                        'world_size': dist.get_world_size() if (world > 1 or force_dist) else 1, 'backend': backend,
-                       'allreduce_calls_per_step': (round(net.reducer.calls / (args.steps + args.warmup), 2) if (world > 1 or force_dist) else 0),
+                       'allreduce_calls_per_step': (round(net.reducer.calls / max(nsteps_run[0], 1), 2) if (world > 1 or force_dist) else 0),
                        'param_checksum_spread_over_ranks': param_spread},
-            'final_loss': round(final_loss, 4),
+            'final_loss': round(final_loss, 4), 'prewarm_s': round(prewarm_s, 3), 'prewarm_steps': prewarm_steps,
         }
         from hd_yolo_amd import bench_util
+        from hd_yolo_amd.parallel import GradAllReduce
         plan = next(iter(model._eng().plans.values()))
+        # what one backward pass hands to RCCL when N > 1 (from the plan's "range is final" marks, hd_yolo_amd/parallel.py): printed at every N so that
+        # the first multi-GPU run checks itself — `allreduce_calls_per_step` (measured) must equal `calls_per_step` here and the bytes must add up to 4 x parameters
+        sends = GradAllReduce.expected_sends(plan.bucket_marks(), plan.grad_store.numel)
+        line['config']['allreduce_expected'] = {'calls_per_step': len(sends), 'mb_per_call': [round((b - a) * 4 / 2**20, 2) for a, b in sends],
+                                                'mb_per_step': round(sum(b - a for a, b in sends) * 4 / 2**20, 2)}
+        if world > 1 or force_dist:
+            line['config']['allreduce_mb_per_step'] = round(net.reducer.bytes / max(nsteps_run[0], 1) / 2**20, 2)
         fl, by = bench_util.plan_work(plan)
         ms = dt / args.steps * 1e3
         line['step'] = {'conv_tflop_per_step': round(fl / 1e12, 3), 'mfma_frac': round(fl / ms / 1e9 / PEAK_BF16_TFLOPS, 4),
@@ -326,11 +381,16 @@ def main():
             line['roofline_hbm'] = bench_util.hbm_kernel_roofline(plan, PEAK_HBM_GBS)
         if world == 1 and not args.no_infer and args.variant == 's' and args.batch == 64:
             try:
-                line['infer'] = bench_util.infer_benchmark('l', 128, 1024, 3, device)
+                line['infer'] = bench_util.infer_benchmark('l', 128, 1024, 3, device, cpu_nms=None if args.no_cpu_baseline else cpu_nms_baseline)
             except Exception as e:                                     # never lose the headline line to the side measurement
                 line['infer'] = {'error': repr(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.variant, args.nc, args.size)
+            ref = reference_c1()
+            if ref is not None:
+                line['cpu_baseline']['reference_c1'] = ref
+                line['cpu_baseline']['sample'] += ('; reference_c1 = the reference\'s own train.py:455-472 loop body / val forward on configs[0], timed by '
+                                                   'scripts/time_reference_cpu.py (profiles/ref_cpu_c1.json), other host')
         print(json.dumps(line), flush=True)
     if world > 1 or force_dist:
         dist.barrier()

@@ -9,7 +9,28 @@ import os
 # HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  RCCL brings its own streams: with the default the weight-gradient
 # side stream then shares a queue with the main stream and the two launch lists run one after the other (measured with one rank over
 # RCCL: 14.69 ms per train step against 13.82 with 8 queues).  Must be in the environment before the HIP runtime starts.
+_queues_preset = os.environ.get('GPU_MAX_HW_QUEUES')
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
+
+def _hip_runtime_already_up():
+    import sys
+    t = sys.modules.get('torch')
+    try:
+        return bool(t is not None and t.cuda.is_initialized())
+    except Exception:          # noqa: BLE001 — a torch without the cuda module, half-imported torch: nothing has started the runtime
+        return False
+
+
+if _hip_runtime_already_up() and (_queues_preset is None or int(_queues_preset or 0) < 8):
+    # the setdefault above is a no-op for a runtime that has already read its environment: say so LOUDLY, the symptom (the two launch lists of a
+    # training step running one after the other as soon as RCCL brings its streams, +6 % per step) is silent
+    import warnings
+    warnings.warn('hd_yolo_amd: the HIP runtime was initialised before this package was imported and GPU_MAX_HW_QUEUES was '
+                  f'{"unset (HIP default: 4)" if _queues_preset is None else _queues_preset} at that time.  With fewer than 8 hardware queues the '
+                  'weight-gradient stream shares a queue with the main stream once RCCL creates its own (multi-GPU runs): export '
+                  'GPU_MAX_HW_QUEUES=8 before the process touches the GPU, or import hd_yolo_amd before torch.cuda is initialised.',
+                  RuntimeWarning, stacklevel=2)
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL across processes needs it on this driver
 
 

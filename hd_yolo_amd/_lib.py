@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # HDY_LIB: load another build of the same ABI (kernel A/B experiments); it must still sit under csrc/build/
 LIB_PATH = os.path.join(_HERE, 'csrc', 'build', os.path.basename(os.environ.get('HDY_LIB', 'libhdyolo_hip.so')))
 
+ABI_VERSION = 5                   # = HDY_ABI_VERSION of the include/hdyolo.h that SIGNATURES below was written for (tests/test_abi.py holds the two together)
 F32, BF16 = 0, 1
 OK, EINVAL, EUNSUPPORTED = 0, -1, -2      # status codes (include/hdyolo.h); positive = hipError_t
 PACK_FWD, PACK_DGRAD, PACK_STEM = 0, 1, 2
@@ -150,6 +151,12 @@ def load():
             raise HdyError(f'{LIB_PATH} is missing: run `python -m hd_yolo_amd.build` (hipcc, gfx950). '
                            'hd_yolo_amd has no CPU fallback.')
         lib = ctypes.CDLL(LIB_PATH)
+        lib.hdy_version.restype, lib.hdy_version.argtypes = _I, []
+        got = lib.hdy_version()
+        if got != ABI_VERSION:
+            # SIGNATURES below is this revision's parameter lists: an older / newer build would receive shifted arguments instead of an error
+            raise HdyError(f'{LIB_PATH} was built for ABI revision {got}, this binding is written for {ABI_VERSION} (include/hdyolo.h HDY_ABI_VERSION): '
+                           'rebuild with `python -m hd_yolo_amd.build --force`')
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args

@@ -139,7 +139,7 @@ int hdy_get_option(const char* name) {
     return hdy_opt(i);
 }
 
-int hdy_version(void) { return 1; }
+int hdy_version(void) { return HDY_ABI_VERSION; }
 
 // the reciprocal the conv loader divides by (host-only; exported so that the identity can be tested without a GPU)
 int hdy_fastdiv_magic(unsigned d, unsigned* magic, int* shift) {

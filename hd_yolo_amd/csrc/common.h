@@ -70,6 +70,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+// One-time per-kernel setup that is bound to a DEVICE (hipFuncSetAttribute: dynamic LDS above 64 KB): once per process and device, not once per
+// process — a second device in the same process (one plan per device; the executor keeps per-device events for that case) would otherwise launch
+// without the attribute.
+struct PerDeviceOnce {
+    std::once_flag flag[16];
+    template <typename F> void run(F&& fn) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::call_once(flag[dev & 15], fn);
+    }
+};
+
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 

@@ -431,8 +431,8 @@ template <int KT, int CT, int BM, int NXB>
 int fused_launch(const FusedArgs& a, int grid, hipStream_t st) {
     constexpr size_t smem = fused_smem<KT, CT, BM, NXB>();
     static_assert(2 * smem <= 160 * 1024, "two workgroups per CU");
-    static std::once_flag attr_once;           // first launch of this instance on any thread
-    std::call_once(attr_once, [&] {
+    static PerDeviceOnce attr_once;           // first launch of this instance on any thread
+    attr_once.run([&] {
         (void)hipFuncSetAttribute((const void*)conv1x1_bwd_kernel<KT, CT, BM, NXB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     });
     hdy_note_dispatch(KT == 32 ? "conv1x1_bwd_32" : (KT == 64 ? "conv1x1_bwd_64" : "conv1x1_bwd_128"));

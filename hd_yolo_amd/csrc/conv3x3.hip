@@ -381,8 +381,8 @@ __global__ __launch_bounds__(NTHR, C == 32 ? 3 : 2) void conv3x3_c64_kernel(cons
 
 template <int C, int EPI, bool STATS>
 static void launch_c3(const ConvArgs& a, int grid, hipStream_t st) {
-    static std::once_flag attr_once;           // first launch of this instance on any thread
-    std::call_once(attr_once, [&] {
+    static PerDeviceOnce attr_once;           // first launch of this instance on any thread
+    attr_once.run([&] {
         (void)hipFuncSetAttribute((const void*)conv3x3_c64_kernel<C, EPI, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<C>::SMEM_B);
     });
     hdy_note_dispatch(C == 64 ? "conv3x3_c64" : "conv3x3_c32");

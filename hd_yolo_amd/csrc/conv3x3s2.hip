@@ -230,8 +230,8 @@ __global__ __launch_bounds__(NTHR, 3) void conv3x3s2_c32_kernel(const ConvArgs p
 
 template <int EPI, bool STATS>
 static void launch_s2(const ConvArgs& a, int grid, hipStream_t st) {
-    static std::once_flag attr_once;           // first launch of this instance on any thread
-    std::call_once(attr_once, [&] {
+    static PerDeviceOnce attr_once;           // first launch of this instance on any thread
+    attr_once.run([&] {
         (void)hipFuncSetAttribute((const void*)conv3x3s2_c32_kernel<EPI, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B);
     });
     hdy_note_dispatch("conv3x3s2_c32");

@@ -586,6 +586,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_deep_kernel(const ConvArgs p) {
         // sums against 5.8 us without)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");                            // the barrier builtin is IntrNoMem: keep the C++ `red[]` accesses below on this side of it
         float* red = (float*)smem;                                // [WM][BN][2]; the ring is free
 #pragma unroll
         for (int n = 0; n < NTQ; ++n)
@@ -605,6 +606,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_deep_kernel(const ConvArgs p) {
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");                            // (as above: the loads of `red[]` stay behind the barrier)
         for (int j = tid; j < 2 * BN; j += NTHR) {
             const int which = j / BN, c = j - which * BN;
             if (n0 + c < p.K) {
@@ -644,8 +646,8 @@ template <int BN, bool STATS, int EPI>
 int deep_launch(const ConvArgs& a, int grid, hipStream_t st) {
     constexpr size_t smem = deep_smem<BN>();
     static_assert(smem <= 160 * 1024, "LDS budget");
-    static std::once_flag attr_once;
-    std::call_once(attr_once, [&] {
+    static PerDeviceOnce attr_once;
+    attr_once.run([&] {
         (void)hipFuncSetAttribute((const void*)conv_deep_kernel<BN, STATS, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     });
     hipLaunchKernelGGL((conv_deep_kernel<BN, STATS, EPI>), dim3(grid), dim3(NTHR), smem, st, a);

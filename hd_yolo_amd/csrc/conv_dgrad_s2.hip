@@ -193,8 +193,8 @@ int hdy_dgrad3x3s2_try(const ConvArgs& a, int dtype, hipStream_t st, int* rc) {
             return 0;
     if (a.ldx % 8 || a.ldy % 8 || ((uintptr_t)a.x & 15) || ((uintptr_t)a.y & 15) || ((uintptr_t)a.w & 15)) return 0;
     const int tiles = a.N * (a.Ho / TH) * (a.Wo / TW);
-    static std::once_flag attr_once;           // first launch of this instance on any thread
-    std::call_once(attr_once, [&] {
+    static PerDeviceOnce attr_once;           // first launch of this instance on any thread
+    attr_once.run([&] {
         (void)hipFuncSetAttribute((const void*)dgrad3x3s2_k64c32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B);
     });
     const int grid = tiles < 512 ? tiles : 512;        // two 70 KB, 4-wave workgroups per CU

@@ -735,8 +735,8 @@ int launch(const ConvArgs& a, hipStream_t st) {
     for (int r = 0; r < a.nstat; ++r)
         HDY_ARG(a.stat[r].nslabs == grid, "conv: statistics request %d holds %d slabs, this launch writes %d", r, a.stat[r].nslabs, grid);
     const size_t smem = (size_t)NS * (BM * 128 + BN * 128) + (BN > 32 ? 2 * BN * sizeof(float) : 0);
-    static std::once_flag attr_once;           // first launch of this instance on any thread
-    std::call_once(attr_once, [&] {
+    static PerDeviceOnce attr_once;           // first launch of this instance on any thread
+    attr_once.run([&] {
         (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, OT, BM, BN, NS, STAT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     });
     {

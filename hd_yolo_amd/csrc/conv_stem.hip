@@ -221,8 +221,8 @@ template <int NT>
 int launch_nt(const ConvArgs& a, int grid, hipStream_t st) {
     const size_t smem = 2 * PATCH_B + (size_t)TOH * TOW * NT * 32 + (size_t)NT * 16 * 400;
     const int epi = a.act == 1 ? 2 : ((a.scale || a.shift) ? 1 : 0);
-    static std::once_flag attr_once;           // first launch of this instance on any thread
-    std::call_once(attr_once, [&] {
+    static PerDeviceOnce attr_once;           // first launch of this instance on any thread
+    attr_once.run([&] {
         (void)hipFuncSetAttribute((const void*)conv_stem_kernel<NT, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         (void)hipFuncSetAttribute((const void*)conv_stem_kernel<NT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         (void)hipFuncSetAttribute((const void*)conv_stem_kernel<NT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

@@ -289,8 +289,8 @@ int hdy_wgrad3x3_try(const void* x, int ldx, const void* dy, int lddy, int N, in
     a.nkb = pl.nkb; a.ncb = pl.ncb; a.nsplit = pl.nsplit;
     const int grid = pl.nkb * pl.ncb * pl.nsplit;
     constexpr int smem = 2 * W3_BUF;
-    static std::once_flag attr_once;           // first launch of this instance on any thread
-    std::call_once(attr_once, [&] {
+    static PerDeviceOnce attr_once;           // first launch of this instance on any thread
+    attr_once.run([&] {
         (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<64, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<64, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<32, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);

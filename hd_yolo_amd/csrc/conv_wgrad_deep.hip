@@ -323,8 +323,8 @@ int hdy_wgrad_deep_try(const void* x, int ldx, const void* dy, int lddy, int N, 
     hdy_magic((unsigned)C, &a.mg_c, &a.sh_c);
     hdy_magic((unsigned)S, &a.mg_tw, &a.sh_tw);
     const int grid = a.ktiles * a.qtiles * a.splits;
-    static std::once_flag attr_once;
-    std::call_once(attr_once, [&] {
+    static PerDeviceOnce attr_once;
+    attr_once.run([&] {
         (void)hipFuncSetAttribute((const void*)wgrad_deep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING);
     });
     hdy_note_dispatch("wgrad_deep");

@@ -127,9 +127,11 @@ int run_words(const u64* w, size_t n, hipStream_t main, hipStream_t side, hipStr
         const u64 op = w[i], nargs = w[i + 1];
         HDY_ARG(nargs <= 64 && i + 2 + nargs <= n, "exec: item at word %zu has %llu arguments, %zu words left", i, nargs, n - i - 2);
         const u64* a = w + i + 2;
+        const size_t item = i;                                   // the item's first word, for messages
         i += 2 + nargs;
         if (op == HDY_EXEC_FORK) {
-            HDY_ARG(!in_fork && nargs == 2 && side && i + a[1] <= n, "exec: bad fork at word %zu (nested, no side stream, or longer than the program)", i);
+            // a[1] <= n - i, not i + a[1] <= n: the sum wraps for a huge length word (i <= n holds here)
+            HDY_ARG(!in_fork && nargs == 2 && side && a[1] <= (u64)(n - i), "exec: bad fork at word %zu (nested, no side stream, or longer than the program)", item);
             TokenEvents ev;
             HDY_ARG(events_for(a[0], &ev) == HDY_OK, "exec: no events for fork token %llu", a[0]);
             HDY_HIP(hipEventRecord(ev.start, main));
@@ -139,7 +141,7 @@ int run_words(const u64* w, size_t n, hipStream_t main, hipStream_t side, hipStr
             HDY_HIP(hipEventRecord(ev.done, side));
             i += a[1];
         } else if (op == HDY_EXEC_JOIN) {
-            HDY_ARG(!in_fork && nargs == 1, "exec: bad join at word %zu", i);
+            HDY_ARG(!in_fork && nargs == 1, "exec: bad join at word %zu", item);
             TokenEvents ev;
             HDY_ARG(events_for(a[0], &ev) == HDY_OK, "exec: no events for join token %llu", a[0]);
             HDY_HIP(hipStreamWaitEvent(main, ev.done, 0));        // (an event never recorded: no wait)

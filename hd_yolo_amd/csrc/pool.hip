@@ -353,8 +353,8 @@ inline int sgrid(long long total) {
 template <typename T, typename PT, int CGK, int NT>
 int sppf_fwd_launch(const void* x, void* y1, void* y2, void* y3, int ld, unsigned char* i1, unsigned char* i2, unsigned char* i3, int N, int H, int W,
                            int C, size_t smem, hipStream_t st) {
-    static std::once_flag once;
-    std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)sppf_pool_fwd_kernel<T, PT, CGK, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); });
+    static PerDeviceOnce once;
+    once.run([] { (void)hipFuncSetAttribute((const void*)sppf_pool_fwd_kernel<T, PT, CGK, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); });
     hipLaunchKernelGGL((sppf_pool_fwd_kernel<T, PT, CGK, NT>), dim3(N * (C / CGK)), dim3(NT), smem, st, (const T*)x, (T*)y1, (T*)y2, (T*)y3, ld, i1, i2, i3, H, W, C);
     HDY_LAUNCH_CHECK("sppf_pool_fwd");
     return HDY_OK;
@@ -363,8 +363,8 @@ int sppf_fwd_launch(const void* x, void* y1, void* y2, void* y3, int ld, unsigne
 template <typename T, int CGK, int NT>
 int sppf_bwd_launch(const void* g0, const void* g1, const void* g2, const void* g3, int ldg, const unsigned char* i1, const unsigned char* i2,
                            const unsigned char* i3, void* dx, int lddx, int N, int H, int W, int C, int two_ix, size_t smem, hipStream_t st) {
-    static std::once_flag once;
-    std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)sppf_pool_bwd_kernel<T, CGK, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); });
+    static PerDeviceOnce once;
+    once.run([] { (void)hipFuncSetAttribute((const void*)sppf_pool_bwd_kernel<T, CGK, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); });
     hipLaunchKernelGGL((sppf_pool_bwd_kernel<T, CGK, NT>), dim3(N * (C / CGK)), dim3(NT), smem, st, (const T*)g0, (const T*)g1, (const T*)g2, (const T*)g3, ldg, i1, i2,
                        i3, (T*)dx, lddx, H, W, C, two_ix);
     HDY_LAUNCH_CHECK("sppf_pool_bwd");

@@ -272,8 +272,8 @@ int hdy_roi_align_bwd(const void* dout, float* dfeat_f32, int B, int H, int W, i
     const dim3 grid(R, (C + CB - 1) / CB);
     const int pp = P <= PM ? P : 1;
     const size_t smem = (size_t)(2 * PM * FT + PM * PM * CB + pp * FT * CB) * sizeof(float);        // Wy, Wx, D, Tm: 70 KB at P = 14
-    static std::once_flag attr_once;           // first launch of this instance on any thread
-    std::call_once(attr_once, [&] {
+    static PerDeviceOnce attr_once;           // first launch of this instance on any thread
+    attr_once.run([&] {
         (void)hipFuncSetAttribute((const void*)roi_align_bwd_tiled_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * PM * FT + PM * PM * CB + PM * FT * CB) * 4);
         (void)hipFuncSetAttribute((const void*)roi_align_bwd_tiled_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * PM * FT + PM * PM * CB + PM * FT * CB) * 4);
     });

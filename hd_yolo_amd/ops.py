@@ -9,6 +9,7 @@ device addresses.  Records are either executed at once (`run`) or stored in a st
 import ctypes
 import struct
 import os
+import threading
 
 import torch
 
@@ -121,19 +122,46 @@ class Program:
     """A launch list compiled for hdy_exec_run: segments of 64-bit words (one C call each) between the list's host callbacks.  It keeps the
     records (and through them every tensor and host array whose address the words hold) alive."""
 
-    _next_token = 0                     # the library's fork events are per (device, token): every program gets its own range of tokens
+    # the library's fork events are per (device, token): every live program owns its own range of the 65536 tokens (two programs sharing events
+    # could lose a fork dependency when they run on different stream pairs).  Ranges are handed out under a lock, returned by __del__, and an
+    # exhausted table is an error, never a silent wrap.
+    _TOKENS = 65536
+    _lock = threading.Lock()
+    _next_token = 0
+    _free = []                          # [(base, count)] of programs that are gone
+
+    @classmethod
+    def _take_tokens(cls, n):
+        with cls._lock:
+            for i, (base, cnt) in enumerate(cls._free):
+                if cnt >= n:
+                    if cnt == n:
+                        del cls._free[i]
+                    else:
+                        cls._free[i] = (base + n, cnt - n)
+                    return base
+            if cls._next_token + n > cls._TOKENS:
+                raise _lib.HdyError(f'launch-list programs: all {cls._TOKENS} fork tokens are held by live programs ({n} more wanted)')
+            base = cls._next_token
+            cls._next_token += n
+            return base
+
+    def __del__(self):
+        n = getattr(self, '_ntok', 0)
+        if n:
+            with Program._lock:
+                Program._free.append((self.token_base, n))
 
     def __init__(self, records):
         lib = _lib.load()
         self.records = records
+        self.nrec = len(records)        # Plan._replay recompiles when the list it was made from has changed length in place
         self.side = None
         self.segments = []              # ('words', ctypes array, count) | ('call', fn)
         words = []
         ntok = 1 + max([r[3] for r in records if r[0] == '@fork'] + [r[2] for r in records if r[0] == '@join'] + [0])
-        if Program._next_token + ntok > 65536:
-            Program._next_token = 0     # (wrap: thousands of programs later, the first ones' lists are long gone or at worst share events in stream order)
-        self.token_base = Program._next_token
-        Program._next_token += ntok
+        self.token_base = Program._take_tokens(ntok)
+        self._ntok = ntok
 
         def item(rec):
             name, args = rec[0], rec[1]

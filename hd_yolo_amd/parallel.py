@@ -77,6 +77,39 @@ class GradAllReduce:
         self.sent = []            # ranges already given to the communication stream in this backward pass
         self.pending = None       # a ready range not yet sent (too small on its own)
         self.calls = 0            # all_reduce calls issued (tests / diagnostics)
+        self.bytes = 0            # bytes handed to them
+
+    @classmethod
+    def expected_sends(cls, marks, numel, split=True):
+        """The all-reduce calls ONE backward pass issues for a plan whose marks (Plan.bucket_marks(): ranges in the order the backward
+        list completes them) cover a flat buffer of `numel` fp32 elements: [(a, b)] in issue order — the hold-back of ranges under
+        MIN_BYTES, the merge with a contiguous neighbour, the leftovers behind the list and the BUCKET_BYTES cut, exactly as bucket() /
+        __call__ / _send do them on a GPU.  bench.py prints it next to the measured count, so that the first run with N > 1 ranks checks itself."""
+        sent, pending = [], None
+        for a, b in marks:
+            p, pending = pending, None
+            if p is not None and p[1] == a:
+                a = p[0]
+            elif p is not None and p[0] == b:
+                b = p[1]
+            elif p is not None:
+                sent.append(p)
+            if (b - a) * 4 >= cls.MIN_BYTES:
+                sent.append((a, b))
+            else:
+                pending = (a, b)
+        if pending is not None:
+            sent.append(pending)
+        x = 0
+        for a, b in sorted(sent):
+            if a > x:
+                sent.append((x, a))
+            x = max(x, b)
+        if x < numel:
+            sent.append((x, numel))
+        if not split:                   # host tensors (gloo rehearsals on the CPU) go out uncut
+            return sent
+        return [(c, min(b, c + cls.BUCKET_BYTES // 4)) for a, b in sent for c in range(a, b, cls.BUCKET_BYTES // 4)]
 
     def _active(self):
         # HDY_FORCE_DIST=1: issue the collectives with one rank too (rehearsal of the N > 1 path over RCCL on a one-GPU box)
@@ -104,6 +137,7 @@ class GradAllReduce:
         else:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         self.calls += 1
+        self.bytes += t.numel() * t.element_size()
 
     def bucket(self, store, a, b, side_stream=None):
         """Engine bucket hook: gradient elements [a, b) of store.cur are final once the work issued so far has run."""

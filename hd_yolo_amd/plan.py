@@ -512,7 +512,7 @@ class Plan:
             # the list is static: compiled once into words for hdy_exec_run (one C call per stretch between host callbacks) and replayed
             progs = self.__dict__.setdefault('_progs', {})
             prog = progs.get(key)
-            if prog is None or prog.records is not recs:
+            if prog is None or prog.records is not recs or prog.nrec != len(recs):
                 prog = progs[key] = ops.Program(recs)
             return prog.run()
         g = self._graphs[key]
@@ -867,8 +867,13 @@ class Plan:
         for pos in sorted(by_pos, reverse=True):              # insert from the back so earlier positions stay valid
             for a, b in by_pos[pos]:
                 fn = (lambda a=a, b=b: self.bucket_hook(a, b, side.stream if side is not None else None) if self.bucket_hook else None)
+                fn.hdy_mark = (a, b)            # bucket_marks() reads the marks back in execution order
                 recs.insert(pos + 1, ('@call', fn))
                 self.grad_marks.append((pos + 1, a, b))
+
+    def bucket_marks(self):
+        """the "flat gradient range [a, b) is final" marks of the backward list, in the order the list reaches them"""
+        return [rec[1].hdy_mark for rec in (self.bwd or []) if rec[0] == '@call' and hasattr(rec[1], 'hdy_mark')]
 
     def _det_bias_tmp(self, u):
         if not hasattr(u, 'gbias_pad'):

@@ -43,6 +43,10 @@ extern "C" {
 #define HDY_ACT_RELU 2 /* the Mask-RCNN head's convolutions (row f2) */
 
 const char* hdy_last_error(void);
+/* ABI revision of THIS header: bumped whenever an entry point's parameter list, a structure or an option changes meaning.  hdy_version() returns the
+ * value the library was built with; a binding written against another revision must refuse the library (hd_yolo_amd/_lib.py:load does) — with
+ * plain pointers and sizes a mismatched parameter list would otherwise shift arguments silently. */
+#define HDY_ABI_VERSION 5
 int hdy_version(void);
 /* Which kernel ran: every launcher names the kernel family it picked ("igemm_128x128x2", "conv3x3_c64", "deep_256x128", "wgrad3x3", ...).
  * hdy_last_dispatch: the last pick on this thread; hdy_dispatch_log: every pick of every thread since hdy_dispatch_log_reset(), in launch

@@ -27,7 +27,7 @@ else:
     plan = next(iter(m._eng().plans.values()))
 torch.cuda.synchronize()
 
-from hd_yolo_amd.bench_util import describe  # noqa: E402
+from hd_yolo_amd.bench_util import describe, time_record  # noqa: E402
 
 rows = []
 for phase, recs in (('F', plan.fwd), ('B', plan.bwd or [])):
@@ -38,14 +38,7 @@ for phase, recs in (('F', plan.fwd), ('B', plan.bwd or [])):
         elif rec[0][0] != '@':
             flat.append(rec)
     for rec in flat:
-        for _ in range(2):
-            ops.run([rec])
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            ops.run([rec])
-        e1.record(); torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) / reps * 1e3
+        us = time_record(rec, reps)          # the same measurement as bench.py's `layers_3x3` rows: fastest of 5 blocks of `reps`
         d, fl, by = describe(rec)
         rows.append((phase, d, us, fl, by))
 tot = sum(r[2] for r in rows)

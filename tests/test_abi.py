@@ -33,7 +33,9 @@ def test_header_symbols_exported_and_bound(lib):
 
 
 def test_pure_host_queries(lib):
-    assert lib.hdy_version() == 1
+    # one ABI revision in three places: the header's macro, the library built from it, the binding's SIGNATURES (load() refuses any other library)
+    header = open(os.path.join(ROOT, 'include', 'hdyolo.h')).read()
+    assert int(re.search(r'#define\s+HDY_ABI_VERSION\s+(\d+)', header).group(1)) == _lib.ABI_VERSION == lib.hdy_version()
     assert lib.hdy_conv_out_dim(640, 6, 2, 2) == 320 and lib.hdy_conv_out_dim(80, 3, 2, 1) == 40
     assert lib.hdy_conv_mtiles(129) == 2
     # statistic slabs: one per 128 output pixels (generic kernel) or one per workgroup (filter-resident 3x3 C=64 kernel)
@@ -179,6 +181,14 @@ def test_launch_list_executor_table_and_malformed_programs(lib):
     assert run([0xF0F0F0F1, 2, 1, 1]) == _lib.EINVAL                           # a join takes one argument
     assert run([op, 4, 0, 16, 0, _lib.BF16]) == _lib.EINVAL                    # well formed: the entry point's own argument check answers (null pointer)
 
+    def run_side(words):                                                       # with a (never used) side stream: the host-side checks come first
+        arr = (ctypes.c_ulonglong * len(words))(*words)
+        return lib.hdy_exec_run(arr, len(words), None, ctypes.c_void_p(0x10))
+
+    # a fork whose length word is huge: `i + length` would wrap in 64 bits and pass a naive bound check
+    assert run_side([0xF0F0F0F0, 2, 1, (1 << 64) - 1]) == _lib.EINVAL and b'bad fork at word 0' in lib.hdy_last_error()
+    assert run_side([0xF0F0F0F0, 2, 1, 7, op, 4, 0, 16, 0, _lib.BF16]) == _lib.EINVAL and b'bad fork at word 0' in lib.hdy_last_error()   # one word longer than the program
+    assert run_side([0xF0F0F0F1, 2, 1, 1]) == _lib.EINVAL and b'bad join at word 0' in lib.hdy_last_error()                  # messages name the item's first word
 
 def test_program_words_follow_the_record_list(lib):
     """ops.Program (the Python side of hdy_exec_run) on a hand-made record list, no GPU: one segment per stretch between host callbacks, fork bodies
@@ -201,7 +211,10 @@ def test_program_words_follow_the_record_list(lib):
     item_s = [op_s, 4, 0x1000, 7, 0x2000, _lib.BF16]
     item_a = [op_a, 7, 0x3000, 64, 0x4000, 64, (1 << 64) - 5, 64, _lib.BF16]
     tb = prog.token_base                                                   # each program owns a range of the library's fork tokens
-    assert ops.Program([scale]).token_base == tb + 10
+    keep = ops.Program([scale])
+    assert keep.token_base == tb + 10                                      # a live program's range is its own ...
+    del keep
+    assert ops.Program([scale]).token_base == tb + 10                      # ... and returns to the table with it
     assert w0 == item_s + [ops.EXEC_FORK, 2, tb + 9, len(item_a) + len(item_s)] + item_a + item_s
     f32 = lambda v: struct.unpack('<I', struct.pack('<f', v))[0]
     assert w1 == [op_f, 19, 0x10, 8, 0x20, 8, 8] + [0] * 8 + [f32(1e-3), f32(0.03)] + [0x30] * 4 + [ops.EXEC_JOIN, 1, tb + 9]

@@ -179,6 +179,7 @@ DEEP_CASES = [
     (1, 24, 56, 192, 128, 3, 1, 1),      # three channel blocks per tap
     (3, 40, 40, 256, 512, 1, 1, 0),      # 1x1: four K-tiles per output tile, the stream runs across tiles
     (1, 16, 16, 128, 256, 1, 1, 0),      # exactly one row tile
+    (1, 16, 16, 192, 128, 1, 1, 0),      # one tile per workgroup and three K-tiles (with the cases above: K loops of 1, 2 and 3 in front of the statistics tail)
     (2, 48, 48, 128, 256, 3, 2, 1),      # stride-2 forward; its data gradient is the four-class walk on the deep pipeline (1 + 2 + 2 + 4 taps)
     (2, 40, 40, 256, 512, 3, 2, 1),      # ... with two 128-wide column tiles (one 256-wide)
     (1, 36, 44, 128, 128, 3, 2, 1),      # ... 396 class pixels: a ragged second row tile

@@ -118,3 +118,48 @@ def test_bucket_bounds_cover_exactly():
             assert all(x[1] == y[0] for x, y in zip(b, b[1:]))
             assert all(lo < hi for lo, hi in b)
             assert len(b) <= max(nb, 1)
+
+
+def test_expected_sends_is_what_the_reducer_issues():
+    """GradAllReduce.expected_sends (what bench.py prints as `allreduce_expected`) against the calls the reducer really makes for the same marks:
+    ranges under MIN_BYTES held back and merged with a contiguous neighbour, a range kept back that is NOT contiguous sent on its own, leftovers
+    behind the list — on host tensors (no BUCKET_BYTES cut), with a recording stand-in for the collective."""
+    n = 5_000_000
+    mb = lambda x: int(x * (1 << 20)) // 4          # noqa: E731 — megabytes -> fp32 elements
+    # completion order of a backward list: from the end of the buffer; one small range (merges with the next), one small non-contiguous range
+    marks, hi = [], n
+    for size in (mb(6.5), mb(1.0), mb(5.0), mb(0.5)):
+        marks.append((hi - size, hi))
+        hi -= size
+    marks.append((mb(0.25), mb(0.75)))                # not contiguous with the range kept back: that one goes out alone
+    store = _Store(n)
+    got = []
+    red = parallel.GradAllReduce(reduce_fn=lambda t: got.append((t.storage_offset(), t.storage_offset() + t.numel())))
+    for a, b in marks:
+        red.bucket(store, a, b)
+    red(store)
+    want = parallel.GradAllReduce.expected_sends(marks, n, split=False)
+    assert got == want, (got, want)
+    covered = sorted(got)
+    assert covered[0][0] == 0 and covered[-1][1] == n and all(x[1] == y[0] for x, y in zip(covered, covered[1:]))      # tiles the buffer exactly once
+    assert red.calls == len(want) and red.bytes == 4 * n
+    # the GPU path cuts a call at BUCKET_BYTES: same coverage, no call above the cap
+    cut = parallel.GradAllReduce.expected_sends([(0, 40_000_000)], 40_000_000)
+    assert max(b - a for a, b in cut) * 4 <= parallel.GradAllReduce.BUCKET_BYTES and sum(b - a for a, b in cut) == 40_000_000
+
+
+def test_late_hw_queue_setting_warns_loudly():
+    """hd_yolo_amd/__init__.py: GPU_MAX_HW_QUEUES only counts if it is in the environment before the HIP runtime starts.  A caller that initialised
+    torch.cuda first gets a RuntimeWarning instead of two silently serialised launch lists under RCCL."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ('import sys, warnings, torch\n'
+            'torch.cuda.is_initialized = lambda: True\n'            # stands in for a caller that touched the GPU before the import
+            'warnings.simplefilter("always")\n'
+            'import hd_yolo_amd\n')
+    env = {k: v for k, v in os.environ.items() if k != 'GPU_MAX_HW_QUEUES'}
+    p = subprocess.run([sys.executable, '-c', code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and 'GPU_MAX_HW_QUEUES' in p.stderr and 'RuntimeWarning' in p.stderr, p.stderr[-2000:]
+    p = subprocess.run([sys.executable, '-c', code], cwd=root, env=dict(env, GPU_MAX_HW_QUEUES='8'), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and 'GPU_MAX_HW_QUEUES' not in p.stderr, p.stderr[-2000:]
