@@ -557,8 +557,9 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const hdy_pack_desc* __
 
 static inline void wgrad_tile(int K, int Q, int dtype, int* sd, int* sx) {
     const int TK = dtype == HDY_BF16 ? 64 : 32;
-    *sd = K > TK ? 2 : 1;
-    *sx = Q > TK ? 2 : 1;
+    const bool small = hdy_opt(HDY_OPT_WGRAD_TILE) == 64;        // measurement switch (profiles/r05_wgrad_splits_ab.txt)
+    *sd = (K > TK && !small) ? 2 : 1;
+    *sx = (Q > TK && !small) ? 2 : 1;
 }
 
 int hdy_wgrad_plan(int K, int Q, long long P, int dtype, int* splits, int* pix_per_split) {

@@ -124,7 +124,11 @@ def _iou_matrix(a, b):
 
 # fraction of the reference's kept detections (fp32 CPU run of the reference's own code) that the bf16 network reproduces: a detection of the same
 # label at IoU >= 0.9.  Measured on MI355X first, then pinned a few points below (see the test's docstring); the floor is the assertion.
-BF16_DETECTION_RECALL = {'c1_640': float(os.environ.get('HDY_BF16_RECALL_C1', '0.0')), 's_640': float(os.environ.get('HDY_BF16_RECALL_S', '0.0'))}
+# Measured (MI355X, round 5): yolov5n / C1 0.996 per tile (0.993-0.997), mean best IoU 0.990; yolov5s 0.367 (0.35 / 0.383), mean best IoU 0.79 — with
+# synth_state_dict's gain the 8-class yolov5s' objectness logits are nearly flat over a tile's 25 200 candidates, so WHICH 300 survive the
+# threshold-and-NMS is decided by logit differences below bf16's resolution: the same sensitivity test_train_step_bf16_is_close_to_fp32 documents
+# for its gradients.  The floors sit a few points under the measurements.
+BF16_DETECTION_RECALL = {'c1_640': 0.97, 's_640': 0.30}
 
 
 @pytest.mark.parametrize('tag,variant', [('c1_640', 'n'), ('s_640', 's')])
@@ -140,13 +144,16 @@ def test_full_size_eval_bf16_detections_against_reference_golden(golden_dir, tag
     batch, size, nc = (int(v) for v in g['meta'])
     model = build(variant, nc, synth.make_hyp(conf_thres=float(g['conf_thres']))).eval().half()
     x = synth.synth_images(batch, size, seed=7).to(DEV)
-    _lib.dispatch_log(reset=True)
-    with torch.no_grad():
-        _, outputs = model(x)
-    log = set(_lib.dispatch_log(reset=True))
+    # a 2-tile batch has 50 row tiles where the bench's 64 tiles have 1 600: HDY_DEEP_MIN_TILES = 1 gives the wide layers to the deep-pipelined kernel
+    # the benchmark runs them on (set before the plan is built: the switch also steers its sizing queries)
+    with _lib.option('HDY_DEEP_MIN_TILES', 1):
+        _lib.dispatch_log(reset=True)
+        with torch.no_grad():
+            _, outputs = model(x)
+        log = set(_lib.dispatch_log(reset=True))
     if variant == 's':
         assert any(n.startswith('deep_256x') for n in log) and 'conv3x3_c64' in log, sorted(log)
-    fracs, ious = [], []
+    fracs, half, ious = [], [], []
     for b in range(batch):
         o = outputs[b]['det']
         rb, rl = g[f'out_{b}_boxes'], g[f'out_{b}_labels']
@@ -156,9 +163,10 @@ def test_full_size_eval_bf16_detections_against_reference_golden(golden_dir, tag
         iou[rl[:, None] != gl[None, :]] = 0.0
         best = iou.max(1)
         fracs.append(float((best >= 0.9).mean()))
+        half.append(float((best >= 0.5).mean()))
         ious.append(float(best.mean()))
     frac = float(np.mean(fracs))
-    print(f'bf16 detections vs reference fp32 goldens [{tag}]: recall@IoU0.9 per tile {[round(f, 3) for f in fracs]} mean {frac:.3f}, '
+    print(f'bf16 detections vs reference fp32 goldens [{tag}]: recall@IoU0.9 per tile {[round(f, 3) for f in fracs]} mean {frac:.3f}, recall@IoU0.5 {np.mean(half):.3f}, '
           f'mean best IoU {np.mean(ious):.3f}, kept {[len(outputs[b]["det"]["boxes"]) for b in range(batch)]}')
     assert frac >= BF16_DETECTION_RECALL[tag], (frac, BF16_DETECTION_RECALL[tag])
 
