@@ -403,6 +403,7 @@ __global__ __launch_bounds__(2 * BM, (BM == 256 || BN == 128 || STAT) ? 2 : (BN 
             coef_ntile = ntile;
         }
         OT* __restrict__ y = (OT*)p.y;
+        const bool vec4_rows = sizeof(OT) == 4 && (((uintptr_t)p.y | (uintptr_t)p.res) & 15) == 0 && p.ldy % 4 == 0 && (!p.res || p.ldr % 4 == 0);
         if (VEC_OUT && p.vec_out) {
             // stage RPP rows of the bf16 tile at a time in the A part of the finished stage; 8-byte slots XORed with a row key keep the 16 pixel lanes of a
             // write on different slots (a ds_write_b64 is banked over 16 consecutive lanes and 32 banks: the key takes all 16 rows apart — row & 15, or
@@ -557,19 +558,42 @@ __global__ __launch_bounds__(2 * BM, (BM == 256 || BN == 128 || STAT) ? 2 : (BN 
             OT* yrow = y + opix * p.ldy;
             const OT* rrow = p.res ? (const OT*)p.res + opix * p.ldr : nullptr;
 #pragma unroll
-            for (int b = 0; b < NT; ++b)
+            for (int b = 0; b < NT; ++b) {
+                const int kc0 = n0 + wn * (BN / 2) + b * 16 + fq * 4;
+                float v4[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int kc = n0 + wn * (BN / 2) + b * 16 + fq * 4 + r;
-                    if (kc >= p.K) continue;
+                    const int kc = kc0 + r;
                     float v = acc[a][b][r];
-                    if (affine) v = COEF_LDS ? v * coef[kc - n0] + coef[BN + kc - n0] : v * sc_reg[r] + sh_reg[r];
-                    if (p.act == 1) v = silu_f(v);
-                    else if (p.act == 2) v = fmaxf(v, 0.0f);
+                    if (kc < p.K) {
+                        if (affine) v = COEF_LDS ? v * coef[kc - n0] + coef[BN + kc - n0] : v * sc_reg[r] + sh_reg[r];
+                        if (p.act == 1) v = silu_f(v);
+                        else if (p.act == 2) v = fmaxf(v, 0.0f);
+                    }
+                    v4[r] = v;
+                }
+                if constexpr (sizeof(OT) == 4) {
+                    // fp32 rows (detection logits, fp32 parity mode): one 16-byte store per lane where its four channels are all real and the row is
+                    // 16-byte aligned — the scalar form below issued four 4-byte stores per lane, 64-byte runs per wave instruction (round 5: the
+                    // detection convolutions, K = 39 in 40-float rows, ran at 0.35 of their HBM bound)
+                    if (vec4_rows && kc0 + 4 <= p.K) {
+                        f32x4 o = {v4[0], v4[1], v4[2], v4[3]};
+                        if (rrow) o += *(const f32x4*)((const float*)rrow + kc0);
+                        if (p.accumulate) o += *(const f32x4*)((const float*)yrow + kc0);
+                        *(f32x4*)((float*)yrow + kc0) = o;
+                        continue;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kc = kc0 + r;
+                    if (kc >= p.K) continue;
+                    float v = v4[r];
                     if (rrow) v += to_f32<OT>(rrow[kc]);
                     if (p.accumulate) v += to_f32<OT>(yrow[kc]);
                     yrow[kc] = from_f32<OT>(v);
                 }
+            }
         }
         return false;
     };

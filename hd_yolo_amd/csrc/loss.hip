@@ -340,6 +340,7 @@ __global__ void final_kernel(const LossArgs p) {
 template <typename T>
 __global__ __launch_bounds__(256) void scale_kernel(T* p, size_t n, const float* scale) {
     const float s = *scale;
+    if (s == 1.0f) return;          // the usual upstream gradient of `loss.backward()`: x * 1.0f == x for every bf16 / fp32 value, so nothing to do (20 us for the 43 MB of logits gradients)
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         p[i] = from_f32<T>(to_f32<T>(p[i]) * s);
 }

@@ -35,6 +35,11 @@ SKIP_WGRAD = os.environ.get('HDY_SKIP_WGRAD') == '1'     # measurement only: no 
 PRODUCER_STATS = os.environ.get('HDY_PRODUCER_STATS', 'fused')       # 'fused': statistics served by the fused 1x1 backward kernel only (train step 13.47 vs 13.54 ms off); '1': by dgrad epilogues too (slower); '0': off
 STEM_FUSED = os.environ.get('HDY_STEM_FUSED', '1') == '1'   # the stem's weight gradient applies its unit's BatchNorm / SiLU backward itself (no dy tensor)
 FUSED_1X1 = os.environ.get('HDY_FUSED_1X1', '1') == '1'     # BN-apply + wgrad + dgrad of eligible 1x1 units in one kernel (conv1x1_bwd.hip)
+# probe, off: the weight re-pack on a second stream beside the input conversion (both are needed in front of the first convolution, neither depends on
+# the other).  Measured round 5, one box, alternating x3: 11.813 / 11.799 / 11.793 ms per step with it, 11.673 / 11.665 / 11.649 without — the two
+# cross-stream dependencies cost the main queue more than the 50-us gather they hide
+PACK_SIDE = os.environ.get('HDY_PACK_SIDE', '0') == '1'
+FORK_MIN_PIXELS = int(os.environ.get('HDY_FORK_MIN_PIXELS', '0'))     # probe: weight gradients of layers with fewer output pixels run inline on the main stream (no fork marker)
 GRAD_BUCKET_BYTES = int(os.environ.get('HDY_GRAD_BUCKET_MB', '6')) << 20      # granularity of the "these gradients are final" marks
 
 
@@ -392,6 +397,7 @@ class Plan:
         self.dy_ring = [self._new(max_dy) for _ in range(DY_RING if SIDE_WGRAD else 1)]
         self.dy = self.dy_ring[0]
         self.wg_ws = self._new(max_wg // 4 + 16, dtype=f32)
+        self.wg_ws_main = self._new(max_wg // 4 + 16, dtype=f32) if (FORK_MIN_PIXELS > 0 and SIDE_WGRAD) else self.wg_ws
         self.bn_c12 = self._new(2, kmax if False else max(u.K for u in self.units if isinstance(u, ConvUnit)), dtype=f32)     # c1 / c2 of the unit in flight
         self.f1_ws = self._new(max_f1 // 4 + 16, dtype=f32)      # weight-gradient slabs of the fused 1x1 backward (main stream: not shared with wg_ws)
         self.bn_ws = self._new(max_bnws, dtype=f32)
@@ -555,11 +561,24 @@ class Plan:
             images = images.float().contiguous()
         assert tuple(images.shape) == (self.B, self.Cin, self.H, self.W), (images.shape, self.B, self.H, self.W)
         assert images.shape[1] == self.Cin
+        pack_side = self.training and PACK_SIDE
+        if pack_side:
+            # the per-step weight re-pack (one launch, ~50 us of gathers at yolov5s) depends on the optimizer's update, not on the images: it runs on a
+            # second stream beside the input conversion (an HBM stream of ~90 us) and joins in front of the first convolution
+            main = torch.cuda.current_stream(self.device)
+            if self.__dict__.get('_pack_stream') is None:
+                self._pack_stream = torch.cuda.Stream(device=self.device)
+            self._pack_stream.wait_stream(main)
+            with torch.cuda.stream(self._pack_stream):
+                self.packs.run(skip_unchanged=False)
         if self.input is None:
             ops.run([ops.rec_stem_prep(images, self.prep)])
         else:
             ops.run([ops.rec_nchw_to_nhwc(images, self.input.t())])
-        self.packs.run(skip_unchanged=not self.training)
+        if pack_side:
+            main.wait_stream(self._pack_stream)
+        else:
+            self.packs.run(skip_unchanged=not self.training)
         self.bn_eval.run(skip_unchanged=not self.training)
         self._replay('fwd', self.fwd)
         if self.training:
@@ -616,9 +635,15 @@ class Plan:
         side = ops.SideStream(self.device) if SIDE_WGRAD else None
         nfork = [0]
 
-        def wgrad(rec, reads_dy_slot=None):
+        def wgrad(rec, reads_dy_slot=None, pixels=None):
             if SKIP_WGRAD:          # timing experiment only (gradients wrong): what the step costs without the weight-gradient stream
                 return
+            if callable(rec):       # rec(workspace): an inline launch must not share the side stream's split-slab workspace
+                inline = side is None or (pixels is not None and pixels < FORK_MIN_PIXELS)
+                rec = rec(self.wg_ws_main if (inline and side is not None) else self.wg_ws)
+                if inline:
+                    recs.append(rec)
+                    return
             if side is None:
                 recs.append(rec)
                 return
@@ -687,7 +712,7 @@ class Plan:
                 gb = self._grad_views(u.conv.bias)
                 recs.append(ops.rec_copy_f32(tmp[:u.K], gb))                                    # Kp-padded column sums -> the bias gradient
                 gw = self._grad_views(u.conv.weight)
-                wgrad(ops.rec_conv_wgrad(x.t(), u.gdet, gw, None, 1, 1, 1, 0, self.wg_ws))
+                wgrad(lambda ws, x=x, u=u, gw=gw: ops.rec_conv_wgrad(x.t(), u.gdet, gw, None, 1, 1, 1, 0, ws), pixels=x.n * x.h * x.w)
                 if not up(x):
                     continue
                 self.packs.add(u.conv.weight, None, 1, 0, ops.PACK_DGRAD, u.wpd, K=u.Kp)
@@ -825,7 +850,8 @@ class Plan:
                                                         self.wg_ws))
                     continue
                 if want_w:
-                    wgrad(ops.rec_conv_wgrad(x, dy, ga, gb, u.k, u.k, u.s, u.p, self.wg_ws, stem_hw=stem_hw), reads_dy_slot=slot)
+                    wgrad(lambda ws, x=x, dy=dy, ga=ga, gb=gb, u=u, stem_hw=stem_hw: ops.rec_conv_wgrad(x, dy, ga, gb, u.k, u.k, u.s, u.p, ws, stem_hw=stem_hw),
+                          reads_dy_slot=slot, pixels=M)
                 if want_x:
                     mk = (lambda st, u=u, dy=dy, xv=xv, acc=acc: ops.rec_conv_dgrad(dy, u.wpd, xv.g(), u.k, u.k, u.s, u.p, accumulate=acc, stats=st))
                     recs.append(mk(None))
