@@ -95,7 +95,7 @@ def make_optimizer(model, hyp, batch_total):
 def pmc_traffic():
     """HBM bytes per launch of the roofline kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, see
     profiles/r03_conv3x3_pmc.json and scripts/roofline_kernel.py); None when the file is absent."""
-    for name in ('r04_conv3x3_pmc.json', 'r03_conv3x3_pmc.json', 'r02_conv3x3_pmc.json'):
+    for name in ('r05_conv3x3_pmc.json', 'r04_conv3x3_pmc.json', 'r03_conv3x3_pmc.json'):
         try:
             with open(os.path.join(ROOT, 'profiles', name)) as f:
                 return json.load(f)['traffic_bytes_per_launch']
@@ -367,7 +367,7 @@ def main():
         # measured HBM bytes of the whole step (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE over 13 steps, scripts/step_traffic.sh) against the
         # algorithmic bytes: well above 1 = wasted re-reads.  From the committed summary of the same command (PMC passes cannot run inside the timed process).
         pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles')
-        tj = next((n for n in ('r04_step_traffic.json', 'r03_step_traffic.json') if os.path.exists(os.path.join(pdir, n))), None)
+        tj = next((n for n in ('r05_step_traffic.json', 'r04_step_traffic.json', 'r03_step_traffic.json') if os.path.exists(os.path.join(pdir, n))), None)
         if args.variant == 's' and args.batch == 64 and args.size == 640 and tj:
             tr = json.load(open(os.path.join(pdir, tj)))
             line['step'].update(traffic_gb_per_step=tr['hbm_gb_per_step'], traffic_ratio=round(tr['hbm_gb_per_step'] / (by / 1e9), 3),

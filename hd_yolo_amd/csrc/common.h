@@ -22,8 +22,8 @@ enum HdyOption {
     HDY_OPT_NO_CLASS_WALK,     // HDY_NO_CLASS_WALK: stride-2 dgrad as four launches instead of one class-walking launch
     HDY_OPT_NO_CONV3X3,        // HDY_NO_CONV3X3: filter-resident 3x3 kernel off (generic implicit GEMM instead)
     HDY_OPT_C3_GRID,           // HDY_C3_GRID: workgroups of the filter-resident 3x3 kernel (0 = default)
-    HDY_OPT_NO_CONV3X3S2,      // HDY_NO_CONV3X3S2: patch-resident 3x3 / stride-2 forward off
-    HDY_OPT_NO_DGRAD_S2,       // HDY_NO_DGRAD_S2: patch-resident stride-2 data gradient off
+    HDY_OPT_NO_CONV3X3S2,      // HDY_NO_CONV3X3S2: patch-resident 3x3 / stride-2 forward off (1: both forms, 2: the 64 -> 128 form only)
+    HDY_OPT_NO_DGRAD_S2,       // HDY_NO_DGRAD_S2: patch-resident stride-2 data gradient off (1: both forms, 2: the 64 <- 128 form only)
     HDY_OPT_TILE_INTERLEAVE,   // HDY_TILE_INTERLEAVE: tile order of the generic kernel (bit 0: column tiles, bit 1: parity classes)
     HDY_OPT_NO_BIG_TILES,      // HDY_NO_BIG_TILES: never the 256-row tile of the generic kernel
     HDY_OPT_NO_STEM_KERNEL,    // HDY_NO_STEM_KERNEL: patch-resident stem forward off

@@ -2,7 +2,7 @@
 # Copy the summaries that scripts/collect_profiles.sh left under gpurun_out/prof_<round>/ into profiles/<round>_* (the tracked, judged copies):
 #   bash scripts/publish_profiles.sh r04
 set -e
-R=${1:-r04}
+R=${1:-r05}
 O=gpurun_out/prof_$R
 grep "^{" $O/bench.log | tail -1 > profiles/${R}_bench.json
 cp $O/bench/bench_kernel_stats.csv profiles/${R}_bench_kernel_stats.csv

@@ -66,6 +66,7 @@ CONV_CASES = [
     (2, 48, 48, 128, 256, 3, 2, 1),      # two column tiles per class
     (3, 40, 40, 256, 512, 1, 1, 0),
     (2, 32, 64, 32, 64, 3, 2, 1),        # the patch-resident stride-2 data gradient (dx 32 <- dy 64 channels, dy grid 16 x 32 = 2 x 2 tiles)
+    (2, 32, 64, 64, 128, 3, 2, 1),       # ... its 64 <- 128 form (two dy planes, eight waves): dy grid 16 x 32 = 2 x 2 tiles
     (2, 24, 24, 16, 32, 3, 2, 1),        # stride-2 dgrad over 32 gradient channels: class walk with k-blocks that straddle taps
     (1, 20, 28, 32, 48, 3, 2, 1),        # ... over 48
     (2, 20, 20, 128, 128, 3, 1, 1),      # wide 3x3 / stride 1: one column tile
@@ -95,6 +96,8 @@ def expected_dispatch(case):
             dgrad = 'conv3x3_c%d' % K
     if R == 3 and stride == 2 and C == 32 and K == 64 and H % 16 == 0 and W % 64 == 0:
         fwd, dgrad = 'conv3x3s2_c32', 'dgrad3x3s2_k64c32'
+    if R == 3 and stride == 2 and C == 64 and K == 128 and H % 8 == 0 and W % 32 == 0:
+        fwd, dgrad = 'conv3x3s2_c64', 'dgrad3x3s2_k128c64'
     if R == 3 and stride == 1 and C % 32 == 0 and K % 32 == 0 and C <= 256 and K <= 256:
         wgrad = 'wgrad3x3'
     return fwd, dgrad, wgrad
@@ -849,6 +852,8 @@ AB_CASES = [
     ('HDY_NO_CONV3X3S2', 'conv3x3s2_c32', 'fwd', 6, 256, 256, 32, 64, 2),          # 1536 tiles of 4x16 outputs on 768 workgroups
     ('HDY_NO_DGRAD_S2', 'dgrad3x3s2_k64c32', 'dgrad', 16, 256, 256, 32, 64, 2),    # 1024 dy tiles of 8x16 on 512 workgroups
     ('HDY_NO_CONV3X3', 'conv3x3_c64', 'dgrad', 8, 128, 128, 64, 64, 1),
+    ('HDY_NO_DGRAD_S2', 'dgrad3x3s2_k128c64', 'dgrad', 6, 256, 256, 64, 128, 2),   # 1536 dy tiles of 4x16 on 512 workgroups
+    ('HDY_NO_CONV3X3S2', 'conv3x3s2_c64', 'fwd', 6, 256, 256, 64, 128, 2),         # 1536 tiles of 4x16 outputs on 256 eight-wave workgroups
 ]
 
 
