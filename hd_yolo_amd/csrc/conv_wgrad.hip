@@ -555,9 +555,11 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const hdy_pack_desc* __
 
 }  // namespace
 
-static inline void wgrad_tile(int K, int Q, int dtype, int* sd, int* sx) {
+static inline void wgrad_tile(int K, int Q, long long P, int dtype, int* sd, int* sx) {
     const int TK = dtype == HDY_BF16 ? 64 : 32;
-    const bool small = hdy_opt(HDY_OPT_WGRAD_TILE) == 64;        // measurement switch (profiles/r05_wgrad_splits_ab.txt)
+    // measurement switch (profiles/r05_wgrad_splits_ab.txt): 64 = 64 x 64 blocks everywhere, N > 64 = only for layers with at most N pixels
+    const int opt = hdy_opt(HDY_OPT_WGRAD_TILE);
+    const bool small = opt == 64 || (opt > 64 && P <= opt);
     *sd = (K > TK && !small) ? 2 : 1;
     *sx = (Q > TK && !small) ? 2 : 1;
 }
@@ -565,7 +567,7 @@ static inline void wgrad_tile(int K, int Q, int dtype, int* sd, int* sx) {
 int hdy_wgrad_plan(int K, int Q, long long P, int dtype, int* splits, int* pix_per_split) {
     const int TK = dtype == HDY_BF16 ? 64 : 32;
     int sd, sx;
-    wgrad_tile(K, Q, dtype, &sd, &sx);
+    wgrad_tile(K, Q, P, dtype, &sd, &sx);
     const int tiles = cdiv(K, TK * sd) * cdiv(Q, TK * sx);
     const int target = hdy_opt(HDY_OPT_WGRAD_BLOCKS);     // = resident workgroups (2 per CU): one wave of blocks, half the slab traffic of 1024
     int s = cdiv(target, tiles);
@@ -599,7 +601,7 @@ int hdy_wgrad_launch(WgradArgs a, int dtype, hipStream_t st) {
     a.Q = a.TH * a.TW * a.C;
     a.P = a.N * a.Ho * a.Wo;
     int sd, sx;
-    wgrad_tile(a.K, a.Q, dtype, &sd, &sx);
+    wgrad_tile(a.K, a.Q, a.P, dtype, &sd, &sx);
     a.ktiles = cdiv(a.K, TK * sd);
     a.qtiles = cdiv(a.Q, TK * sx);
     HDY_ARG(a.splits >= 1 && a.pix_per_split % PB == 0 && (long long)a.splits * a.pix_per_split >= a.P, "wgrad: bad split plan");

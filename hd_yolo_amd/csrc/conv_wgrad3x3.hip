@@ -163,45 +163,64 @@ __global__ __launch_bounds__(768) void wgrad3x3_kernel(const W3Args p) {
 #pragma unroll
             for (int b = 0; b < NTW; ++b) acc[t][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // Main loop, round 5.  One workgroup owns a CU (152 KB of LDS), so nothing else covers an exposed wait — and the first form had one per tile: its counted
+    // `s_waitcnt vmcnt(n)` ("tile t has landed, tile t + 1 may still be in flight") was followed by `__syncthreads()`, into which hipcc puts
+    // `s_waitcnt vmcnt(0)`: the NEXT tile's 76 KB were waited for before the current tile's MFMAs started (ISA of the round-4 build).  Now: wait for this
+    // wave's requests of tile t (nothing newer is in flight at that point), ONE raw barrier (everyone's requests have landed AND everyone has left the
+    // other buffer), then the requests of tile t + 1, then the MFMAs — with every LDS read as inline asm, because a compiler-visible LDS read behind a
+    // pending LDS-DMA gets the same `vmcnt(0)`.  lgkmcnt is counted by hand: a tap's fragments are requested while the tap before it runs.
+    typedef int i32x2 __attribute__((ext_vector_type(2)));
+#define W3_TRR(dst, addr) asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst) : "v"(addr) : "memory")
+#define W3_LGKM(n) do { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+    const unsigned lds0 = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)smem;
     if (split < tiles) issue(split, 0);
     int cur = 0;
     for (int t = split; t < tiles; t += p.nsplit, cur ^= 1) {
-        const bool more = t + p.nsplit < tiles;
-        if (more) {
-            issue(t + p.nsplit, cur ^ 1);                // the buffer tile t - nsplit used: everyone left it at the barrier below
-            // everything but the next tile's requests of this wave must have landed (waves 8-11 skip one patch request, see W3_BUF)
-            if (dy_loader) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W3_DY_Q) : "memory");
-            else if ((wave - 4 + 8 * (W3_P_Q - 1)) * 8 >= W3_MAXPP) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W3_P_Q - 1) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W3_P_Q) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();
-        const unsigned char* sD = smem + cur * W3_BUF;
-        const unsigned char* sP = sD + W3_MAXTP * 128;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + p.nsplit < tiles) issue(t + p.nsplit, cur ^ 1);
+        const unsigned sD = lds0 + cur * W3_BUF;
+        const unsigned sP = sD + W3_MAXTP * 128;
         // ---- MFMAs: 32 reduction pixels per step, this wave's three taps from the same two LDS images.  16-channel tile a (b) of a wave
         // sits 2 chunks further: chunk ^ f with bit 1 flipped = byte offset ^ 32 per tile.
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) {
             if (s < steps) {
-                V16 af[MTW];
+                i32x2 al[MTW], ah[MTW], bl[2][NTW], bh[2][NTW];
 #pragma unroll
                 for (int a = 0; a < MTW; ++a) {
-                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(sD + s * 4096 + (dtab[0] ^ (a << 5))));
-                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(sD + s * 4096 + (dtab[1] ^ (a << 5))));
-                    af[a].h = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    W3_TRR(al[a], sD + s * 4096 + (dtab[0] ^ (a << 5)));
+                    W3_TRR(ah[a], sD + s * 4096 + (dtab[1] ^ (a << 5)));
                 }
-#pragma unroll
-                for (int sx = 0; sx < 3; ++sx) {
-                    V16 bf[NTW];
-                    unsigned pk = ptab[s][sx];
+                {
+                    unsigned pk = ptab[s][0];
                     asm volatile("" : "+v"(pk));           // keep the unpacking inside the tile loop (hoisted, the unpacked offsets double the registers)
 #pragma unroll
                     for (int b = 0; b < NTW; ++b) {
-                        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(sP + ((pk & 0xFFFFu) ^ (b << 5))));
-                        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(sP + ((pk >> 16) ^ (b << 5))));
-                        bf[b].h = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        W3_TRR(bl[0][b], sP + ((pk & 0xFFFFu) ^ (b << 5)));
+                        W3_TRR(bh[0][b], sP + ((pk >> 16) ^ (b << 5)));
                     }
+                }
+#pragma unroll
+                for (int sx = 0; sx < 3; ++sx) {
+                    if (sx < 2) {
+                        unsigned pk = ptab[s][sx + 1];
+                        asm volatile("" : "+v"(pk));
+#pragma unroll
+                        for (int b = 0; b < NTW; ++b) {
+                            W3_TRR(bl[(sx + 1) & 1][b], sP + ((pk & 0xFFFFu) ^ (b << 5)));
+                            W3_TRR(bh[(sx + 1) & 1][b], sP + ((pk >> 16) ^ (b << 5)));
+                        }
+                        W3_LGKM(2 * NTW);                  // everything but the next tap's fragments is back
+                    } else {
+                        W3_LGKM(0);
+                    }
+                    V16 af[MTW], bf[NTW];
+#pragma unroll
+                    for (int a = 0; a < MTW; ++a) af[a].i = i32x4{al[a][0], al[a][1], ah[a][0], ah[a][1]};
+#pragma unroll
+                    for (int b = 0; b < NTW; ++b) bf[b].i = i32x4{bl[sx & 1][b][0], bl[sx & 1][b][1], bh[sx & 1][b][0], bh[sx & 1][b][1]};
 #pragma unroll
                     for (int a = 0; a < MTW; ++a)
 #pragma unroll
@@ -210,8 +229,9 @@ __global__ __launch_bounds__(768) void wgrad3x3_kernel(const W3Args p) {
                 }
             }
         }
-        __syncthreads();                                   // everyone is done with this tile's LDS images
     }
+#undef W3_TRR
+#undef W3_LGKM
 
     const int Q = 9 * p.C;
     float* out = p.partial + (size_t)split * p.K * Q;
