@@ -297,7 +297,13 @@ def main():
                 step()
                 it[0] = 0
             torch.cuda.synchronize()
-            prewarm_s += time.perf_counter() - tp
+            dtp = time.perf_counter() - tp
+            if world > 1 or force_dist:
+                # every rank must run the SAME number of steps (each step holds collectives): the slowest rank's clock decides for all
+                tblk = torch.tensor([dtp], device=device, dtype=torch.float64)
+                dist.all_reduce(tblk, op=dist.ReduceOp.MAX)
+                dtp = tblk.item()
+            prewarm_s += dtp
             prewarm_steps += 10
     for _ in range(args.warmup):
         step()
