@@ -38,6 +38,16 @@ class SoftDiceLoss(torch.nn.Module):
         return -(dice * w).sum() / w.sum()
 
 
+class _Runs(dict):
+    """executors (device buffers, recorded launch lists) of the module OBJECT they were made for: a copied or unpickled module starts without"""
+
+    def __deepcopy__(self, memo):
+        return _Runs()
+
+    def __reduce__(self):
+        return (_Runs, ())
+
+
 class _SegFn(torch.autograd.Function):
     """connector + class head + soft dice as ONE autograd node over the pyramid features: forward -> loss (1,); backward -> feature
     gradients (NCHW-shaped, channels-last) and the header's parameter gradients written through `grad_of`."""
@@ -51,7 +61,7 @@ class _SegFn(torch.autograd.Function):
         low_w = run.low_shape[2]
         ctx.w_reduced = tuple(run.out_size) != tuple(run.low_shape[1:3]) and ops.softdice_wgrad_ok(logits, masks.shape[1], low_w)
         if ctx.w_reduced:          # loss + gradient already reduced along W: the full-resolution gradient tensor is never written
-            loss, dl = ops.softdice_wgrad(logits, masks, cw, low_w)
+            loss, dl = ops.softdice_wgrad(logits, masks, cw, low_w, bufs=run.__dict__.setdefault('_loss_bufs', {}))
         else:
             loss, dl = ops.softdice(logits, masks, cw, want_grad=True)
         ctx.run, ctx.dl, ctx.grad_of, ctx.dtypes = run, dl, grad_of, [f.dtype for f in feats]
@@ -102,8 +112,13 @@ class PanopticSeg(torch.nn.Module):
         return [m for m in self.layers if isinstance(m, torch.nn.Conv2d)][0]
 
     def _run(self, dtype):
+        """one executor per arithmetic type, kept across calls: it owns the tapes of the training step (hd_yolo_amd/segrun.py)"""
         cache = self.__dict__.setdefault('_hdy_pack', PackCache())
-        return PanopticRun(self.connector, self.class_conv(), dtype, cache)
+        runs = self.__dict__.setdefault('_hdy_runs', _Runs())
+        run = runs.get(dtype)
+        if run is None or run.class_conv is not self.class_conv():
+            run = runs[dtype] = PanopticRun(self.connector, self.class_conv(), dtype, cache)
+        return run
 
     def _param_grad(self, p):
         """default gradient sink: the parameter's own .grad (an engine passes its flat store's views instead)"""

@@ -211,6 +211,8 @@ def run(records, stream=None):
     """Execute launch records on `stream` (default: torch's current HIP stream)."""
     lib = _lib.load()
     s = stream_ptr() if stream is None else stream
+    if Tape.current is not None and stream is None:
+        Tape.current.records.extend(records)
     for rec in records:
         name, args = rec[0], rec[1]
         if name[0] == '@':
@@ -225,6 +227,57 @@ def run(records, stream=None):
         rc = getattr(lib, name)(*args, s)
         if rc != 0:
             raise _lib.HdyError(f'{name} failed (status {rc}): {lib.hdy_last_error().decode()}')
+
+
+# ------------------------------------------------------------------------------------------ tapes: record an eager call sequence once, replay it as one list
+class Tape:
+    """Records what a sequence of eager calls of THIS module launches and allocates, so that the same sequence can later be replayed
+    as one compiled launch list (`Program`, one C call) over the same buffers — for call sequences whose shapes and pointers are
+    fixed but which are written as ordinary eager code (hnet's segmentation branch, hd_yolo_amd/segrun.py).
+
+        with tape:                   # first time: runs eagerly AND records
+            y = some_eager_code(x)
+        ...
+        tape.replay()                # later: the same launches over the same buffers, no Python between them
+
+    While a tape is active, `run()` and `_call()` append their launch records to it and `_new()` allocations are kept alive by it
+    (a replay writes the same addresses, so everything the recorded code allocated must outlive the tape).  Host-side tensor
+    expressions between the launches are NOT captured: code meant for a tape uses launch records for everything it does per call."""
+    current = None
+
+    def __init__(self):
+        self.records, self.keep, self.prog = [], [], None
+
+    def __enter__(self):
+        assert Tape.current is None, 'tapes do not nest'
+        Tape.current = self
+        return self
+
+    def __exit__(self, *exc):
+        Tape.current = None
+        return False
+
+    def replay(self):
+        if not USE_EXEC:
+            return run(self.records)
+        if self.prog is None:
+            self.prog = Program(self.records)
+        self.prog.run()
+
+
+def _new(shape, dtype, device, zero=False):
+    """torch.empty / torch.zeros that an active tape keeps alive"""
+    t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=device)
+    if Tape.current is not None:
+        Tape.current.keep.append(t)
+    return t
+
+
+def _call(name, *args):
+    """one launch through the C ABI on the current stream (`args` without the trailing stream); recorded by an active tape"""
+    _lib.call(name, *args, stream_ptr())
+    if Tape.current is not None:
+        Tape.current.records.append((name, args, ()))
 
 
 # ------------------------------------------------------------------------------------------ convolution
@@ -793,7 +846,7 @@ def cast_store(src_f32, dst, accumulate=False):
     """dst (NHWC view, any pitch) (+)= src_f32 (same logical shape, contiguous fp32)."""
     dp, N, H, W, C, ldd = nhwc(dst)
     assert src_f32.dtype == torch.float32 and src_f32.is_contiguous() and tuple(src_f32.shape) == (N, H, W, C)
-    _lib.call('hdy_cast_store', src_f32.data_ptr(), dp, ldd, N * H * W, C, int(accumulate), dcode(dst.dtype), stream_ptr())
+    _call('hdy_cast_store', src_f32.data_ptr(), dp, ldd, N * H * W, C, int(accumulate), dcode(dst.dtype))
 
 
 # ------------------------------------------------------------------------------------------ fused detection loss
@@ -865,19 +918,19 @@ def det_targets(boxes, img, labels, nc):
 def scale_inplace(t, scale):
     """t *= scale (a 1-element fp32 device tensor), no host sync"""
     assert t.is_contiguous() and scale.dtype == torch.float32 and scale.is_cuda
-    _lib.call('hdy_scale_inplace', t.data_ptr(), t.numel(), scale.data_ptr(), dcode(t.dtype), stream_ptr())
+    _call('hdy_scale_inplace', t.data_ptr(), t.numel(), scale.data_ptr(), dcode(t.dtype))
 
 
 # ------------------------------------------------------------------------------------------ segmentation branch primitives (row f4)
 def groupnorm_relu_fwd(x, gamma, beta, G, eps=1e-5, relu=True):
     """x NHWC (N, H, W, C) -> (y, saved) with y = relu(GroupNorm_G(x)); saved = (stat [N][G][2], ab [N][2][C]) for the backward."""
     xp, N, H, W, C, ldx = nhwc(x)
-    y = torch.empty((N, H, W, C), dtype=x.dtype, device=x.device)
-    stat = torch.empty((N, G, 2), dtype=torch.float32, device=x.device)
-    ab = torch.empty((N, 2, C), dtype=torch.float32, device=x.device)
-    ws = torch.empty(_lib.query('hdy_groupnorm_workspace_floats', N, C), dtype=torch.float32, device=x.device)
-    _lib.call('hdy_groupnorm_fwd', xp, ldx, ptr(gamma), ptr(beta), y.data_ptr(), C, stat.data_ptr(), ab.data_ptr(), N, H * W, C, G, float(eps),
-              int(relu), dcode(x.dtype), ws.data_ptr(), ws.numel(), stream_ptr())
+    y = _new((N, H, W, C), x.dtype, x.device)
+    stat = _new((N, G, 2), torch.float32, x.device)
+    ab = _new((N, 2, C), torch.float32, x.device)
+    ws = _new((_lib.query('hdy_groupnorm_workspace_floats', N, C),), torch.float32, x.device)
+    _call('hdy_groupnorm_fwd', xp, ldx, ptr(gamma), ptr(beta), y.data_ptr(), C, stat.data_ptr(), ab.data_ptr(), N, H * W, C, G, float(eps),
+              int(relu), dcode(x.dtype), ws.data_ptr(), ws.numel())
     return y, (stat, ab)
 
 
@@ -886,12 +939,12 @@ def groupnorm_relu_bwd(dout, x, gamma, saved, G, dgamma, dbeta, relu=True, accum
     dop, N, H, W, C, lddo = nhwc(dout)
     xp, _, _, _, _, ldx = nhwc(x)
     stat, ab = saved
-    dx = torch.empty((N, H, W, C), dtype=x.dtype, device=x.device)
-    coef = torch.empty((N, 3, C), dtype=torch.float32, device=x.device)
-    ws = torch.empty(_lib.query('hdy_groupnorm_workspace_floats', N, C), dtype=torch.float32, device=x.device)
+    dx = _new((N, H, W, C), x.dtype, x.device)
+    coef = _new((N, 3, C), torch.float32, x.device)
+    ws = _new((_lib.query('hdy_groupnorm_workspace_floats', N, C),), torch.float32, x.device)
     assert dout.dtype == x.dtype and dgamma.dtype == dbeta.dtype == torch.float32 and dgamma.is_contiguous() and dbeta.is_contiguous()
-    _lib.call('hdy_groupnorm_bwd', dop, lddo, xp, ldx, ptr(gamma), stat.data_ptr(), ab.data_ptr(), dx.data_ptr(), C, dgamma.data_ptr(),
-              dbeta.data_ptr(), int(accumulate), coef.data_ptr(), N, H * W, C, G, int(relu), dcode(x.dtype), ws.data_ptr(), ws.numel(), stream_ptr())
+    _call('hdy_groupnorm_bwd', dop, lddo, xp, ldx, ptr(gamma), stat.data_ptr(), ab.data_ptr(), dx.data_ptr(), C, dgamma.data_ptr(),
+              dbeta.data_ptr(), int(accumulate), coef.data_ptr(), N, H * W, C, G, int(relu), dcode(x.dtype), ws.data_ptr(), ws.numel())
     return dx
 
 
@@ -900,11 +953,11 @@ def bilinear_fwd(x, size, out=None, accumulate=False):
     xp, N, Hi, Wi, C, ldx = nhwc(x)
     Ho, Wo = size
     if out is None:
-        out = torch.empty((N, Ho, Wo, C), dtype=x.dtype, device=x.device)
+        out = _new((N, Ho, Wo, C), x.dtype, x.device)
         accumulate = False
     op, _, _, _, Co, ldo = nhwc(out)
     assert Co == C and tuple(out.shape[:3]) == (N, Ho, Wo) and out.dtype == x.dtype
-    _lib.call('hdy_bilinear_fwd', xp, ldx, op, ldo, N, Hi, Wi, Ho, Wo, C, int(accumulate), dcode(x.dtype), stream_ptr())
+    _call('hdy_bilinear_fwd', xp, ldx, op, ldo, N, Hi, Wi, Ho, Wo, C, int(accumulate), dcode(x.dtype))
     return out
 
 
@@ -912,16 +965,16 @@ def bilinear_bwd(dy, in_size, out=None, accumulate=False):
     dyp, N, Ho, Wo, C, lddy = nhwc(dy)
     Hi, Wi = in_size
     if out is None:
-        out = torch.empty((N, Hi, Wi, C), dtype=dy.dtype, device=dy.device)
+        out = _new((N, Hi, Wi, C), dy.dtype, dy.device)
         accumulate = False
     op, _, _, _, _, ldo = nhwc(out)
     if Wo >= 2 * Wi and Ho >= 2 * Hi:
         # separable: W pass over every gradient row (contiguous reads, result Wo / Wi times smaller), then the H pass
-        tmp = torch.empty((N, Ho, Wi, C), dtype=dy.dtype, device=dy.device)
-        _lib.call('hdy_bilinear_bwd_axis', dyp, lddy, tmp.data_ptr(), C, N * Ho, Wi, Wo, 1, C, 0, dcode(dy.dtype), stream_ptr())
-        _lib.call('hdy_bilinear_bwd_axis', tmp.data_ptr(), C, op, ldo, N, Hi, Ho, Wi, C, int(accumulate), dcode(dy.dtype), stream_ptr())
+        tmp = _new((N, Ho, Wi, C), dy.dtype, dy.device)
+        _call('hdy_bilinear_bwd_axis', dyp, lddy, tmp.data_ptr(), C, N * Ho, Wi, Wo, 1, C, 0, dcode(dy.dtype))
+        _call('hdy_bilinear_bwd_axis', tmp.data_ptr(), C, op, ldo, N, Hi, Ho, Wi, C, int(accumulate), dcode(dy.dtype))
         return out
-    _lib.call('hdy_bilinear_bwd', dyp, lddy, op, ldo, N, Hi, Wi, Ho, Wo, C, int(accumulate), dcode(dy.dtype), stream_ptr())
+    _call('hdy_bilinear_bwd', dyp, lddy, op, ldo, N, Hi, Wi, Ho, Wo, C, int(accumulate), dcode(dy.dtype))
     return out
 
 
@@ -947,16 +1000,23 @@ def softdice_wgrad_ok(logits, nc, in_w):
     return ld == 4 and nc <= 4 and W * 16 <= 64 * 1024 and W >= 2 * in_w
 
 
-def softdice_wgrad(logits, targets, class_weight, in_w):
-    """(loss[1], dw (N, H, in_w, 4)): hdy_softdice's loss and the W pass of the resize backward of its gradient, in one launch sequence"""
+def softdice_wgrad(logits, targets, class_weight, in_w, bufs=None):
+    """(loss[1], dw (N, H, in_w, 4)): hdy_softdice's loss and the W pass of the resize backward of its gradient, in one launch sequence.
+    bufs: a dict that keeps the three output / workspace tensors between calls (a taped backward reads `dw` at a fixed address)"""
     require_gpu(logits)
     N, H, W, ld = logits.shape
     nc = targets.shape[1]
     assert logits.dtype == torch.float32 and logits.is_contiguous() and targets.dtype == torch.float32 and targets.is_contiguous()
     assert tuple(targets.shape) == (N, nc, H, W) and softdice_wgrad_ok(logits, nc, in_w)
-    loss = torch.empty(1, dtype=torch.float32, device=logits.device)
-    ws = torch.empty(_lib.query('hdy_softdice_workspace_floats', N, nc), dtype=torch.float32, device=logits.device)
-    dw = torch.empty((N, H, in_w, 4), dtype=torch.float32, device=logits.device)
+    key = ('softdice_wgrad', N, H, W, nc, in_w)
+    if bufs is not None and bufs.get('key') == key:
+        loss, ws, dw = bufs['t']
+    else:
+        loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+        ws = torch.empty(_lib.query('hdy_softdice_workspace_floats', N, nc), dtype=torch.float32, device=logits.device)
+        dw = torch.empty((N, H, in_w, 4), dtype=torch.float32, device=logits.device)
+        if bufs is not None:
+            bufs['key'], bufs['t'] = key, (loss, ws, dw)
     _lib.call('hdy_softdice_wgrad', logits.data_ptr(), targets.data_ptr(), ptr(class_weight), N, H, W, nc, in_w, loss.data_ptr(), dw.data_ptr(),
               ws.data_ptr(), ws.numel(), stream_ptr())
     return loss, dw
@@ -966,7 +1026,7 @@ def bilinear_bwd_h(dw, in_h, out, accumulate=False):
     """H pass of the resize backward: dw (N, Ho, Wi, C) -> out (N, in_h, Wi, C) (+)="""
     dp, N, Ho, Wi, C, ldd = nhwc(dw)
     op, _, _, _, _, ldo = nhwc(out)
-    _lib.call('hdy_bilinear_bwd_axis', dp, ldd, op, ldo, N, in_h, Ho, Wi, C, int(accumulate), dcode(dw.dtype), stream_ptr())
+    _call('hdy_bilinear_bwd_axis', dp, ldd, op, ldo, N, in_h, Ho, Wi, C, int(accumulate), dcode(dw.dtype))
     return out
 
 

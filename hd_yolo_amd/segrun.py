@@ -8,11 +8,21 @@ The reference resizes the 128-channel feature map BEFORE the 1x1 conv (panoptic_
 both linear and commute (the resize weights sum to 1, so the bias commutes too), hence the conv runs first, on 1/s^2 of the pixels,
 and the resize moves nc channels instead of 128.
 
-Everything is NHWC; buffers are allocated per call and the launch records run immediately (as hd_yolo_amd/maskhead.py).  Backward =
-reverse walk: resize^T, GroupNorm/ReLU backward, weight gradient and data gradient of each conv on the detector's conv kernels."""
+Everything is NHWC.  Backward = reverse walk: resize^T, GroupNorm/ReLU backward, weight gradient and data gradient of each conv on the
+detector's conv kernels.
+
+Round 5: the training forward and backward are TAPED (ops.Tape).  The branch's shapes are fixed (whole-tile rois, pyramid levels of a static
+plan), so the first step runs the eager code below once while a tape records its launches and keeps its buffers; every later step with the
+same inputs (same feature-map addresses, parameters, gradient views) replays the tape as one compiled launch list — one C call instead of
+~60 ctypes calls and ~40 allocations per step (round 4: 9.7 ms of host time per 14.7 ms hnet step, and a step that stretched to 18 ms whenever
+the host was slowed, e.g. under the kernel tracer).  Inference and anything whose addresses change from call to call stay eager."""
+import os
+
 import torch
 
 from . import ops
+
+TAPE = os.environ.get('HDY_SEG_TAPE', '1') != '0'        # HDY_SEG_TAPE=0: the eager path everywhere (A/B, debugging)
 
 
 class PackCache:
@@ -32,10 +42,13 @@ class PackCache:
         hit = self.slots.get(key)
         # a slot belongs to ONE live parameter object: the weak reference both frees the packed buffer when the parameter dies and keeps a
         # new parameter that happens to reuse the id (and storage address, and version 0) from inheriting another model's packing
-        if hit is not None and hit[0] == tag and hit[2]() is weight:
+        live = hit is not None and hit[2]() is weight
+        if live and hit[0] == tag and ops.Tape.current is None:
             return hit[1]
         Kw, C, R, S = weight.shape
-        wp = ops.pack_alloc(Kw if K is None else K, C, R, S, stride, pad, kind, dtype, weight.device)
+        # under a tape the packing launch must be ON the tape (a replay runs after an optimizer step: the weights have changed) and must
+        # write the buffer the recorded convolutions read: re-pack into the slot's buffer, whatever the version says
+        wp = hit[1] if (live and ops.Tape.current is not None) else ops.pack_alloc(Kw if K is None else K, C, R, S, stride, pad, kind, dtype, weight.device)
         ops.run([ops.rec_pack(weight.detach().float().contiguous(), None, stride, pad, kind, wp, K=K)])
         import weakref
         wid = id(weight)
@@ -68,7 +81,48 @@ class PanopticRun:
         self.class_conv, self.dtype = class_conv, dtype
         self.cache = cache or PackCache()
 
+    def _params(self):
+        ps = [q for stages in self.levels for conv, gn, _ in stages for q in (conv.weight, gn.weight, gn.bias)]
+        return ps + [self.class_conv.weight, self.class_conv.bias]
+
     def forward(self, feats, out_size=None, train=False):
+        """Training calls are taped: the first call with a given set of input addresses runs forward_eager under a tape, later ones replay it."""
+        if not (TAPE and train) or any(q.dtype != torch.float32 for q in self._params()):
+            self._fwd = self._bwd = None
+            return self.forward_eager(feats, out_size, train)
+        key = (tuple((f.data_ptr(), tuple(f.shape), tuple(f.stride())) for f in feats), None if out_size is None else tuple(out_size),
+               tuple(q.data_ptr() for q in self._params()))
+        ent = self.__dict__.get('_fwd')
+        if ent is None or ent['key'] != key:
+            tape = ops.Tape()
+            with tape:
+                logits = self.forward_eager(feats, out_size, True)
+            ent = self._fwd = {'key': key, 'tape': tape, 'logits': logits, 'state': (self.tape, self.total, self.low_shape, self.out_size)}
+            self._bwd = None
+        else:
+            ent['tape'].replay()
+            self.tape, self.total, self.low_shape, self.out_size = ent['state']
+        return ent['logits']
+
+    def backward(self, dlogits, grad_of, scale=None, w_reduced=False):
+        ent = self.__dict__.get('_fwd')
+        if ent is None or scale is None:                       # untaped forward: eager
+            return self.backward_eager(dlogits, grad_of, scale, w_reduced)
+        if self.__dict__.get('_scale') is None:
+            self._scale = torch.ones(1, dtype=torch.float32, device=dlogits.device)
+        self._scale.copy_(scale.reshape(-1)[:1])                # the upstream factor at a fixed address (the one host-side op of a replayed step)
+        key = (ent['key'], dlogits.data_ptr(), tuple(dlogits.shape), bool(w_reduced), tuple(grad_of(q).data_ptr() for q in self._params()))
+        bw = self.__dict__.get('_bwd')
+        if bw is None or bw['key'] != key:
+            tape = ops.Tape()
+            with tape:
+                dfeats = self.backward_eager(dlogits, grad_of, self._scale, w_reduced, keep=True)
+            self._bwd = {'key': key, 'tape': tape, 'dfeats': dfeats}
+        else:
+            bw['tape'].replay()
+        return self._bwd['dfeats']
+
+    def forward_eager(self, feats, out_size=None, train=False):
         dt = self.dtype
         self.tape = []
         total = None
@@ -78,7 +132,7 @@ class PanopticRun:
                 N, H, W, _ = h.shape
                 K = conv.out_channels
                 wp = self.cache.get(conv.weight, 1, 1, ops.PACK_FWD, dt)
-                y = torch.empty((N, H, W, K), dtype=dt, device=h.device)
+                y = ops._new((N, H, W, K), dt, h.device)
                 ops.run([ops.rec_conv_fwd(h, wp, y, K, 3, 3, 1, 1)])
                 z, saved = ops.groupnorm_relu_fwd(y, gn.weight.detach().float(), gn.bias.detach().float(), gn.num_groups, gn.eps)
                 last = si == len(stages) - 1
@@ -100,7 +154,7 @@ class PanopticRun:
         kp = (nc + 7) // 8 * 8
         N, H, W, C = total.shape
         wl = self.cache.get(cc.weight, 1, 0, ops.PACK_FWD, dt)
-        low = torch.zeros((N, H, W, kp), dtype=torch.float32, device=total.device)
+        low = ops._new((N, H, W, kp), torch.float32, total.device, zero=True)
         ops.run([ops.rec_conv_fwd(total, wl, low[..., :nc], nc, 1, 1, 1, 0, shift=cc.bias.detach().float())])
         out_size = (H, W) if out_size is None else tuple(out_size)
         # the resized logits are the largest tensor of the branch (mask resolution): they carry the classes padded to one 16-byte vector
@@ -112,36 +166,39 @@ class PanopticRun:
             self.tape = None
         return logits                                          # fp32 NHWC (N, Ho, Wo, nc4 or kp), channels [nc, ..) are zero
 
-    def backward(self, dlogits, grad_of, scale=None, w_reduced=False):
+    def backward_eager(self, dlogits, grad_of, scale=None, w_reduced=False, keep=False):
         """dlogits fp32 (N, Ho, Wo, nc4 | kp) -> list of feature gradients (NHWC, finest first); parameter gradients into grad_of(p).
-        scale: 1-element tensor multiplied in AFTER the resize backward (linear: the same result, on 1/64 of the elements)."""
+        scale: 1-element tensor multiplied in AFTER the resize backward (linear: the same result, on 1/64 of the elements).
+        Every step between the launches is itself a launch record (no tensor expressions): the sequence can run under a tape."""
         dt = self.dtype
         N, H, W, kp = self.low_shape
         dev = dlogits.device
         cc = self.class_conv
         nc = cc.out_channels
         if self.out_size == (H, W):
-            dlow = dlogits
+            dlow = ops._new((N, H, W, kp), torch.float32, dev)          # a copy: the scaling below is in place
+            ops.run([ops.rec_copy_f32(dlogits.reshape(-1), dlow.reshape(-1))])
         elif w_reduced:                                        # (N, Ho, W, 4): the loss kernel already ran the W pass of the resize backward
-            dlow = torch.zeros((N, H, W, kp), dtype=torch.float32, device=dev)
+            dlow = ops._new((N, H, W, kp), torch.float32, dev, zero=True)
             ops.bilinear_bwd_h(dlogits, H, dlow[..., :dlogits.shape[3]])
         else:
-            dlow = torch.zeros((N, H, W, kp), dtype=torch.float32, device=dev)
+            dlow = ops._new((N, H, W, kp), torch.float32, dev, zero=True)
             ops.bilinear_bwd(dlogits, (H, W), out=dlow[..., :dlogits.shape[3]])
         if scale is not None:
-            dlow = dlow * scale.reshape(-1)[:1].to(dlow.dtype)
-        g = dlow.to(dt)
-        ws_bn = torch.empty(ops.bn_bwd_ws_floats(N * H * W, max(kp, 8)), dtype=torch.float32, device=dev)
-        tmp = torch.empty(kp, dtype=torch.float32, device=dev)
+            ops.scale_inplace(dlow, scale.reshape(-1)[:1].float())
+        g = ops._new((N, H, W, kp), dt, dev)
+        ops.cast_store(dlow, g)
+        ws_bn = ops._new((ops.bn_bwd_ws_floats(N * H * W, max(kp, 8)),), torch.float32, dev)
+        tmp = ops._new((kp,), torch.float32, dev)
         ops.run([ops.rec_colsum(g, tmp, ws_bn)])
-        grad_of(cc.bias).copy_(tmp[:nc])
+        ops.run([ops.rec_copy_f32(tmp[:nc], grad_of(cc.bias))])
         C = self.total.shape[3]
-        gw = torch.empty((kp, C, 1, 1), dtype=torch.float32, device=dev)
-        ws = torch.empty(ops.wgrad_ws_bytes(N, H, W, C, kp, 1, 1, 1, 0, dt) // 4 + 16, dtype=torch.float32, device=dev)
+        gw = ops._new((kp, C, 1, 1), torch.float32, dev)
+        ws = ops._new((ops.wgrad_ws_bytes(N, H, W, C, kp, 1, 1, 1, 0, dt) // 4 + 16,), torch.float32, dev)
         ops.run([ops.rec_conv_wgrad(self.total, g, gw, None, 1, 1, 1, 0, ws)])
-        grad_of(cc.weight).copy_(gw[:nc])
+        ops.run([ops.rec_copy_f32(gw[:nc].reshape(-1), grad_of(cc.weight).reshape(-1))])
         wl_d = self.cache.get(cc.weight, 1, 0, ops.PACK_DGRAD, dt, K=kp)
-        dtotal = torch.empty_like(self.total)
+        dtotal = ops._new(tuple(self.total.shape), self.total.dtype, dev)
         ops.run([ops.rec_conv_dgrad(g, wl_d, dtotal, 1, 1, 1, 0)])
         dfeats = []
         for rec in self.tape:
@@ -151,11 +208,12 @@ class PanopticRun:
                 dz = ops.bilinear_bwd(dh, (Hh, Ww)) if up else dh
                 dy = ops.groupnorm_relu_bwd(dz, y, gn.weight.detach().float(), saved, gn.num_groups, grad_of(gn.weight), grad_of(gn.bias))
                 Cin = xin.shape[3]
-                wsz = torch.empty(ops.wgrad_ws_bytes(Nn, Hh, Ww, Cin, K, 3, 3, 1, 1, dt) // 4 + 16, dtype=torch.float32, device=dev)
+                wsz = ops._new((ops.wgrad_ws_bytes(Nn, Hh, Ww, Cin, K, 3, 3, 1, 1, dt) // 4 + 16,), torch.float32, dev)
                 ops.run([ops.rec_conv_wgrad(xin, dy, grad_of(conv.weight), None, 3, 3, 1, 1, wsz)])
                 wd = self.cache.get(conv.weight, 1, 1, ops.PACK_DGRAD, dt)
-                dh = torch.empty((Nn, Hh, Ww, Cin), dtype=dt, device=dev)
+                dh = ops._new((Nn, Hh, Ww, Cin), dt, dev)
                 ops.run([ops.rec_conv_dgrad(dy, wd, dh, 3, 3, 1, 1)])
             dfeats.append(dh)
-        self.tape = None
+        if not keep:
+            self.tape = None
         return dfeats

@@ -31,7 +31,8 @@ for i, t in enumerate(det_t):
     anns = {k: [{kk: (vv.to(dev) if torch.is_tensor(vv) else vv) for kk, vv in a.items()} for a in v] for k, v in t['anns'].items()}
     anns['seg'] = [{'roi': torch.tensor([0.0, 0.0, S, S]), 'masks': masks[i]}]
     targets.append({**t, 'anns': anns})
-opt = torch.optim.SGD(m.parameters(), lr=1e-4, momentum=0.9)
+from hd_yolo_amd.optim import SGD          # torch.optim.SGD's update in one launch over all tensors (csrc/optim.hip), as bench.py / train.py use it
+opt = SGD(m.parameters(), lr=1e-4, momentum=0.9)
 
 
 def step():

@@ -197,6 +197,53 @@ def test_hnet_mixed_detection_and_segmentation_step_matches_oracle():
     assert all(float(p.grad.abs().max()) == 0.0 for p in m.headers['seg'].parameters())
 
 
+@pytest.mark.parametrize('half', [False, True])
+def test_taped_segmentation_steps_equal_the_eager_ones(half):
+    """hd_yolo_amd/segrun.py replays the segmentation branch's training forward / backward as recorded launch lists from the second step on
+    (same feature-map addresses, parameters and gradient views).  Four optimizer steps with the tapes against four steps of the eager code on an
+    identical copy: every loss and every parameter bit for bit — a replay that read a stale packed weight, skipped a launch or wrote a buffer
+    the next step still needs would show within these steps.  Also: the tapes really are replayed (one record per step is not enough)."""
+    from hd_yolo_amd import segrun
+    from hd_yolo_amd.optim import SGD
+    B, S, nc, ncls = 2, 64, 2, 3
+    x = synth.synth_images(B, S, seed=3).to(DEV)
+    det_t = synth.synth_targets(B, S, nc, nmin=3, nmax=8, seed=4)
+    lab = torch.randint(0, ncls, (B, S, S), generator=torch.Generator().manual_seed(6))
+    masks = F.one_hot(lab, ncls).permute(0, 3, 1, 2).float().contiguous().to(DEV)
+    targets = []
+    for i, t in enumerate(det_t):
+        anns = {k: [{kk: (vv.to(DEV) if torch.is_tensor(vv) else vv) for kk, vv in a.items()} for a in v] for k, v in t['anns'].items()}
+        anns['seg'] = [{'roi': torch.tensor([0.0, 0.0, S, S]), 'masks': masks[i]}]
+        targets.append({**t, 'anns': anns})
+    results, replays = {}, {}
+    saved = segrun.TAPE
+    try:
+        for mode in (True, False):
+            segrun.TAPE = mode
+            m = _hnet(nc, ncls).to(DEV).train()
+            if half:
+                m.half()
+            opt = SGD(m.parameters(), lr=1e-3, momentum=0.9, nesterov=True)
+            hist = []
+            for step in range(4):
+                losses, _ = m(x, targets)
+                (losses['det_det_loss'] + 2.0 * losses['seg_soft_iou_loss']).backward()
+                opt.step()
+                opt.zero_grad(set_to_none=True)
+                hist.append((float(losses['det_det_loss']), float(losses['seg_soft_iou_loss'])))
+            results[mode] = (hist, {k: p.detach().clone() for k, p in m.named_parameters()})
+            run = next(iter(m.headers['seg'].__dict__['_hdy_runs'].values()))
+            replays[mode] = (run.__dict__.get('_fwd') is not None and run._fwd['tape'].prog is not None,
+                             run.__dict__.get('_bwd') is not None and run._bwd['tape'].prog is not None)
+    finally:
+        segrun.TAPE = saved
+    assert replays[True] == (True, True) and replays[False] == (False, False), replays
+    assert results[True][0] == results[False][0], (results[True][0], results[False][0])
+    assert all(np.isfinite(v) for pair in results[True][0] for v in pair) and results[True][0][0] != results[True][0][3]        # the steps did train
+    for k, p in results[True][1].items():
+        assert torch.equal(p, results[False][1][k]), k
+
+
 def test_hnet_eval_outputs():
     m = _hnet().to(DEV).eval()
     x = synth.synth_images(2, 64, seed=3).to(DEV)
