@@ -1,7 +1,7 @@
 """Finalize inside the apply pass (hdy_bn_fin_act_fwd) against the two launches it replaces, replayed alone: microseconds per
 [bump, finalize, apply] and per [bump, fused] at the shapes of the yolov5s train step, with the kernel's measurement variants
 (HDY_DEEP_DEBUG bits: 1 first row requested after the wait, 2 long poll sleep, 4 no fence (wrong), 8 no wait (wrong)).
-Run: PYTHONPATH=. python scripts/probes/fin_fused_probe.py"""
+Needs scripts/probes/retired/bn_finalize_inside_apply.patch applied (git apply) and the library rebuilt.  Results: profiles/r05_finalize_inside_apply.txt"""
 import torch
 
 from hd_yolo_amd import _lib, ops
