@@ -46,10 +46,18 @@ def from_dev_nhwc(v):
     return v.float().cpu().permute(0, 3, 1, 2).contiguous()
 
 
-def assert_close(got, ref, tol, what=''):
+def assert_close(got, ref, tol, what='', elementwise=None):
+    """Two criteria.  (1) max |error| / max |ref| < tol.  (2) for the fp32 path (tol <= 3e-4; north_star: "within 1e-4 relative") EVERY element:
+    |error| <= tol * |ref| + 0.2 * tol * rms(ref) — the absolute term is what a sum of ~1000 fp32 products in a different order costs an element
+    that cancels to near zero (measured: <= 0.1 * tol * rms on every tensor of the model goldens, scripts/probes/elementwise_parity.py)."""
     scale = ref.abs().max().item() + 1e-12
-    err = (got - ref).abs().max().item() / scale
+    d = (got - ref).abs()
+    err = d.max().item() / scale
     assert err < tol, f'{what}: max rel-to-max error {err:.3e} >= {tol}'
+    if tol <= 3e-4 if elementwise is None else elementwise:
+        rms = ref.float().pow(2).mean().sqrt().item()
+        over = (d - tol * ref.abs() - 0.2 * tol * rms).max().item()
+        assert over <= 0, f'{what}: an element is off by {over + 0.2 * tol * rms:.3e} beyond {tol} * |ref| (allowed absolute part {0.2 * tol * rms:.3e})'
 
 
 CONV_CASES = [
@@ -632,7 +640,7 @@ def test_fused_1x1_backward_matches_reference_and_the_three_launch_path(K, M, pa
     assert_close(got_dx, ref_dx, 1.5e-2, 'dx vs torch')
     assert_close(got_dw, ref_dw, 1.5e-2, 'dW vs torch')
     assert_close(got_dx, dx_b.float().cpu().reshape(M, C), 8e-3, 'dx vs three launches')         # one bf16 rounding of the output apart at most
-    assert_close(got_dw, gw_b.cpu()[:, :, 0, 0], 2e-4, 'dW vs three launches')           # fp32 sums in a different order
+    assert_close(got_dw, gw_b.cpu()[:, :, 0, 0], 2e-4, 'dW vs three launches', elementwise=False)   # two bf16-operand paths: the three launches round dy to bf16 in between, the fused kernel does not — elements that cancel differ by more than a summation order
     # dgrad only / wgrad only
     dx_o = to_dev_nhwc(dx0, dt, ld=C + 8, off=8)
     gw_o = torch.zeros((K, C, 1, 1), device=DEV)
