@@ -498,7 +498,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_deep_kernel(const ConvArgs p) {
 #pragma unroll
                         for (int q = 0; q < 2; ++q) {
                             f32x4 v = acc[AI(a, b, m, nb + q)];
-                            if (STATS) {
+                            if (STATS && !(dbg & 512)) {
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) {
                                     s1[(nb + q) * 4 + r] += v[r];
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_deep_kernel(const ConvArgs p) {
 #undef DP_READ_B
 #undef DP_LGKM0_A
 
-    if (STATS) {
+    if (STATS && !(dbg & 1024)) {
         // one slab row per workgroup position (mt0): lane-local sums -> 16 pixel lanes (shuffles) -> the wr waves that share the channels (LDS).
         // No LDS-DMA is in flight here (the loader ran dry and its last units were waited for with vmcnt(0) inside the K loop), so the barriers below wait
         // for LDS traffic only — raw barriers: `__syncthreads()` would also wait (vmcnt(0)) for the last tile's output stores, ~2.5 us of acknowledgement
