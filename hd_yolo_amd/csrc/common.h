@@ -74,6 +74,24 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 // One-time per-kernel setup that is bound to a DEVICE (hipFuncSetAttribute: dynamic LDS above 64 KB): once per process and device, not once per
 // process — a second device in the same process (one plan per device; the executor keeps per-device events for that case) would otherwise launch
 // without the attribute.
+// Sum over the 16 lanes of a DPP row (lanes 16k .. 16k + 15), delivered to every lane of the row: four v_add_f32 with row_ror operands, no LDS
+// crossbar.  The BatchNorm sums of the conv epilogues end in this reduction (pixel lanes of an MFMA accumulator tile); as `u += __shfl_xor(u, m)`
+// hipcc emitted ds_bpermute_b32 + s_waitcnt lgkmcnt(0) per step and value, one after the other: 64 LDS round trips = 3.2 us for the 32 sums at the
+// end of every conv_deep forward launch (profiles/r05_small_probes_ab.txt).
+#if defined(__HIPCC__)
+__device__ __forceinline__ float row_sum16(float v) {
+#ifdef HDY_ROW_SUM_SHFL      // A/B build: the former shuffle chain
+    for (int m = 1; m < 16; m <<= 1) v += __shfl_xor(v, m);
+    return v;
+#endif
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));   // row_ror:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));   // row_ror:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xF, 0xF, true));   // row_ror:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xF, 0xF, true));   // row_ror:1
+    return v;
+}
+#endif
+
 struct PerDeviceOnce {
     std::once_flag flag[16];
     template <typename F> void run(F&& fn) {

@@ -365,11 +365,8 @@ __global__ __launch_bounds__(NTHR, C == 32 ? 3 : 2) void conv3x3_c64_kernel(cons
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float u = s1[r], q = s2[r];
-#pragma unroll
-            for (int m = 1; m < 16; m <<= 1) {
-                u += __shfl_xor(u, m);
-                q += __shfl_xor(q, m);
-            }
+            u = row_sum16(u);
+            q = row_sum16(q);
             const int c = wave * 16 + fq * 4 + r;
             if (fr == 0 && c < p.K) {
                 p.stats[((size_t)wg * 2 + 0) * p.K + c] = u;

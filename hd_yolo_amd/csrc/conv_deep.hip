@@ -593,11 +593,8 @@ __global__ __launch_bounds__(NTHR, 2) void conv_deep_kernel(const ConvArgs p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float u = s1[n * 4 + r], q = s2[n * 4 + r];
-#pragma unroll
-                for (int msk = 1; msk < 16; msk <<= 1) {
-                    u += __shfl_xor(u, msk);
-                    q += __shfl_xor(q, msk);
-                }
+                u = row_sum16(u);
+                q = row_sum16(q);
                 if (fr == 0) {
                     const int col = wc * 64 + n * 16 + fq * 4 + r;
                     red[(wr * BN + col) * 2 + 0] = u;

@@ -327,11 +327,8 @@ __global__ __launch_bounds__(2 * BM, (BM == 256 || BN == 128 || STAT) ? 2 : (BN 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float u = u1[b][r], q = u2[b][r];
-#pragma unroll
-                for (int m = 1; m < 16; m <<= 1) {
-                    u += __shfl_xor(u, m);
-                    q += __shfl_xor(q, m);
-                }
+                u = row_sum16(u);
+                q = row_sum16(q);
                 if (fr == 0) {
                     const int col = wn * (BN / 2) + b * 16 + fq * 4 + r;
                     red[(wm * BN + col) * 2 + 0] = u;

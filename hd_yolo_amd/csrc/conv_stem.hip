@@ -195,11 +195,8 @@ __global__ __launch_bounds__(NTHR) void conv_stem_kernel(const ConvArgs p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float u = s1[b][r], q = s2[b][r];
-#pragma unroll
-                for (int m = 1; m < 16; m <<= 1) {
-                    u += __shfl_xor(u, m);
-                    q += __shfl_xor(q, m);
-                }
+                u = row_sum16(u);
+                q = row_sum16(q);
                 if (fr == 0) {
                     const int c = b * 16 + fq * 4 + r;
                     red[(wave * K + c) * 2 + 0] = u;
