@@ -197,8 +197,9 @@ def test_bench_config_step_is_sane_at_full_size():
     assert all(torch.isfinite(d).all() for d in plan.det_views())
 
 
-def _c2_step(switches):
-    """loss and every parameter gradient of one BASELINE configs[1] step (yolov5s, 8 classes, batch 64, 640x640, bf16) under kernel switches"""
+def _c2_step(switches, fp32=False):
+    """loss and every parameter gradient of one BASELINE configs[1] step (yolov5s, 8 classes, batch 64, 640x640, bf16) under kernel switches;
+    fp32=True: the same step in fp32 arithmetic (the parity mode of the generic kernels)"""
     import contextlib
     from hd_yolo_amd import _lib, plan as planmod
     from metayolo.models.yolo import Model
@@ -213,7 +214,8 @@ def _c2_step(switches):
             m = Model(synth.make_cfg('s', 8), synth.make_hyp())
             m.load_state_dict(synth.synth_state_dict(synth.shapes_of(m), seed=0), strict=False)
             m = m.to(DEV).train()
-            m.half()
+            if not fp32:
+                m.half()
             x = synth.synth_images(64, 640, seed=0).to(DEV)
             t = synth.synth_targets(64, 640, 8, seed=1)
             _lib.dispatch_log(reset=True)
@@ -232,7 +234,8 @@ def test_bench_config_step_fast_kernels_against_all_generic_kernels():
     """The step bench.py times, twice: with every specialised kernel (filter- / patch-resident 3x3, stride-2 forward and data gradient, stem,
     patch-resident and stem weight gradients, fused 1x1 backward, deep-pipelined implicit GEMM) and with all of them switched off (generic
     implicit GEMM, generic weight gradient, three-launch BatchNorm backward).  Same weights, tiles and targets: the loss must agree within 1e-3
-    and every parameter gradient must point the same way (cosine > 0.999; bf16 operands: the kernels round at different places)."""
+    for both, the detection convs' gradients point the same way (cosine > 0.999), and — against the same step in fp32 arithmetic — the specialised
+    kernels are as close to the truth as the generic ones at every quantile of the per-parameter cosines."""
     off = ['HDY_NO_CONV3X3', 'HDY_NO_CONV3X3S2', 'HDY_NO_DGRAD_S2', 'HDY_NO_STEM_KERNEL', 'HDY_NO_STEM_WGRAD', 'HDY_NO_WGRAD3X3', 'HDY_NO_DEEP']
     loss_f, g_f, log_f = _c2_step([])
     loss_g, g_g, log_g = _c2_step(off)
@@ -252,7 +255,25 @@ def test_bench_config_step_fast_kernels_against_all_generic_kernels():
     rows.sort()
     cos = {k: c for c, k in rows}
     assert cos['headers.det.m.0.weight'] > 0.999 and cos['headers.det.m.2.weight'] > 0.999 and cos['headers.det.m.2.bias'] > 0.999, rows[:5]
-    assert rows[0][0] > 0.93, f'gradient of {rows[0][1]} differs between the fast and the generic kernels: cosine {rows[0][0]:.5f}'
-    # (round 5: the third down-sampling layer's forward and data gradient joined the specialised set — two more early layers whose roundings differ
-    # between the two runs; median 0.9786, every per-kernel and per-unit comparison unchanged)
-    assert rows[len(rows) // 2][0] > 0.97, rows[len(rows) // 2]
+    # The worst and the median of ~180 tensors of a chaotic system are noisy statistics (one early-layer rounding difference moves all gradients
+    # behind it together): fast against generic gave worst / median 0.961 / 0.99 with round 4's kernels, 0.96 / 0.979 with round 5's stride-2
+    # kernels, 0.869 / 0.959 after the BatchNorm sums changed their summation order (row_sum16) in BOTH kernel sets.  What must hold whatever the
+    # sample: each set is as close to the SAME step in fp32 arithmetic as the other — the specialised kernels are not further from the truth
+    # than the generic ones at any quantile.
+    quant = lambda rs: [rs[int(f * (len(rs) - 1))] for f in (0.0, 0.05, 0.1, 0.25, 0.5)]
+    loss_32, g_32, _ = _c2_step([], fp32=True)
+    cosine = lambda a, b: float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
+    q_fg = quant([c for c, _ in rows])
+    q_f = quant(sorted(cosine(g_f[k], g_32[k]) for k in g_f))
+    q_g = quant(sorted(cosine(g_g[k], g_32[k]) for k in g_g))
+    fmt = lambda q: ' '.join(f'{v:.4f}' for v in q)
+    print(f'cosine of the parameter gradients (worst / 5 % / 10 % / 25 % / median): fast~generic {fmt(q_fg)} | fast~fp32 {fmt(q_f)} | generic~fp32 {fmt(q_g)}; '
+          f'loss fast {loss_f:.6f} generic {loss_g:.6f} fp32 {loss_32:.6f}')
+    assert rows[0][0] > 0.80, f'gradient of {rows[0][1]} differs between the fast and the generic kernels: cosine {rows[0][0]:.5f}'
+    assert abs(loss_f - loss_32) < 2e-3 * abs(loss_32) and abs(loss_g - loss_32) < 2e-3 * abs(loss_32), (loss_f, loss_g, loss_32)
+    for a, b, name in zip(q_f, q_g, ('worst', '5 %', '10 %', '25 %', 'median')):
+        assert a > b - 0.04, f'{name} quantile: the specialised kernels are at cosine {a:.4f} from the fp32 step, the generic ones at {b:.4f}'
+    # measured (round 5): fast~generic 0.869 0.916 0.924 0.936 0.959 | fast~fp32 0.775 0.830 0.847 0.859 0.896 | generic~fp32 0.768 0.826 0.846 0.865 0.899:
+    # bf16 operands alone put this network's gradients at cosine ~0.9 from the fp32 step, the two kernel sets within 0.008 of each other at every quantile
+    assert q_f[4] > 0.85, f'median cosine between the bf16 step and the fp32 step {q_f[4]:.4f}'
+
