@@ -396,7 +396,7 @@ def test_bn_pair_equals_two_single_calls(shape, dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('shape', [(2, 20, 20, 32), (1, 5, 7, 8), (1, 32, 32, 16), (1, 40, 40, 8)])
+@pytest.mark.parametrize('shape', [(2, 20, 20, 32), (1, 5, 7, 8), (1, 32, 32, 16), (1, 40, 40, 8), (2, 32, 32, 64), (1, 40, 40, 32)])
 def test_sppf_pool(shape, dtype):
     N, H, W, C = shape
     x = q(rnd((N, C, H, W), 1), dtype)
