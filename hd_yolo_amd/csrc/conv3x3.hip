@@ -311,14 +311,6 @@ __global__ __launch_bounds__(NTHR, C == 32 ? 3 : 2) void conv3x3_c64_kernel(cons
             const long long org = (((long long)it.n * p.Ho + it.th * TH + it.row0) * p.Wo + it.tw * TW);
             bf16_t* yb = (bf16_t*)p.y + org * p.ldy + st_off;
             const bf16_t* rb = p.res ? (const bf16_t*)p.res + org * p.ldr + rs_off : nullptr;
-            // residual / accumulate operands of all AR / 2 passes requested before the first one is used (in the loop each pass paid its own memory
-            // round trip: the shortcut convolutions of yolov5l's eval plan); one of the two at a time, as conv_deep.hip
-            V16 pre[AR / 2];
-            const bool pre_res = rb != nullptr, pre_acc = !pre_res && p.accumulate;
-            if (pre_res || pre_acc) {
-#pragma unroll
-                for (int j = 0; j < AR / 2; ++j) pre[j].i = pre_res ? *(const i32x4*)(rb + j * rs_step) : *(const i32x4*)(yb + j * st_step);
-            }
 #pragma unroll
             for (int j = 0; j < AR / 2; ++j) {             // 32 pixel rows of 128 bytes per pass
                 V16 v;
@@ -328,11 +320,13 @@ __global__ __launch_bounds__(NTHR, C == 32 ? 3 : 2) void conv3x3_c64_kernel(cons
                     float f[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) f[e] = (float)v.h[e];
-                    if (pre_res || pre_acc) {
+                    if (p.res) {
+                        V16 q;
+                        q.i = *(const i32x4*)(rb + j * rs_step);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) f[e] += (float)pre[j].h[e];
+                        for (int e = 0; e < 8; ++e) f[e] += (float)q.h[e];
                     }
-                    if (p.accumulate && !pre_acc) {
+                    if (p.accumulate) {
                         V16 q;
                         q.i = *(const i32x4*)(yb + j * st_step);
 #pragma unroll

@@ -490,41 +490,10 @@ __global__ __launch_bounds__(NTHR, 2) void conv_deep_kernel(const ConvArgs p) {
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(csc[0]), "+v"(csh[0]), "+v"(csc[1]), "+v"(csh[1]));
                 }
-                // Residual / accumulate operands of this pass group's 2 * MT stores, all requested BEFORE the first conversion: as a load inside the
-                // store loop (load -> wait -> add -> store, once per pass) the eval-mode bottleneck convolutions of yolov5l paid a memory round trip per
-                // pass: 128->128 3x3 @128x128 with the shortcut 795 us, without 635 us (profiles/r05_layer_table_l_eval.txt).  One of the two at a time
-                // (the plans never ask for both); if both are set the accumulate operand is still fetched in the loop.
-                auto out_pix = [&](int a, int m, int& mg_out) -> size_t {
-                    const int mg = m0 + a * 128 + (BN == 256 ? wr * 64 : wr * 32) + m * 16 + fr;
-                    mg_out = mg;
-                    size_t opix = (size_t)mg;
-                    if (walk) {                                    // class pixel (n, oi, oj) -> its place in the strided output image
-                        const int mc = min(mg, p.M - 1);
-                        const int n = (int)fdiv((unsigned)mc, p.mg_howo, p.sh_howo), rem = mc - n * HoWo;
-                        const int oi = (int)fdiv((unsigned)rem, p.mg_wo, p.sh_wo), oj = rem - oi * p.Wo;
-                        opix = ((size_t)n * p.Hout + (p.c_oh[j & 3] + oi * p.oh_mul)) * p.Wout + (p.c_ow[j & 3] + oj * p.ow_mul);
-                    }
-                    return opix;
-                };
-                constexpr int PB = BN == 256 ? 2 : 2 * MT;         // stores per batch = operands in flight (BN = 256: the registers allow two)
-                V16 pre[PB];
-                const bool pre_res = p.res != nullptr, pre_acc = !pre_res && p.accumulate;
 #pragma unroll
-                for (int i0 = 0; i0 < 2 * MT; i0 += PB) {
-                if (pre_res || pre_acc) {
-                    const int kc = n0 + cb + cl;
+                for (int a = 0; a < 2; ++a)
 #pragma unroll
-                    for (int i = i0; i < i0 + PB; ++i) {
-                        int mg;
-                        const size_t opix = out_pix(i / MT, i % MT, mg);
-                        pre[i - i0].i = i32x4{0, 0, 0, 0};
-                        if (mg < p.M && kc < p.K)
-                            pre[i - i0].i = pre_res ? *(const i32x4*)((const bf16_t*)p.res + opix * p.ldr + kc) : *(const i32x4*)(y + opix * p.ldy + kc);
-                    }
-                }
-#pragma unroll
-                for (int i = i0; i < i0 + PB; ++i) {
-                    const int a = i / MT, m = i % MT;
+                    for (int m = 0; m < MT; ++m) {
                         unsigned pk[2][2];
 #pragma unroll
                         for (int q = 0; q < 2; ++q) {
@@ -556,19 +525,27 @@ __global__ __launch_bounds__(NTHR, 2) void conv_deep_kernel(const ConvArgs p) {
                         const unsigned r1_ = (unsigned)__builtin_amdgcn_ds_swizzle((int)s1_, 0x401F);
                         V16 o;
                         o.i = odd ? i32x4{(int)r0_, (int)r1_, (int)pk[1][0], (int)pk[1][1]} : i32x4{(int)pk[0][0], (int)pk[0][1], (int)r0_, (int)r1_};
-                        int mg;
-                        const size_t opix = out_pix(a, m, mg);
+                        const int mg = m0 + a * 128 + (BN == 256 ? wr * 64 : wr * 32) + m * 16 + fr;
                         const int kc = n0 + cb + cl;
+                        size_t opix = (size_t)mg;
+                        if (walk) {                                // class pixel (n, oi, oj) -> its place in the strided output image
+                            const int mc = min(mg, p.M - 1);
+                            const int n = (int)fdiv((unsigned)mc, p.mg_howo, p.sh_howo), rem = mc - n * HoWo;
+                            const int oi = (int)fdiv((unsigned)rem, p.mg_wo, p.sh_wo), oj = rem - oi * p.Wo;
+                            opix = ((size_t)n * p.Hout + (p.c_oh[j & 3] + oi * p.oh_mul)) * p.Wout + (p.c_ow[j & 3] + oj * p.ow_mul);
+                        }
                         if (mg < p.M && kc < p.K) {
                             if (p.res || p.accumulate) {
                                 float f[8];
 #pragma unroll
                                 for (int e = 0; e < 8; ++e) f[e] = (float)o.h[e];
-                                if (pre_res || pre_acc) {
+                                if (p.res) {
+                                    V16 q;
+                                    q.i = *(const i32x4*)((const bf16_t*)p.res + opix * p.ldr + kc);
 #pragma unroll
-                                    for (int e = 0; e < 8; ++e) f[e] += (float)pre[i - i0].h[e];
+                                    for (int e = 0; e < 8; ++e) f[e] += (float)q.h[e];
                                 }
-                                if (p.accumulate && !pre_acc) {
+                                if (p.accumulate) {
                                     V16 q;
                                     q.i = *(const i32x4*)(y + opix * p.ldy + kc);
 #pragma unroll
@@ -581,7 +558,6 @@ __global__ __launch_bounds__(NTHR, 2) void conv_deep_kernel(const ConvArgs p) {
                             else asm volatile("" ::"v"(o.i));          // timing ablation: the epilogue's arithmetic without its stores
                         }
                     }
-                }
             }
         }
 #pragma unroll
