@@ -163,6 +163,138 @@ __global__ __launch_bounds__(NT) void sppf_pool_fwd_kernel(const T* __restrict__
     }
 }
 
+// ---------------------------------------------------------------- bf16 forward on ORDER-PRESERVING KEYS (round 5)
+// One workgroup of the kernel above takes ~26 us whatever the batch (profiles/r05_small_probes_ab.txt): four serial rounds of global loads, and six 5-tap
+// stages whose per-channel-and-tap work is a compare, a NaN test and two selects (value, position) — ~1400 VALU instructions per thread at four
+// waves per SIMD.  Here the planes hold 16-bit keys  k(v) = v < 0 ? ~bits : bits | 0x8000  (NaN -> the largest key, -0 -> +0: ATen's comparison treats
+// the zeros as equal), a maximum of values is a maximum of keys, and
+//   * with positions: key << 16 | (7 - tap) as ONE unsigned maximum per channel and tap — the largest value wins, among equals the first tap;
+//   * without (inference): v_pk_max_u16 on the packed pairs, one instruction per two channels and tap;
+// Same outputs and positions as the kernel above (the FIRST of several NaNs in a window where that one keeps the last — a NaN window is NaN either
+// way).  Requesting a thread's plane loads before the border fill was tried on top (forward: +1 us; backward, with all four gradients and three
+// position tables: 81 -> 106 us): sixteen waves per workgroup already overlap those loads.
+__device__ __forceinline__ unsigned sppf_key2(unsigned d) {           // two packed bf16 -> two packed keys
+    unsigned r = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        unsigned v = (d >> (16 * h)) & 0xFFFFu;
+        v = (v & 0x7FFFu) > 0x7F80u ? 0x7FC0u : v;                  // any NaN -> +qNaN
+        v = v == 0x8000u ? 0u : v;                                   // -0 -> +0
+        v = (v & 0x8000u) ? (~v & 0xFFFFu) : (v | 0x8000u);
+        r |= v << (16 * h);
+    }
+    return r;
+}
+__device__ __forceinline__ unsigned sppf_unkey2(unsigned d) {
+    unsigned r = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const unsigned k = (d >> (16 * h)) & 0xFFFFu;
+        r |= ((k & 0x8000u) ? (k & 0x7FFFu) : (~k & 0xFFFFu)) << (16 * h);
+    }
+    return r;
+}
+typedef unsigned short sppf_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned sppf_pkmax(unsigned a, unsigned b) {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(sppf_us2, a), __builtin_bit_cast(sppf_us2, b)));
+}
+
+template <int CGK, int NT>
+__global__ __launch_bounds__(NT) void sppf_pool_fwd_keys_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y1, bf16_t* __restrict__ y2,
+                                                                 bf16_t* __restrict__ y3, int ld, unsigned char* __restrict__ i1,
+                                                                 unsigned char* __restrict__ i2, unsigned char* __restrict__ i3, int H, int W, int C) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pl_raw[];
+    typedef PlaneWalkT<CGK, NT> PlaneWalk;
+    constexpr int CG = CGK, QPP = CGK / 4;
+    const int HW = H * W, WP = W + 2 * PB, PP = (H + 2 * PB) * WP;
+    unsigned short* a = (unsigned short*)pl_raw;                     // [2][(H+4)*(W+4)][CG] keys; 0 = below every key of a value: the border
+    unsigned short* b = a + PP * CG;
+    unsigned char* rx = (unsigned char*)(a + 2 * PP * CG);           // row-stage positions (training form)
+    const int cgs = C / CG;
+    const int cl = (threadIdx.x % QPP) * 4;
+    const int n = blockIdx.x / cgs, c0 = (blockIdx.x - n * cgs) * CG + cl;
+    const size_t base = (size_t)n * HW;
+    for (int e = threadIdx.x; e < 2 * PP * CG / 8; e += NT) ((uint4*)a)[e] = uint4{0u, 0u, 0u, 0u};
+    for (int e = 2 * PP * CG / 8 * 8 + threadIdx.x; e < 2 * PP * CG; e += NT) a[e] = 0;
+    __syncthreads();
+    for (PlaneWalk q(W); q.pix < HW; q.next(W)) {
+        const uint2 d = *(const uint2*)(x + (base + q.pix) * ld + c0);
+        *(uint2*)(a + ((q.h + PB) * WP + q.w + PB) * CG + cl) = uint2{sppf_key2(d.x), sppf_key2(d.y)};
+    }
+    __syncthreads();
+    bf16_t* outs[3] = {y1, y2, y3};
+    unsigned char* idxs[3] = {i1, i2, i3};
+    if (!i1) {
+#pragma unroll
+        for (int pass = 0; pass < 3; ++pass) {
+            for (PlaneWalk q(W); q.pix < HW; q.next(W)) {          // rows: a -> b
+                const int o = ((q.h + PB) * WP + q.w + PB) * CG + cl;
+                uint2 m = *(const uint2*)(a + o - 2 * CG);
+#pragma unroll
+                for (int dx = -1; dx <= 2; ++dx) {
+                    const uint2 v = *(const uint2*)(a + o + dx * CG);
+                    m.x = sppf_pkmax(m.x, v.x);
+                    m.y = sppf_pkmax(m.y, v.y);
+                }
+                *(uint2*)(b + o) = m;
+            }
+            __syncthreads();
+            for (PlaneWalk q(W); q.pix < HW; q.next(W)) {          // columns: b -> a
+                const int o = ((q.h + PB) * WP + q.w + PB) * CG + cl;
+                uint2 m = *(const uint2*)(b + o - 2 * WP * CG);
+#pragma unroll
+                for (int dy = -1; dy <= 2; ++dy) {
+                    const uint2 v = *(const uint2*)(b + o + dy * WP * CG);
+                    m.x = sppf_pkmax(m.x, v.x);
+                    m.y = sppf_pkmax(m.y, v.y);
+                }
+                *(uint2*)(a + o) = m;
+                *(uint2*)(outs[pass] + (base + q.pix) * ld + c0) = uint2{sppf_unkey2(m.x), sppf_unkey2(m.y)};
+            }
+            __syncthreads();
+        }
+        return;
+    }
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass) {
+        for (PlaneWalk q(W); q.pix < HW; q.next(W)) {              // rows: a -> b, position = 7 - low bits of the winning key
+            const int o = ((q.h + PB) * WP + q.w + PB) * CG + cl;
+            unsigned k0 = 0, k1 = 0, k2 = 0, k3 = 0;
+#pragma unroll
+            for (int dx = 0; dx < 5; ++dx) {
+                const uint2 v = *(const uint2*)(a + o + (dx - 2) * CG);
+                const unsigned t = 7u - dx;
+                k0 = max(k0, (v.x << 16) | t);
+                k1 = max(k1, (v.x & 0xFFFF0000u) | t);
+                k2 = max(k2, (v.y << 16) | t);
+                k3 = max(k3, (v.y & 0xFFFF0000u) | t);
+            }
+            *(uint2*)(b + o) = uint2{(k0 >> 16) | (k1 & 0xFFFF0000u), (k2 >> 16) | (k3 & 0xFFFF0000u)};
+            *(unsigned*)(rx + o) = 0x07070707u - ((k0 & 7u) | (k1 & 7u) << 8 | (k2 & 7u) << 16 | (k3 & 7u) << 24);
+        }
+        __syncthreads();
+        for (PlaneWalk q(W); q.pix < HW; q.next(W)) {              // columns: b -> a (the next pool's source)
+            const int o = ((q.h + PB) * WP + q.w + PB) * CG + cl;
+            unsigned k0 = 0, k1 = 0, k2 = 0, k3 = 0;
+#pragma unroll
+            for (int dy = 0; dy < 5; ++dy) {
+                const uint2 v = *(const uint2*)(b + o + (dy - 2) * WP * CG);
+                const unsigned t = 7u - dy;
+                k0 = max(k0, (v.x << 16) | t);
+                k1 = max(k1, (v.x & 0xFFFF0000u) | t);
+                k2 = max(k2, (v.y << 16) | t);
+                k3 = max(k3, (v.y & 0xFFFF0000u) | t);
+            }
+            const uint2 m = uint2{(k0 >> 16) | (k1 & 0xFFFF0000u), (k2 >> 16) | (k3 & 0xFFFF0000u)};
+            *(uint2*)(a + o) = m;
+            *(uint2*)(outs[pass] + (base + q.pix) * ld + c0) = uint2{sppf_unkey2(m.x), sppf_unkey2(m.y)};
+            const unsigned bj = 0x07070707u - ((k0 & 7u) | (k1 & 7u) << 8 | (k2 & 7u) << 16 | (k3 & 7u) << 24);
+            *(unsigned*)(idxs[pass] + (base + q.pix) * C + c0) = bj | (*(const unsigned*)(rx + o) << 4);
+        }
+        __syncthreads();
+    }
+}
+
 // dx = g0 + P1^T( g1 + P2^T( g2 + P3^T g3 ) ), P^T = scatter-to-argmax written as two 5-tap gathers (deterministic):
 // column stage  r[h'][w] = SUM_dy [dy(h' - dy + 2, w) == dy] t[h' - dy + 2][w],  row stage  s[h][w'] = SUM_dx [dx'(h, w' - dx + 2) == dx] r[h][w' - dx + 2].
 template <typename T, int CGK, int NT>
@@ -360,6 +492,17 @@ int sppf_fwd_launch(const void* x, void* y1, void* y2, void* y3, int ld, unsigne
     return HDY_OK;
 }
 
+template <int CGK, int NT>
+int sppf_fwd_keys_launch(const void* x, void* y1, void* y2, void* y3, int ld, unsigned char* i1, unsigned char* i2, unsigned char* i3, int N, int H, int W, int C,
+                         size_t smem, hipStream_t st) {
+    static PerDeviceOnce once;
+    once.run([] { (void)hipFuncSetAttribute((const void*)sppf_pool_fwd_keys_kernel<CGK, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); });
+    hipLaunchKernelGGL((sppf_pool_fwd_keys_kernel<CGK, NT>), dim3(N * (C / CGK)), dim3(NT), smem, st, (const bf16_t*)x, (bf16_t*)y1, (bf16_t*)y2, (bf16_t*)y3, ld, i1,
+                       i2, i3, H, W, C);
+    HDY_LAUNCH_CHECK("sppf_pool_fwd(keys)");
+    return HDY_OK;
+}
+
 template <typename T, int CGK, int NT>
 int sppf_bwd_launch(const void* g0, const void* g1, const void* g2, const void* g3, int ldg, const unsigned char* i1, const unsigned char* i2,
                            const unsigned char* i3, void* dx, int lddx, int N, int H, int W, int C, int two_ix, size_t smem, hipStream_t st) {
@@ -385,6 +528,13 @@ int hdy_sppf_pool_fwd(const void* x, void* y1, void* y2, void* y3, int ld, unsig
     hipStream_t st = (hipStream_t)stream;
     if (dtype == HDY_BF16) {
         // bf16 planes, 32 channels per workgroup when they fit (20 x 20: 92 KB with the position plane)
+        // order-preserving keys (sppf_pool_fwd_keys_kernel): the same two shapes of workgroup; HDY_DEEP_DEBUG bit 1024 keeps the float-compare kernels (A/B)
+        const bool keys = !(hdy_opt(HDY_OPT_DEEP_DEBUG) & 1024) && ld % 4 == 0 && ((uintptr_t)x & 7) == 0 && ((uintptr_t)y1 & 7) == 0 && ((uintptr_t)y2 & 7) == 0 &&
+                          ((uintptr_t)y3 & 7) == 0;
+        if (keys && C % 32 == 0 && pix * 32 * (2 * sizeof(bf16_t) + ix) <= 150 * 1024)
+            return sppf_fwd_keys_launch<32, 1024>(x, y1, y2, y3, ld, idx1, idx2, idx3, N, H, W, C, pix * 32 * (2 * sizeof(bf16_t) + ix), st);
+        if (keys && C % 16 == 0 && pix * 16 * (2 * sizeof(bf16_t) + ix) <= 150 * 1024)
+            return sppf_fwd_keys_launch<16, 1024>(x, y1, y2, y3, ld, idx1, idx2, idx3, N, H, W, C, pix * 16 * (2 * sizeof(bf16_t) + ix), st);
         if (C % 32 == 0 && pix * 32 * (2 * sizeof(bf16_t) + ix) <= 150 * 1024)
             return sppf_fwd_launch<bf16_t, bf16_t, 32, 1024>(x, y1, y2, y3, ld, idx1, idx2, idx3, N, H, W, C, pix * 32 * (2 * sizeof(bf16_t) + ix), st);
         // larger planes (32 x 32 of yolov5l at 1024 x 1024, 40 x 40 of the 1280 x 1280 tiles without positions): 16 channels per workgroup, still bf16
