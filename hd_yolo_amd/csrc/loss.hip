@@ -270,6 +270,9 @@ __global__ __launch_bounds__(256) void dense_kernel(const LossArgs p) {
             int best = -1;
             int r0 = head[(size_t)pix * na + a0];
             int r1 = two ? head[(size_t)pix * na + a0 + 1] : 0;
+            // the objectness logit travels with the list heads (its address does not depend on them): requested after the walk it was a second memory
+            // round trip per item for the third of the groups that hold an objectness channel
+            const float lg_obj = logits[(size_t)pix * p.ldl + c0 + (has_obj ? i4 : 0)];
             if (r0 | r1) {
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(256) void dense_kernel(const LossArgs p) {
             float g_obj = 0.f;
             if (has_obj) {
                 float go;
-                s_obj += (double)bce(logits[(size_t)pix * p.ldl + c0 + i4], tgt, p.obj_pw, &go);
+                s_obj += (double)bce(lg_obj, tgt, p.obj_pw, &go);
                 g_obj = go * k_obj;
             }
             int a = a0, o = o0;
