@@ -95,7 +95,7 @@ def make_optimizer(model, hyp, batch_total):
 def pmc_traffic():
     """HBM bytes per launch of the roofline kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, see
     profiles/r03_conv3x3_pmc.json and scripts/roofline_kernel.py); None when the file is absent."""
-    for name in ('r05_conv3x3_pmc.json', 'r04_conv3x3_pmc.json', 'r03_conv3x3_pmc.json'):
+    for name in ('r06_conv3x3_pmc.json', 'r05_conv3x3_pmc.json', 'r04_conv3x3_pmc.json', 'r03_conv3x3_pmc.json'):
         try:
             with open(os.path.join(ROOT, 'profiles', name)) as f:
                 return json.load(f)['traffic_bytes_per_launch']
@@ -280,14 +280,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Pre-warm (not counted, not timed): a fresh box starts with cold clocks, cold caches and unbuilt plans, and the driver's command line fixes
-    # --warmup at a handful of steps (62 ms of GPU work in round 4: the timed region then saw 12.49 ms per step where the same build held 11.8-12.1 in
-    # longer runs).  Untimed steps run until >= PREWARM_S seconds of GPU work have gone by; they are the SAME step (forward + loss + backward + SGD
-    # launch) with the warm-up schedule held at iteration 0, where every learning rate is 0: the weights do not move, the counted warm-up and the
-    # timed steps that follow are what they would have been without it.  `steps` / `warmup` on the JSON line stay the requested values.
-    prewarm_target = float(os.environ.get('HDY_BENCH_PREWARM_S', '1.0'))
+    # Pre-warm is OPT-IN (HDY_BENCH_PREWARM_S=<seconds>; round 5 ran it by default and the advisor was right that the headline then was not the
+    # driver's `--warmup W` measurement: with lr = 0 the SGD kernel still integrates the momentum buffers and BatchNorm's running statistics
+    # move).  When asked for, the untimed steps run with the schedule held at iteration 0 and the optimizer's momentum buffers and the BatchNorm
+    # running statistics are put back afterwards, so the counted warm-up starts from the state it would have had; `prewarm_steps` says how many
+    # ran.  The default line is W warm-up steps, then EXACTLY K timed steps (`value`), then a SECOND block of K timed steps reported beside it as
+    # `steady_state` (same fences; by then the clocks and caches are warm) — both numbers, never only the better one.
+    prewarm_target = float(os.environ.get('HDY_BENCH_PREWARM_S', '0'))
     prewarm_s, prewarm_steps = 0.0, 0
     if prewarm_target > 0:
+        keep_buf = {k: v.detach().clone() for k, v in model.state_dict().items() if 'running_' in k or 'num_batches_tracked' in k}
         step()                                    # builds the plans, loads the code objects: not counted towards the target
         it[0] = 0
         torch.cuda.synchronize()
@@ -305,6 +307,12 @@ def main():
                 dtp = tblk.item()
             prewarm_s += dtp
             prewarm_steps += 10
+        with torch.no_grad():                     # back to the state of a process that never pre-warmed: BatchNorm buffers as loaded, no momentum buffers
+            sd_now = model.state_dict()
+            for k, v in keep_buf.items():
+                sd_now[k].copy_(v)
+            opt.state.clear()
+            opt._key = None
     for _ in range(args.warmup):
         step()
     fence()
@@ -322,15 +330,41 @@ def main():
             acc = [acc[0] + t1 - t0, acc[1] + t2 - t1, acc[2] + t3 - t2]
         if rank == 0:
             print('phases ms (fwd+loss, bwd, opt):', [round(a / 5 * 1e3, 2) for a in acc], file=sys.stderr, flush=True)
+    dp_on = world > 1 or force_dist
+    if dp_on:
+        net.reducer.exposed_events = []             # two events around the main stream's wait for the communication stream, every step from here on
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     fence()
-    dt = time.perf_counter() - t0
-    if world > 1 or force_dist:
+    dt_rank = dt = time.perf_counter() - t0
+    dt_min = dt
+    if dp_on:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        tmin = tmax.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = tmax.item()
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        dt, dt_min = tmax.item(), tmin.item()
+    # time the main stream stood waiting for the all-reduce in front of the optimizer (0 = every collective finished under the backward pass): this
+    # rank's average over the timed steps, then the largest over the ranks
+    exposed_ms = None
+    if dp_on:
+        ev = net.reducer.exposed_events
+        net.reducer.exposed_events = None
+        mine = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
+        tex = torch.tensor([mine], device=device, dtype=torch.float64)
+        dist.all_reduce(tex, op=dist.ReduceOp.MAX)
+        exposed_ms = tex.item()
+    # second block of K steps, same fences: the steady-state number beside the headline (never instead of it)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt2 = time.perf_counter() - t0
+    if dp_on:
+        tmax = torch.tensor([dt2], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt2 = tmax.item()
     final_loss = float(loss.detach())
     param_spread = 0.0
     if world > 1 or force_dist:
@@ -354,7 +388,16 @@ def main():
                        'allreduce_calls_per_step': (round(net.reducer.calls / max(nsteps_run[0], 1), 2) if (world > 1 or force_dist) else 0),
                        'param_checksum_spread_over_ranks': param_spread},
             'final_loss': round(final_loss, 4), 'prewarm_s': round(prewarm_s, 3), 'prewarm_steps': prewarm_steps,
+            'steady_state': {'ms_per_step': round(dt2 / args.steps * 1e3, 3), 'value': round(tiles / dt2, 2),
+                             'what': f'a second block of {args.steps} timed steps right after the headline block (same barrier + synchronize on both sides)'},
         }
+        import hd_yolo_amd
+        # self-diagnosis of an N > 1 run: where a scaling loss would come from.  rank_step_ms_min / max: the fastest and the slowest rank's own clock
+        # over the timed block (`ms_per_step` is the max); allreduce_exposed_ms: see above; hw_queues: GPU_MAX_HW_QUEUES as the HIP runtime of this
+        # process read it (the package sets 8 before the runtime loads; `hw_queues_in_time` False = it was already up and the default 4 applies)
+        line['config'].update(rank_step_ms_min=round(dt_min / args.steps * 1e3, 3), rank_step_ms_max=round(dt / args.steps * 1e3, 3),
+                              allreduce_exposed_ms=(None if exposed_ms is None else round(exposed_ms, 4)),
+                              hw_queues=int(os.environ.get('GPU_MAX_HW_QUEUES', '4')), hw_queues_in_time=bool(hd_yolo_amd.HW_QUEUES_IN_TIME))
         from hd_yolo_amd import bench_util
         from hd_yolo_amd.parallel import GradAllReduce
         plan = next(iter(model._eng().plans.values()))
@@ -373,7 +416,7 @@ def main():
         # measured HBM bytes of the whole step (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE over 13 steps, scripts/step_traffic.sh) against the
         # algorithmic bytes: well above 1 = wasted re-reads.  From the committed summary of the same command (PMC passes cannot run inside the timed process).
         pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles')
-        tj = next((n for n in ('r05_step_traffic.json', 'r04_step_traffic.json', 'r03_step_traffic.json') if os.path.exists(os.path.join(pdir, n))), None)
+        tj = next((n for n in ('r06_step_traffic.json', 'r05_step_traffic.json', 'r04_step_traffic.json', 'r03_step_traffic.json') if os.path.exists(os.path.join(pdir, n))), None)
         if args.variant == 's' and args.batch == 64 and args.size == 640 and tj:
             tr = json.load(open(os.path.join(pdir, tj)))
             line['step'].update(traffic_gb_per_step=tr['hbm_gb_per_step'], traffic_ratio=round(tr['hbm_gb_per_step'] / (by / 1e9), 3),

@@ -22,7 +22,9 @@ def _hip_runtime_already_up():
         return False
 
 
-if _hip_runtime_already_up() and (_queues_preset is None or int(_queues_preset or 0) < 8):
+# False: the runtime had started before this import with fewer than 8 queues in its environment (bench.py reports it on every line)
+HW_QUEUES_IN_TIME = not (_hip_runtime_already_up() and (_queues_preset is None or int(_queues_preset or 0) < 8))
+if not HW_QUEUES_IN_TIME:
     # the setdefault above is a no-op for a runtime that has already read its environment: say so LOUDLY, the symptom (the two launch lists of a
     # training step running one after the other as soon as RCCL brings its streams, +6 % per step) is silent
     import warnings

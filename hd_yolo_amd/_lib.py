@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # HDY_LIB: load another build of the same ABI (kernel A/B experiments); it must still sit under csrc/build/
 LIB_PATH = os.path.join(_HERE, 'csrc', 'build', os.path.basename(os.environ.get('HDY_LIB', 'libhdyolo_hip.so')))
 
-ABI_VERSION = 5                   # = HDY_ABI_VERSION of the include/hdyolo.h that SIGNATURES below was written for (tests/test_abi.py holds the two together)
+ABI_VERSION = 6                   # = HDY_ABI_VERSION of the include/hdyolo.h that SIGNATURES below was written for (tests/test_abi.py holds the two together)
 F32, BF16 = 0, 1
 OK, EINVAL, EUNSUPPORTED = 0, -1, -2      # status codes (include/hdyolo.h); positive = hipError_t
 PACK_FWD, PACK_DGRAD, PACK_STEM = 0, 1, 2
@@ -99,6 +99,7 @@ SIGNATURES = {
     'hdy_nchw_to_nhwc': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'hdy_decode': (_I, [_P, _L, _L, _L, _L, _P, _F, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'hdy_nms_workspace_bytes': (_Z, [_I, _I]),
+    'hdy_nms_workspace_bytes_for': (_Z, [_I, _I, _I]),
     'hdy_mask_select': (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _F, _F, _P, _P, _P, _P, _P, _Z, _P]),
     'hdy_softdice_wgrad': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _Z, _P]),
     'hdy_det_outputs': (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _F, _I, _P, _P, _P, _P, _P]),

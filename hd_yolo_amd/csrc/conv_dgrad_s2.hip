@@ -267,12 +267,14 @@ static int dgrad_s2_launch(const ConvArgs& a, hipStream_t st) {
     });
     const int tiles = a.N * (a.Ho / TH) * (a.Wo / TW);
     const int grid = tiles < 512 ? tiles : 512;                  // two ~70 KB, 4-wave workgroups per CU
+#ifdef HDY_PROBE_BUILD      // timing ablations (results wrong) exist only in a -DHDY_PROBE_BUILD library, never in the shipped one
     const int abl = hdy_opt(HDY_OPT_DEEP_DEBUG);
     if constexpr (NP == 2) if (abl) {
 #define ABL_CASE(v) if (abl == v) { (void)hipFuncSetAttribute((const void*)dgrad3x3s2_kernel<NP, NCG, TH, v>, hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM_B); hipLaunchKernelGGL((dgrad3x3s2_kernel<NP, NCG, TH, v>), dim3(grid), dim3(G::NTHR), G::SMEM_B, st, a); return (int)hipGetLastError(); }
         ABL_CASE(1) ABL_CASE(4) ABL_CASE(8) ABL_CASE(12) ABL_CASE(9) ABL_CASE(5) ABL_CASE(16)
 #undef ABL_CASE
     }
+#endif
     hipLaunchKernelGGL((dgrad3x3s2_kernel<NP, NCG, TH>), dim3(grid), dim3(G::NTHR), G::SMEM_B, st, a);
     return (int)hipGetLastError();
 }

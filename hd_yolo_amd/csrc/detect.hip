@@ -162,6 +162,8 @@ struct NmsArgs {
     float* out_extra;             // [B][max_det][row-5-nc] or null
     float* out_conf;              // [B][max_det] ranking score, or null
     int* out_cls;                 // [B][max_det] best class (class_aware) or null
+    float4* kept_g;               // max_det > MAX_KEEP: the kept list lives here, [B][max_det] boxes then [B][max_det] areas (behind the sort workspace)
+    float* kept_area_g;
 };
 
 __device__ __forceinline__ bool iou_gt(float ax1, float ay1, float ax2, float ay2, float aarea, float bx1, float by1, float bx2, float by2,
@@ -214,11 +216,20 @@ __device__ __forceinline__ Cand make_cand(const float* p, int nc, int class_awar
     return c;
 }
 
+// GK: the kept list in global memory (max_det beyond the 4096 entries LDS holds: nms_per_image slices [:max_det] for ANY value,
+// utils_general.py:342).  Same greedy pass, same order; the list is written by one wave and read by the others after a workgroup barrier, which
+// orders global accesses of one workgroup as it orders LDS ones.  The LDS instance keeps its ds_read addressing (a generic pointer would turn them
+// into flat loads).
+template <bool GK>
 __global__ __launch_bounds__(NT) void nms_kernel(const NmsArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* lkeys = (unsigned long long*)smem;                 // [LDS_KEYS]
-    float4* kept = (float4*)(smem + (size_t)LDS_KEYS * 8);                 // [MAX_KEEP]
-    float* kept_area = (float*)(kept + MAX_KEEP);                          // [MAX_KEEP]
+    float4* kept_l = (float4*)(smem + (size_t)LDS_KEYS * 8);               // [MAX_KEEP]
+    float* kept_area_l = (float*)(kept_l + MAX_KEEP);                      // [MAX_KEEP]
+    float4* const kept_gb = GK ? p.kept_g + (size_t)blockIdx.x * p.max_det : nullptr;
+    float* const kept_area_gb = GK ? p.kept_area_g + (size_t)blockIdx.x * p.max_det : nullptr;
+#define kept (GK ? kept_gb : kept_l)
+#define kept_area (GK ? kept_area_gb : kept_area_l)
     __shared__ int wave_cnt[NT / 64];
     __shared__ int base_sh;
     __shared__ int nk_hist[NT / 64 + 1];
@@ -365,6 +376,9 @@ __global__ __launch_bounds__(NT) void nms_kernel(const NmsArgs p) {
     }
 }
 
+#undef kept
+#undef kept_area
+
 inline int next_pow2(int v) {
     int p = 1;
     while (p < v) p <<= 1;
@@ -466,6 +480,32 @@ int hdy_det_grad_pack(const float* g, long long sb, long long sa, long long sy, 
 
 size_t hdy_nms_workspace_bytes(int B, int N) { return (size_t)(B > 0 ? B : 0) * next_pow2(N > 1 ? N : 1) * sizeof(unsigned long long); }
 
+// workspace of a call with this max_det: the sort keys, and beyond 4096 kept boxes per tile the kept list itself (20 bytes per entry)
+size_t hdy_nms_workspace_bytes_for(int B, int N, int max_det) {
+    size_t n = (hdy_nms_workspace_bytes(B, N) + 15) & ~(size_t)15;
+    if (max_det > MAX_KEEP) n += (size_t)(B > 0 ? B : 0) * (size_t)max_det * 20;
+    return n;
+}
+
+static int nms_launch(NmsArgs& a, void* workspace, hipStream_t st, const char* who) {
+    const size_t sort_bytes = (hdy_nms_workspace_bytes(a.B, a.N) + 15) & ~(size_t)15;
+    if (a.max_det > MAX_KEEP) {
+        a.kept_g = (float4*)((char*)workspace + sort_bytes);                        
+        a.kept_area_g = (float*)(a.kept_g + (size_t)a.B * a.max_det);
+        HDY_ARG(((uintptr_t)a.kept_g & 15) == 0, "%s: workspace must be 16-byte aligned", who);
+        const size_t smem = (size_t)LDS_KEYS * 8;
+        (void)hipFuncSetAttribute((const void*)nms_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(nms_kernel<true>, dim3(a.B), dim3(NT), smem, st, a);
+    } else {
+        a.kept_g = nullptr; a.kept_area_g = nullptr;
+        const size_t smem = (size_t)LDS_KEYS * 8 + (size_t)MAX_KEEP * 16 + (size_t)MAX_KEEP * 4;
+        (void)hipFuncSetAttribute((const void*)nms_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(nms_kernel<false>, dim3(a.B), dim3(NT), smem, st, a);
+    }
+    HDY_LAUNCH_CHECK(who);
+    return HDY_OK;
+}
+
 int hdy_nms_batched(const float* preds, int B, int N, int row, int nc, float conf, float iou, int max_det, float min_wh, int class_aware,
                     long long* keep, int* n_keep, float* out_boxes, float* out_scores, float* out_extra, float* out_conf, int* out_cls,
                     void* workspace, size_t ws_bytes, void* stream) {
@@ -475,19 +515,15 @@ int hdy_nms_batched(const float* preds, int B, int N, int row, int nc, float con
     HDY_ARG(N == 0 || preds, "nms: null preds");
     HDY_ARG(nc >= 1 && row >= 5 + nc, "nms: row=%d too short for nc=%d", row, nc);
     HDY_ARG(conf >= 0.f && conf <= 1.f && iou >= 0.f && iou <= 1.f, "nms: thresholds must be in [0,1]");
-    HDY_ARG(max_det >= 1 && max_det <= MAX_KEEP, "nms: max_det=%d outside 1..%d", max_det, MAX_KEEP);
-    HDY_ARG(workspace && ws_bytes >= hdy_nms_workspace_bytes(B, N), "nms: workspace too small");
+    HDY_ARG(max_det >= 1, "nms: max_det=%d must be positive", max_det);
+    HDY_ARG(workspace && ws_bytes >= hdy_nms_workspace_bytes_for(B, N, max_det), "nms: workspace too small");
     HDY_ARG(row == 5 + nc || out_extra, "nms: out_extra required when rows carry extra columns");
     NmsArgs a;
     a.preds = preds; a.B = B; a.N = N; a.row = row; a.nc = nc; a.conf = conf; a.iou = iou; a.max_det = max_det; a.min_wh = min_wh;
     a.class_aware = class_aware; a.xyxy = 0; a.ws = (unsigned long long*)workspace; a.P = next_pow2(N > 1 ? N : 1);
     a.keep = keep; a.n_keep = n_keep; a.out_boxes = out_boxes; a.out_scores = out_scores; a.out_extra = out_extra; a.out_conf = out_conf;
     a.out_cls = out_cls;
-    const size_t smem = (size_t)LDS_KEYS * 8 + (size_t)MAX_KEEP * 16 + (size_t)MAX_KEEP * 4;
-    (void)hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(NT), smem, (hipStream_t)stream, a);
-    HDY_LAUNCH_CHECK("nms");
-    return HDY_OK;
+    return nms_launch(a, workspace, (hipStream_t)stream, "nms");
 }
 
 int hdy_det_outputs(float* scores, const float* boxes, const int* n_keep, int B, int max_det, int nc, const int* pairs, int npairs, float conf,
@@ -508,18 +544,14 @@ int hdy_nms_boxes(const float* boxes_scores, int B, int N, float iou, int max_de
     HDY_ARG(keep && n_keep, "nms_boxes: null output pointer");
     HDY_ARG(N == 0 || boxes_scores, "nms_boxes: null input");
     HDY_ARG(iou >= 0.f && iou <= 1.f, "nms_boxes: iou threshold must be in [0,1]");
-    HDY_ARG(max_det >= 1 && max_det <= MAX_KEEP, "nms_boxes: max_det=%d outside 1..%d", max_det, MAX_KEEP);
-    HDY_ARG(workspace && ws_bytes >= hdy_nms_workspace_bytes(B, N), "nms_boxes: workspace too small");
+    HDY_ARG(max_det >= 1, "nms_boxes: max_det=%d must be positive", max_det);
+    HDY_ARG(workspace && ws_bytes >= hdy_nms_workspace_bytes_for(B, N, max_det), "nms_boxes: workspace too small");
     NmsArgs a;
     a.preds = boxes_scores; a.B = B; a.N = N; a.row = 5; a.nc = 0; a.conf = 0.f; a.iou = iou; a.max_det = max_det; a.min_wh = 0.f;
     a.class_aware = 0; a.xyxy = 1; a.ws = (unsigned long long*)workspace; a.P = next_pow2(N > 1 ? N : 1);
     a.keep = keep; a.n_keep = n_keep; a.out_boxes = nullptr; a.out_scores = nullptr; a.out_extra = nullptr; a.out_conf = nullptr;
     a.out_cls = nullptr;
-    const size_t smem = (size_t)LDS_KEYS * 8 + (size_t)MAX_KEEP * 16 + (size_t)MAX_KEEP * 4;
-    (void)hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(NT), smem, (hipStream_t)stream, a);
-    HDY_LAUNCH_CHECK("nms_boxes");
-    return HDY_OK;
+    return nms_launch(a, workspace, (hipStream_t)stream, "nms_boxes");
 }
 
 }  // extern "C"

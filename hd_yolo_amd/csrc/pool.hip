@@ -528,8 +528,8 @@ int hdy_sppf_pool_fwd(const void* x, void* y1, void* y2, void* y3, int ld, unsig
     hipStream_t st = (hipStream_t)stream;
     if (dtype == HDY_BF16) {
         // bf16 planes, 32 channels per workgroup when they fit (20 x 20: 92 KB with the position plane)
-        // order-preserving keys (sppf_pool_fwd_keys_kernel): the same two shapes of workgroup; HDY_DEEP_DEBUG bit 1024 keeps the float-compare kernels (A/B)
-        const bool keys = !(hdy_opt(HDY_OPT_DEEP_DEBUG) & 1024) && ld % 4 == 0 && ((uintptr_t)x & 7) == 0 && ((uintptr_t)y1 & 7) == 0 && ((uintptr_t)y2 & 7) == 0 &&
+        // order-preserving keys (sppf_pool_fwd_keys_kernel): the same two shapes of workgroup; HDY_SPPF_NO_KEYS keeps the float-compare kernels (A/B)
+        const bool keys = !hdy_opt(HDY_OPT_SPPF_NO_KEYS) && ld % 4 == 0 && ((uintptr_t)x & 7) == 0 && ((uintptr_t)y1 & 7) == 0 && ((uintptr_t)y2 & 7) == 0 &&
                           ((uintptr_t)y3 & 7) == 0;
         if (keys && C % 32 == 0 && pix * 32 * (2 * sizeof(bf16_t) + ix) <= 150 * 1024)
             return sppf_fwd_keys_launch<32, 1024>(x, y1, y2, y3, ld, idx1, idx2, idx3, N, H, W, C, pix * 32 * (2 * sizeof(bf16_t) + ix), st);

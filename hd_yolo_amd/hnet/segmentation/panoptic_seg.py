@@ -64,11 +64,14 @@ class _SegFn(torch.autograd.Function):
             loss, dl = ops.softdice_wgrad(logits, masks, cw, low_w, bufs=run.__dict__.setdefault('_loss_bufs', {}))
         else:
             loss, dl = ops.softdice(logits, masks, cw, want_grad=True)
-        ctx.run, ctx.dl, ctx.grad_of, ctx.dtypes = run, dl, grad_of, [f.dtype for f in feats]
-        return loss
+        ctx.run, ctx.dl, ctx.grad_of, ctx.dtypes, ctx.gen = run, dl, grad_of, [f.dtype for f in feats], run.gen
+        # `loss` (and `dl`) live in the run's persistent buffers, the same storage every step: the caller gets its own element (a history of
+        # `loss.detach()` kept across steps must not all read the latest value)
+        return loss.clone()
 
     @staticmethod
     def backward(ctx, g):
+        ctx.run.check_generation(ctx.gen)
         dfeats = ctx.run.backward(ctx.dl, ctx.grad_of, scale=g, w_reduced=ctx.w_reduced)          # the upstream factor goes in at the connector's resolution
         return (None, None, None, None) + tuple(d.permute(0, 3, 1, 2).to(t) for d, t in zip(dfeats, ctx.dtypes))
 

@@ -150,7 +150,18 @@ class Program:
         n = getattr(self, '_ntok', 0)
         if n:
             with Program._lock:
-                Program._free.append((self.token_base, n))
+                # returned ranges are merged with their neighbours (and with the unissued tail), so a long run of programs of growing size —
+                # tapes re-recorded every step — cannot fragment the table into ranges nobody fits
+                fr = sorted(Program._free + [(self.token_base, n)])
+                merged = []
+                for base, cnt in fr:
+                    if merged and merged[-1][0] + merged[-1][1] == base:
+                        merged[-1] = (merged[-1][0], merged[-1][1] + cnt)
+                    else:
+                        merged.append((base, cnt))
+                if merged and merged[-1][0] + merged[-1][1] == Program._next_token:
+                    Program._next_token = merged.pop()[0]
+                Program._free[:] = merged
 
     def __init__(self, records):
         lib = _lib.load()
@@ -729,8 +740,8 @@ def nms_batched(preds, nc, conf_thres, iou_thres, max_det, min_wh=2.0, class_awa
     extra = torch.empty((B, max_det, max(nex, 1)), dtype=torch.float32, device=dev)
     conf = torch.empty((B, max_det), dtype=torch.float32, device=dev)
     cls = torch.empty((B, max_det), dtype=torch.int32, device=dev)
-    wsb = _lib.query('hdy_nms_workspace_bytes', B, N)
-    ws = torch.empty((max(wsb, 8) // 8,), dtype=torch.int64, device=dev)
+    wsb = _lib.query('hdy_nms_workspace_bytes_for', B, N, int(max_det))
+    ws = torch.empty(((wsb + 15) // 16 * 2,), dtype=torch.int64, device=dev)
     _lib.call('hdy_nms_batched', preds.data_ptr(), B, N, row, nc, float(conf_thres), float(iou_thres), int(max_det), float(min_wh),
               int(class_aware), keep.data_ptr(), n_keep.data_ptr(), boxes.data_ptr(), scores.data_ptr(),
               extra.data_ptr() if nex > 0 else None, conf.data_ptr(), cls.data_ptr(), ws.data_ptr(), ws.numel() * 8, stream_ptr())
@@ -752,7 +763,7 @@ def det_outputs(res, nc, conf_thres, pairs, multi_label=False):
     return boxes, scores, labels
 
 
-NMS_LAUNCH_KEEP = 4096          # kept boxes one hdy_nms_boxes launch can hold (its LDS kept-list)
+NMS_LDS_KEEP = 4096             # kept boxes the NMS kernel holds in LDS; calls with a larger max_det keep the list in the workspace
 
 
 def _nms_launch(boxes, scores, iou_thres, max_det):
@@ -760,8 +771,8 @@ def _nms_launch(boxes, scores, iou_thres, max_det):
     bs = torch.cat([boxes.float(), scores.float().reshape(N, 1)], 1).contiguous()
     keep = torch.empty((1, max_det), dtype=torch.int64, device=boxes.device)
     n_keep = torch.empty((1,), dtype=torch.int32, device=boxes.device)
-    wsb = _lib.query('hdy_nms_workspace_bytes', 1, N)
-    ws = torch.empty((max(wsb, 8) // 8,), dtype=torch.int64, device=boxes.device)
+    wsb = _lib.query('hdy_nms_workspace_bytes_for', 1, N, int(max_det))
+    ws = torch.empty(((wsb + 15) // 16 * 2,), dtype=torch.int64, device=boxes.device)
     _lib.call('hdy_nms_boxes', bs.data_ptr(), 1, N, float(iou_thres), int(max_det), keep.data_ptr(), n_keep.data_ptr(), ws.data_ptr(),
               ws.numel() * 8, stream_ptr())
     return keep[0, :int(n_keep.item())]
@@ -769,47 +780,14 @@ def _nms_launch(boxes, scores, iou_thres, max_det):
 
 def nms(boxes, scores, iou_thres, max_det=None):
     """torchvision.ops.nms(boxes xyxy (N,4), scores (N,), iou) on the GPU: ALL kept indices (int64) in descending score order (ties:
-    lower index first), or the first `max_det` of them.  One launch holds 4096 kept boxes; when that fills up the greedy pass is
-    continued on what is left — the candidates ranked behind the last kept box that none of the kept boxes suppresses — so whole-slide
-    merges of many tiles lose nothing (the reference's torchvision call returns every survivor)."""
+    lower index first), or the first `max_det` of them — one launch whatever the count (up to 4096 kept boxes the kernel's list lives in
+    LDS, beyond that in its workspace), so whole-slide merges of many tiles lose nothing (the reference's torchvision call returns
+    every survivor).  Rounds 2-5 continued the greedy pass in further launches with tensor expressions in between."""
     require_gpu(boxes)
     N = boxes.shape[0]
     if N == 0:
         return torch.empty((0,), dtype=torch.int64, device=boxes.device)
-    want = N if max_det is None else int(max_det)
-    out = _nms_launch(boxes, scores, iou_thres, min(want, NMS_LAUNCH_KEEP))
-    if len(out) < NMS_LAUNCH_KEEP or want <= NMS_LAUNCH_KEEP:
-        return out
-    boxes, scores = boxes.float(), scores.float().reshape(N)
-    cand = torch.arange(N, device=boxes.device)
-    chunks, got = [out], len(out)
-    while True:
-        chunk = chunks[-1]
-        last = chunk[-1]
-        cs = scores[cand]
-        live = (cs < scores[last]) | ((cs == scores[last]) & (cand > last))          # ranked behind the last kept box
-        cand = cand[live]
-        kb = boxes[chunk]
-        karea = (kb[:, 2] - kb[:, 0]) * (kb[:, 3] - kb[:, 1])
-        keep_mask = torch.ones(len(cand), dtype=torch.bool, device=boxes.device)
-        for i in range(0, len(cand), 8192):                                          # IoU against the kept chunk, the kernel's fp32 arithmetic
-            cb = boxes[cand[i:i + 8192]]
-            w = (torch.minimum(cb[:, None, 2], kb[None, :, 2]) - torch.maximum(cb[:, None, 0], kb[None, :, 0])).clamp_(min=0)
-            h = (torch.minimum(cb[:, None, 3], kb[None, :, 3]) - torch.maximum(cb[:, None, 1], kb[None, :, 1])).clamp_(min=0)
-            inter = w * h
-            carea = (cb[:, 2] - cb[:, 0]) * (cb[:, 3] - cb[:, 1])
-            keep_mask[i:i + 8192] = ~((inter / (carea[:, None] + karea[None, :] - inter)) > iou_thres).any(1)
-        cand = cand[keep_mask]
-        if len(cand) == 0 or got >= want:
-            break
-        sub = _nms_launch(boxes[cand], scores[cand], iou_thres, min(want - got, NMS_LAUNCH_KEEP))
-        if len(sub) == 0:
-            break
-        chunks.append(cand[sub])
-        got += len(sub)
-        if len(sub) < NMS_LAUNCH_KEEP:
-            break
-    return torch.cat(chunks)[:want]
+    return _nms_launch(boxes, scores, iou_thres, N if max_det is None else max(1, min(int(max_det), N)))
 
 
 # ------------------------------------------------------------------------------------------ mask branch primitives (row f2)

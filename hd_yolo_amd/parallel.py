@@ -78,6 +78,7 @@ class GradAllReduce:
         self.pending = None       # a ready range not yet sent (too small on its own)
         self.calls = 0            # all_reduce calls issued (tests / diagnostics)
         self.bytes = 0            # bytes handed to them
+        self.exposed_events = None   # a list: __call__ appends an event pair around the main stream's wait for the communication stream (bench.py)
 
     @classmethod
     def expected_sends(cls, marks, numel, split=True):
@@ -182,7 +183,16 @@ class GradAllReduce:
             self._send(flat, a, b, waits=waits)
         self.sent = []
         if flat.is_cuda:
-            torch.cuda.current_stream(flat.device).wait_stream(self.stream)
+            main = torch.cuda.current_stream(flat.device)
+            if self.exposed_events is not None:
+                # elapsed time between the two = how long the main stream stood waiting for the collectives (nothing else lies between them)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(main)
+                main.wait_stream(self.stream)
+                e1.record(main)
+                self.exposed_events.append((e0, e1))
+            else:
+                main.wait_stream(self.stream)
 
 
 class DataParallel:

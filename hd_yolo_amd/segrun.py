@@ -73,6 +73,9 @@ def ladder_stages(seq):
     return out
 
 
+MAX_TAPE_MISSES = 3
+
+
 class PanopticRun:
     """One forward (+ backward) of connector + class head.  feats: NHWC tensors, finest level first (the connector's order)."""
 
@@ -86,23 +89,39 @@ class PanopticRun:
         return ps + [self.class_conv.weight, self.class_conv.bias]
 
     def forward(self, feats, out_size=None, train=False):
-        """Training calls are taped: the first call with a given set of input addresses runs forward_eager under a tape, later ones replay it."""
-        if not (TAPE and train) or any(q.dtype != torch.float32 for q in self._params()):
+        """Training calls are taped: the first call with a given set of input addresses runs forward_eager under a tape, later ones replay it.
+        The executor is shared by every call of its header (activation buffers, tapes): ONE forward per backward.  `gen` counts the forwards;
+        the autograd node remembers the one it belongs to and `check_generation` refuses a backward that another forward has overtaken."""
+        self.gen = self.__dict__.get('gen', 0) + 1
+        if not (TAPE and train) or self.__dict__.get('_no_tape') or any(q.dtype != torch.float32 for q in self._params()):
             self._fwd = self._bwd = None
             return self.forward_eager(feats, out_size, train)
         key = (tuple((f.data_ptr(), tuple(f.shape), tuple(f.stride())) for f in feats), None if out_size is None else tuple(out_size),
                tuple(q.data_ptr() for q in self._params()))
         ent = self.__dict__.get('_fwd')
         if ent is None or ent['key'] != key:
+            # a caller whose inputs / gradient sinks are new tensors every step (a torch backbone, `.grad` re-created by zero_grad(set_to_none=True))
+            # can never hit the key: after MAX_TAPE_MISSES re-recordings in a row the run goes back to plain eager launches for good
+            self._misses = self.__dict__.get('_misses', 0) + (1 if ent is not None else 0)
+            if self._misses >= MAX_TAPE_MISSES:
+                self._no_tape, self._fwd, self._bwd = True, None, None
+                return self.forward_eager(feats, out_size, True)
             tape = ops.Tape()
             with tape:
                 logits = self.forward_eager(feats, out_size, True)
             ent = self._fwd = {'key': key, 'tape': tape, 'logits': logits, 'state': (self.tape, self.total, self.low_shape, self.out_size)}
             self._bwd = None
         else:
+            self._misses = 0
             ent['tape'].replay()
             self.tape, self.total, self.low_shape, self.out_size = ent['state']
         return ent['logits']
+
+    def check_generation(self, gen):
+        if gen != self.__dict__.get('gen'):
+            raise RuntimeError('hd_yolo_amd PanopticSeg: backward() of a segmentation forward that a later forward of the same header has overtaken '
+                               f'(forward #{gen}, the executor is at #{self.__dict__.get("gen")}).  The header keeps ONE set of activation buffers per '
+                               'arithmetic type: run backward before the next forward (training, eval or _logits) of this header.')
 
     def backward(self, dlogits, grad_of, scale=None, w_reduced=False):
         ent = self.__dict__.get('_fwd')
@@ -114,6 +133,7 @@ class PanopticRun:
         key = (ent['key'], dlogits.data_ptr(), tuple(dlogits.shape), bool(w_reduced), tuple(grad_of(q).data_ptr() for q in self._params()))
         bw = self.__dict__.get('_bwd')
         if bw is None or bw['key'] != key:
+            self._misses = self.__dict__.get('_misses', 0) + (1 if bw is not None else 0)
             tape = ops.Tape()
             with tape:
                 dfeats = self.backward_eager(dlogits, grad_of, self._scale, w_reduced, keep=True)

@@ -46,7 +46,7 @@ const char* hdy_last_error(void);
 /* ABI revision of THIS header: bumped whenever an entry point's parameter list, a structure or an option changes meaning.  hdy_version() returns the
  * value the library was built with; a binding written against another revision must refuse the library (hd_yolo_amd/_lib.py:load does) — with
  * plain pointers and sizes a mismatched parameter list would otherwise shift arguments silently. */
-#define HDY_ABI_VERSION 5
+#define HDY_ABI_VERSION 6
 int hdy_version(void);
 /* Which kernel ran: every launcher names the kernel family it picked ("igemm_128x128x2", "conv3x3_c64", "deep_256x128", "wgrad3x3", ...).
  * hdy_last_dispatch: the last pick on this thread; hdy_dispatch_log: every pick of every thread since hdy_dispatch_log_reset(), in launch
@@ -242,13 +242,16 @@ int hdy_nchw_to_nhwc(const float* src, void* dst, int ldd, int N, int C, int H, 
  * non_max_suppression (:423-523; class_aware=1) including torchvision.ops.nms / remove_small_boxes.
  * preds [B][N][row] fp32 with row = 5 + nc + extra.  Outputs per tile: keep[max_det] original row indices in
  * descending-score order (stable: ties by lower row), -1 padded; n_keep; and the gathered rows.
- * max_det <= 4096.  workspace: hdy_nms_workspace_bytes(B, N). */
+ * max_det: any positive value, as the reference's `[:max_det]` slice (utils_general.py:342); up to 4096 the kept list lives in LDS, beyond
+ * that in the workspace (round 6).  workspace (16-byte aligned): hdy_nms_workspace_bytes_for(B, N, max_det) (= hdy_nms_workspace_bytes(B, N)
+ * for max_det <= 4096). */
 int hdy_decode(const float* det, long long sb, long long sa, long long sy, long long sx, const float* anchor_px, float stride, float* out,
                int row_offset, int rows_per_image, int level_id, int B, int na, int ny, int nx, int no, void* stream);
 /* autograd's logits gradient (b,a,y,x,o; element strides) -> NHWC [B][ny][nx][ldo] of dtype, channel a*no+o, zero padded */
 int hdy_det_grad_pack(const float* g, long long sb, long long sa, long long sy, long long sx, long long so, void* out, int ldo, int B, int na,
                       int ny, int nx, int no, int dtype, void* stream);
 size_t hdy_nms_workspace_bytes(int B, int N);
+size_t hdy_nms_workspace_bytes_for(int B, int N, int max_det);
 int hdy_nms_batched(const float* preds, int B, int N, int row, int nc, float conf, float iou, int max_det, float min_wh, int class_aware,
                     long long* keep, int* n_keep, float* out_boxes, float* out_scores, float* out_extra, float* out_conf, int* out_cls,
                     void* workspace, size_t ws_bytes, void* stream);
@@ -264,7 +267,7 @@ int hdy_det_outputs(float* scores, const float* boxes, const int* n_keep, int B,
 
 /* torchvision.ops.nms on explicit boxes, as the reference calls it outside nms_per_image (Ensemble.merge, metayolo/models/yolo.py:189-199):
  * boxes_scores [B][N][5] = (x1, y1, x2, y2, score >= 0) fp32; every row is a candidate; keep[B][max_det] row indices in descending
- * score order (stable), -1 padded; n_keep[B].  Same kernel, workspace and max_det limit as hdy_nms_batched. */
+ * score order (stable), -1 padded; n_keep[B].  Same kernel and workspace rule as hdy_nms_batched (any max_det). */
 int hdy_nms_boxes(const float* boxes_scores, int B, int N, float iou, int max_det, long long* keep, int* n_keep, void* workspace,
                   size_t ws_bytes, void* stream);
 

@@ -195,6 +195,77 @@ def gen_eval_compact(tag, variant, nc, batch, size, conf=0.05):
     print('wrote', f'eval_{tag}.npz', [len(out[f'out_{b}_boxes']) for b in range(batch)])
 
 
+def gen_eval_calibrated(tag, variant, nc, batch, size, conf=0.05):
+    """bf16 detection-level fixture whose scores SEPARATE.  The random-init network's detection logits are flat (yolov5s) or
+    saturated (yolov5l): which 300 of 25 200 candidates survive was decided below bf16 resolution, so a recall against those fixtures said nothing
+    about the bf16 kernels.  Here the three detection convs of the REFERENCE model are rescaled — on the reference, on the CPU, in fp32 — so that each
+    level's logits have unit spread (the calibration bench.py's C4 leg applies, synth.calibrate_det_logits); the factors travel in the fixture and the
+    test applies the same ones, so both sides run identical weights.  Everything stored is the reference's own output."""
+    hyp = synth.make_hyp(conf_thres=conf)
+    model = ref_model(variant, nc, hyp).eval()
+    x = synth.synth_images(batch, size, seed=7)
+    out = {'meta': np.array([batch, size, nc]), 'conf_thres': np.array(conf)}
+    with torch.no_grad():
+        neck = model.neck(dict(model.backbone(x)))
+        head = model.headers['det']
+        scales = []
+        for i, conv in enumerate(head.m):
+            sd = float(conv(neck[head.f[i]]).float().std())
+            scales.append(max(sd, 1e-6))
+            conv.weight.div_(scales[-1])
+        out['det_scales'] = np.array(scales, dtype=np.float64)
+        for i, conv in enumerate(head.m):
+            f = conv(neck[head.f[i]])
+            bs, _, ny, nx = f.shape
+            d = f.view(bs, head.na, head.no, ny, nx).permute(0, 1, 3, 4, 2).contiguous()
+            d64 = d.double()
+            out[f'det_{i}_sums'] = np.array([d64.sum().item(), d64.abs().sum().item(), d64.pow(2).sum().sqrt().item()])
+            out[f'det_{i}_strip'] = npf(d[:1, :1, :4])
+        _, outputs = model(x)
+        for b, o in enumerate(outputs):
+            out[f'out_{b}_boxes'] = npf(o['det']['boxes'])
+            out[f'out_{b}_scores'] = npf(o['det']['scores'])
+            out[f'out_{b}_labels'] = npf(o['det']['labels'])
+    np.savez_compressed(os.path.join(HERE, f'eval_cal_{tag}.npz'), **out)
+    sc = np.concatenate([out[f'out_{b}_scores'] for b in range(batch)])
+    print('wrote', f'eval_cal_{tag}.npz', [len(out[f'out_{b}_boxes']) for b in range(batch)], 'scores min / median / max', sc.min(), np.median(sc), sc.max(),
+          'scales', scales)
+
+
+def gen_trajectory(tag, variant, nc, batch, size, steps, nmin, nmax, lr=0.01):
+    """Loss trajectory of the reference over `steps` optimizer steps on one fixed batch: torch.optim.SGD(momentum 0.937, nesterov) over the three
+    parameter groups of train.py:208-233 with a constant learning rate — the loop body of train.py:455-472 without the loader.  Pins that the HIP
+    path TRAINS like the reference (fp32 step by step) and bounds what bf16 storage does to the trajectory (tests/test_gpu_model.py)."""
+    hyp = synth.make_hyp()
+    model = ref_model(variant, nc, hyp).train()
+    x = synth.synth_images(batch, size, seed=11)
+    targets = synth.synth_targets(batch, size, nc, nmin=nmin, nmax=nmax, seed=5)
+    g_bn, g_w, g_b = [], [], []
+    for m in model.modules():
+        if hasattr(m, 'bias') and isinstance(m.bias, nn.Parameter):
+            g_b.append(m.bias)
+        if isinstance(m, nn.BatchNorm2d):
+            g_bn.append(m.weight)
+        elif hasattr(m, 'weight') and isinstance(m.weight, nn.Parameter):
+            g_w.append(m.weight)
+    opt = torch.optim.SGD(g_bn, lr=lr, momentum=hyp['momentum'], nesterov=True)
+    opt.add_param_group({'params': g_w, 'weight_decay': hyp['weight_decay']})
+    opt.add_param_group({'params': g_b})
+    losses = []
+    torch.set_num_threads(1)                    # deterministic objectness scatter (see gen_train)
+    for _ in range(steps):
+        out, _ = model(x, targets, compute_masks=True)
+        loss = out['det']['det_loss']
+        loss.backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        losses.append(float(loss.detach()))
+    torch.set_num_threads(8)
+    np.savez_compressed(os.path.join(HERE, f'trajectory_{tag}.npz'), meta=np.array([batch, size, nc, nmin, nmax, steps]), lr=np.array(lr),
+                        weight_decay=np.array(hyp['weight_decay']), momentum=np.array(hyp['momentum']), losses=np.array(losses, dtype=np.float64))
+    print('wrote', f'trajectory_{tag}.npz', [round(v, 4) for v in losses])
+
+
 GRAD_KEYS = ['backbone.0.conv.weight', 'backbone.1.conv.weight', 'backbone.2.m.0.cv2.conv.weight',
              'backbone.2.cv3.conv.weight', 'backbone.2.cv1.bn.weight', 'backbone.2.cv1.bn.bias',
              'backbone.9.cv2.conv.weight', 'neck.3.cv3.conv.weight', 'neck.8.conv.weight',
@@ -663,6 +734,11 @@ def main():
         gen_train('c1_640', 'n', 2, 4, 640, 50, 400)
         gen_eval_compact('c1_640', 'n', 2, 4, 640)
         gen_eval_compact('s_640', 's', 8, 2, 640)
+        return
+    if sys.argv[1:] == ['calibrated']:         # round 6: bf16 detection-level fixtures whose scores separate; a 30-step loss trajectory
+        gen_eval_calibrated('s_640', 's', 8, 2, 640)
+        gen_eval_calibrated('l_256', 'l', 8, 1, 256)
+        gen_trajectory('n_128', 'n', 2, 4, 128, 30, 4, 12)
         return
     if sys.argv[1:] == ['seg']:
         gen_seg()

@@ -51,6 +51,9 @@ def test_pure_host_queries(lib):
     # stride-2 dgrad = four parity classes holding 1+2+2+4 = 9 taps in total
     assert lib.hdy_conv_pack_elems(128, 64, 3, 3, 2, 1, _lib.PACK_DGRAD, _lib.BF16) == 64 * 128 * 9
     assert lib.hdy_nms_workspace_bytes(2, 25200) == 2 * 32768 * 8
+    # up to 4096 kept boxes the list lives in LDS; beyond, 20 bytes per entry behind the sort keys (any max_det is served, utils_general.py:342)
+    assert lib.hdy_nms_workspace_bytes_for(2, 25200, 300) == 2 * 32768 * 8 and lib.hdy_nms_workspace_bytes_for(2, 25200, 4096) == 2 * 32768 * 8
+    assert lib.hdy_nms_workspace_bytes_for(2, 25200, 5000) == 2 * 32768 * 8 + 2 * 5000 * 20
     assert lib.hdy_bn_bwd_blocks(10) == 1 and lib.hdy_bn_bwd_blocks(10 ** 7) == 1024
 
 

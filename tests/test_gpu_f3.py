@@ -26,7 +26,6 @@ def test_nms_boxes_bit_exact_order(n, iou):
     scores[::7] = scores[0]                       # ties: lower index first
     want = nms_ref.nms_numpy(boxes.numpy(), scores.numpy(), iou)
     got = ops.nms(boxes.to(DEV), scores.to(DEV), iou).cpu().numpy()
-    assert len(want) <= 4096, 'test sized for the kept-list capacity'
     np.testing.assert_array_equal(got, want)
 
 
@@ -126,8 +125,8 @@ def test_non_max_suppression_every_option_matches_reference():
 
 # ---------------------------------------------------------------------------------------------- round 2 additions
 def test_nms_boxes_negative_scores_and_more_than_one_launch_of_survivors():
-    """torchvision.ops.nms takes scores of any sign and returns EVERY survivor: the wrapper continues the greedy pass when one
-    launch's 4096-entry kept list fills up (whole-slide merges), and ranks negative scores below positive ones."""
+    """torchvision.ops.nms takes scores of any sign and returns EVERY survivor: beyond the 4096 entries of the LDS kept list the kernel keeps
+    its list in the workspace (whole-slide merges; round 6: one launch), and ranks negative scores below positive ones."""
     g = torch.Generator().manual_seed(5)
     n = 14000
     c = torch.rand((n, 2), generator=g) * 4000                    # sparse: most boxes survive

@@ -556,9 +556,29 @@ def test_nms_class_aware_and_edges():
     _check_nms(p, 1, 0.15, 0.45, 300)
 
 
+@pytest.mark.parametrize('max_det', [5000, 20000])
+def test_nms_per_image_with_max_det_beyond_the_lds_kept_list(max_det):
+    """the reference slices `[:max_det]` for any value (utils_general.py:342); beyond 4096 kept boxes the kernel's list
+    lives in its workspace.  M = 16 384 survivors, sparse boxes so that most of them are kept: bit-exact order against oracle/nms_ref.c, for
+    two tiles in one launch (the second one dense: its list stays short), and the result of a max_det that is not reached equals the full one."""
+    g = torch.Generator().manual_seed(max_det)
+    N = 16384
+    preds = torch.zeros((2, N, 13))
+    preds[0, :, 0:2] = torch.rand((N, 2), generator=g) * 6000           # sparse: nearly every box survives
+    preds[1, :, 0:2] = torch.rand((N, 2), generator=g) * 500            # dense
+    preds[:, :, 2:4] = 8 + torch.rand((2, N, 2), generator=g) * 24
+    preds[:, :, 4] = 0.2 + torch.rand((2, N), generator=g) * 0.8
+    preds[0, ::13, 4] = preds[0, 5, 4]                                  # ties: lower row first
+    preds[:, :, 5:] = torch.rand((2, N, 8), generator=g)
+    nk = _check_nms(preds, 8, 0.15, 0.45, max_det)
+    assert nk[0] == min(max_det, nk[0]) and nk[0] > 4096 and nk[1] < nk[0]
+    if max_det == 20000:
+        assert nk[0] < max_det                                           # every survivor returned, not a truncated list
+
+
 def test_errors_are_loud():
     with pytest.raises(_lib.HdyError):
-        ops.nms_batched(torch.zeros((1, 4, 7), device=DEV), 1, 0.15, 0.45, 5000)      # max_det > 4096
+        ops.nms_batched(torch.zeros((1, 4, 7), device=DEV), 1, 0.15, 0.45, 0)         # max_det must be positive (any positive value is served)
     with pytest.raises(_lib.HdyError):
         ops.require_gpu(torch.zeros(1))
     x = torch.zeros((1, 4, 4, 12), dtype=torch.bfloat16, device=DEV)                   # C not a multiple of 8

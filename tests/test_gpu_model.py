@@ -142,7 +142,7 @@ def _iou_matrix(a, b):
 # synth_state_dict's gain the 8-class yolov5s' objectness logits are nearly flat over a tile's 25 200 candidates, so WHICH 300 survive the
 # threshold-and-NMS is decided by logit differences below bf16's resolution: the same sensitivity test_train_step_bf16_is_close_to_fp32 documents
 # for its gradients.  The floors sit a few points under the measurements.
-BF16_DETECTION_RECALL = {'c1_640': 0.97, 's_640': 0.30}
+BF16_DETECTION_RECALL = {'c1_640': 0.97, 's_640': 0.30}      # 's_640': a sensitivity note, not a pinned result — see BF16_CALIBRATED_RECALL below
 
 
 @pytest.mark.parametrize('tag,variant', [('c1_640', 'n'), ('s_640', 's')])
@@ -183,6 +183,118 @@ def test_full_size_eval_bf16_detections_against_reference_golden(golden_dir, tag
     print(f'bf16 detections vs reference fp32 goldens [{tag}]: recall@IoU0.9 per tile {[round(f, 3) for f in fracs]} mean {frac:.3f}, recall@IoU0.5 {np.mean(half):.3f}, '
           f'mean best IoU {np.mean(ious):.3f}, kept {[len(outputs[b]["det"]["boxes"]) for b in range(batch)]}')
     assert frac >= BF16_DETECTION_RECALL[tag], (frac, BF16_DETECTION_RECALL[tag])
+
+
+# Round 6: fixtures whose scores SEPARATE.  tests/golden/make_golden.py `calibrated` rescales the reference model's three detection
+# convs on the CPU so that every level's logits have unit spread (what a trained detector's look like; synth.calibrate_det_logits does the same for
+# the C4 bench) and stores the factors; the test applies the same factors, so both sides run identical weights.  The flat-score 's_640' row above stays
+# as a SENSITIVITY NOTE (0.30 floor: "mostly different boxes" there is decided below bf16 resolution and says nothing about the kernels); what
+# protects the bf16 kernels is the unit-by-unit test further down, what protects bf16 DETECTIONS is this one.  Floors: measured, then pinned a few points under.
+BF16_CALIBRATED_RECALL = {'s_640': 0.90, 'l_256': 0.90}
+
+
+def _calibrated_model(g, variant, nc, half):
+    model = build(variant, nc, synth.make_hyp(conf_thres=float(g['conf_thres'])))
+    with torch.no_grad():
+        for conv, sc in zip(model.headers['det'].m, g['det_scales']):
+            conv.weight.div_(float(sc))
+    model.eval()
+    return model.half() if half else model
+
+
+@pytest.mark.parametrize('tag,variant', [('s_640', 's'), ('l_256', 'l')])
+def test_calibrated_eval_detections_fp32_and_bf16_against_reference_golden(golden_dir, tag, variant):
+    """The reference's fp32 detections on logit-calibrated weights (eval_cal_*.npz) against (a) the HIP fp32 path: logits to 1e-4, boxes as the other
+    full-size goldens; (b) `model.half().eval()` (val_nuclei.py:116,143), the bf16 kernels of the benchmark (dispatch log asserted): recall of the
+    reference's detections at IoU >= 0.9 with equal labels."""
+    from hd_yolo_amd import _lib
+    g = np.load(os.path.join(golden_dir, f'eval_cal_{tag}.npz'))
+    batch, size, nc = (int(v) for v in g['meta'])
+    x = synth.synth_images(batch, size, seed=7).to(DEV)
+    # (a) fp32
+    model = _calibrated_model(g, variant, nc, half=False)
+    with torch.no_grad():
+        _, outputs = model(x)
+        plan = list(model._eng().plans.values())[-1]
+        for i, d in enumerate(plan.det_views()):
+            d64 = d.double()
+            got = np.array([d64.sum().item(), d64.abs().sum().item(), d64.pow(2).sum().sqrt().item()])
+            assert abs(got[2] - g[f'det_{i}_sums'][2]) <= 1e-4 * g[f'det_{i}_sums'][2], (i, got, g[f'det_{i}_sums'])
+    for b in range(batch):
+        rb, gb = g[f'out_{b}_boxes'], outputs[b]['det']['boxes'].cpu().numpy()
+        iou = _iou_matrix(rb, gb)
+        assert (iou.max(1) >= 0.999).mean() >= 0.99, f'fp32 detections of tile {b} differ from the reference'
+    # (b) bf16, on the kernels the benchmark runs
+    model = _calibrated_model(g, variant, nc, half=True)
+    with _lib.option('HDY_DEEP_MIN_TILES', 1):
+        _lib.dispatch_log(reset=True)
+        with torch.no_grad():
+            _, outputs = model(x)
+        log = set(_lib.dispatch_log(reset=True))
+    assert any(n.startswith('deep_256x') for n in log), sorted(log)
+    if variant == 's':
+        assert 'conv3x3_c64' in log, sorted(log)
+    fracs, ious = [], []
+    for b in range(batch):
+        o = outputs[b]['det']
+        rb, rl = g[f'out_{b}_boxes'], g[f'out_{b}_labels']
+        gb, gl = o['boxes'].float().cpu().numpy(), o['labels'].cpu().numpy()
+        assert len(gb) > 0 and np.isfinite(gb).all()
+        iou = _iou_matrix(rb, gb)
+        iou[rl[:, None] != gl[None, :]] = 0.0
+        best = iou.max(1)
+        fracs.append(float((best >= 0.9).mean()))
+        ious.append(float(best.mean()))
+    frac = float(np.mean(fracs))
+    print(f'bf16 detections vs reference fp32 goldens, calibrated logits [{tag}]: recall@IoU0.9 per tile {[round(f, 3) for f in fracs]} mean {frac:.3f}, '
+          f'mean best IoU {np.mean(ious):.3f}, kept {[len(outputs[b]["det"]["boxes"]) for b in range(batch)]}')
+    assert frac >= BF16_CALIBRATED_RECALL[tag], (frac, BF16_CALIBRATED_RECALL[tag])
+
+
+def test_loss_trajectory_fp32_follows_the_reference_and_bf16_stays_in_its_band(golden_dir):
+    """30 optimizer steps on one fixed batch (yolov5n, 2 classes, 4 tiles of 128 x 128): the reference's own losses (trajectory_n_128.npz: its modules,
+    torch.optim.SGD with train.py's three parameter groups) against the HIP path in fp32 — step by step, the tolerance growing with the step because
+    thirty updates amplify fp32 reduction-order noise — and against the bf16 path: same seeds, the trajectory must stay inside a stated band around
+    the fp32 one and end within 5 % of it (bf16 storage moves single gradients to cosine ~0.9, DESIGN.md section 6: this is the evidence that
+    training survives it)."""
+    from hd_yolo_amd.optim import SGD
+    g = np.load(os.path.join(golden_dir, 'trajectory_n_128.npz'))
+    batch, size, nc, nmin, nmax, steps = (int(v) for v in g['meta'])
+    ref = g['losses']
+    runs = {}
+    for half in (False, True):
+        model = build('n', nc).train()
+        if half:
+            model.half()
+        x = synth.synth_images(batch, size, seed=11).to(DEV)
+        targets = synth.synth_targets(batch, size, nc, nmin=nmin, nmax=nmax, seed=5)
+        g_bn, g_w, g_b = [], [], []
+        for m in model.modules():
+            if hasattr(m, 'bias') and isinstance(m.bias, torch.nn.Parameter):
+                g_b.append(m.bias)
+            if isinstance(m, torch.nn.BatchNorm2d):
+                g_bn.append(m.weight)
+            elif hasattr(m, 'weight') and isinstance(m.weight, torch.nn.Parameter):
+                g_w.append(m.weight)
+        opt = SGD(g_bn, lr=float(g['lr']), momentum=float(g['momentum']), nesterov=True)
+        opt.add_param_group({'params': g_w, 'weight_decay': float(g['weight_decay'])})
+        opt.add_param_group({'params': g_b})
+        losses = []
+        for _ in range(steps):
+            out, _ = model(x, targets)
+            loss = out['det']['det_loss']
+            loss.backward()
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            losses.append(float(loss.detach()))
+        runs[half] = np.array(losses)
+    rel32 = np.abs(runs[False] - ref) / ref
+    rel16 = np.abs(runs[True] - runs[False]) / runs[False]
+    print('loss trajectory: reference first / last', ref[0], ref[-1], '| fp32 max rel', rel32.max(), 'at step', int(rel32.argmax()),
+          '| bf16 vs fp32 max rel', rel16.max(), 'final', rel16[-1])
+    assert rel32[0] < 2e-4 and (rel32 < 2e-4 + 1e-3 * np.arange(steps)).all(), rel32
+    assert rel16.max() < 0.15 and rel16[-1] < 0.05, rel16
+    assert runs[True][-1] < 0.2 * runs[True][0]
 
 
 def test_backbone_neck_head_called_separately_match_reference(golden_dir):

@@ -244,6 +244,36 @@ def test_taped_segmentation_steps_equal_the_eager_ones(half):
         assert torch.equal(p, results[False][1][k]), k
 
 
+def test_segmentation_loss_is_the_callers_own_and_a_stale_backward_is_refused():
+    """the header keeps one executor (activation buffers, loss buffers, tapes) per arithmetic type.  (a) the returned loss must not alias
+    the executor's loss buffer — a history of `loss.detach()` kept across steps would all read the latest value; (b) a backward whose forward has been
+    overtaken by another forward of the same header must raise, not silently use the later activations."""
+    B, S, nc, ncls = 2, 64, 2, 3
+    x1, x2 = synth.synth_images(B, S, seed=3).to(DEV), synth.synth_images(B, S, seed=9).to(DEV)
+    det_t = synth.synth_targets(B, S, nc, nmin=3, nmax=8, seed=4)
+    lab = torch.randint(0, ncls, (B, S, S), generator=torch.Generator().manual_seed(6))
+    masks = F.one_hot(lab, ncls).permute(0, 3, 1, 2).float().contiguous().to(DEV)
+    targets = []
+    for i, t in enumerate(det_t):
+        anns = {k: [{kk: (vv.to(DEV) if torch.is_tensor(vv) else vv) for kk, vv in a.items()} for a in v] for k, v in t['anns'].items()}
+        anns['seg'] = [{'roi': torch.tensor([0.0, 0.0, S, S]), 'masks': masks[i]}]
+        targets.append({**t, 'anns': anns})
+    m = _hnet(nc, ncls).to(DEV).train()
+    l1, _ = m(x1, targets)
+    kept = l1['seg_soft_iou_loss'].detach()
+    v1 = float(kept)
+    l1['seg_soft_iou_loss'].backward()
+    m.zero_grad(set_to_none=True)
+    l2, _ = m(x2, targets)
+    assert float(l2['seg_soft_iou_loss']) != v1
+    assert float(kept) == v1                                  # the first step's loss still reads the first step's value
+    # a second forward before the first one's backward: the stale backward is refused with a message that names the rule
+    l3, _ = m(x1, targets)
+    with pytest.raises(RuntimeError, match='overtaken'):
+        l2['seg_soft_iou_loss'].backward()
+    l3['seg_soft_iou_loss'].backward()                        # the latest forward's backward still runs
+
+
 def test_hnet_eval_outputs():
     m = _hnet().to(DEV).eval()
     x = synth.synth_images(2, 64, seed=3).to(DEV)
