@@ -235,35 +235,50 @@ def gen_eval_calibrated(tag, variant, nc, batch, size, conf=0.05):
 def gen_trajectory(tag, variant, nc, batch, size, steps, nmin, nmax, lr=0.01):
     """Loss trajectory of the reference over `steps` optimizer steps on one fixed batch: torch.optim.SGD(momentum 0.937, nesterov) over the three
     parameter groups of train.py:208-233 with a constant learning rate — the loop body of train.py:455-472 without the loader.  Pins that the HIP
-    path TRAINS like the reference (fp32 step by step) and bounds what bf16 storage does to the trajectory (tests/test_gpu_model.py)."""
+    path TRAINS like the reference (fp32 step by step) and bounds what bf16 storage does to the trajectory (tests/test_gpu_model.py).
+    The loop is chaotic (train-mode BatchNorm over 4 tiles, random weights): the fixture therefore also holds the reference's OWN deviation from
+    itself — the same loop with 8 host threads instead of 1 (another fp32 summation order) and with every weight perturbed by 1e-6 relative — which is
+    the band any faithful implementation can be held to beyond the first few steps."""
     hyp = synth.make_hyp()
-    model = ref_model(variant, nc, hyp).train()
-    x = synth.synth_images(batch, size, seed=11)
-    targets = synth.synth_targets(batch, size, nc, nmin=nmin, nmax=nmax, seed=5)
-    g_bn, g_w, g_b = [], [], []
-    for m in model.modules():
-        if hasattr(m, 'bias') and isinstance(m.bias, nn.Parameter):
-            g_b.append(m.bias)
-        if isinstance(m, nn.BatchNorm2d):
-            g_bn.append(m.weight)
-        elif hasattr(m, 'weight') and isinstance(m.weight, nn.Parameter):
-            g_w.append(m.weight)
-    opt = torch.optim.SGD(g_bn, lr=lr, momentum=hyp['momentum'], nesterov=True)
-    opt.add_param_group({'params': g_w, 'weight_decay': hyp['weight_decay']})
-    opt.add_param_group({'params': g_b})
-    losses = []
-    torch.set_num_threads(1)                    # deterministic objectness scatter (see gen_train)
-    for _ in range(steps):
-        out, _ = model(x, targets, compute_masks=True)
-        loss = out['det']['det_loss']
-        loss.backward()
-        opt.step()
-        opt.zero_grad(set_to_none=True)
-        losses.append(float(loss.detach()))
+
+    def run(threads, perturb=0.0):
+        torch.set_num_threads(threads)          # 1: deterministic objectness scatter (see gen_train)
+        model = ref_model(variant, nc, hyp).train()
+        if perturb:
+            gen = torch.Generator().manual_seed(123)
+            with torch.no_grad():
+                for q in model.parameters():
+                    q.mul_(1 + perturb * torch.randn(q.shape, generator=gen))
+        x = synth.synth_images(batch, size, seed=11)
+        targets = synth.synth_targets(batch, size, nc, nmin=nmin, nmax=nmax, seed=5)
+        g_bn, g_w, g_b = [], [], []
+        for m in model.modules():
+            if hasattr(m, 'bias') and isinstance(m.bias, nn.Parameter):
+                g_b.append(m.bias)
+            if isinstance(m, nn.BatchNorm2d):
+                g_bn.append(m.weight)
+            elif hasattr(m, 'weight') and isinstance(m.weight, nn.Parameter):
+                g_w.append(m.weight)
+        opt = torch.optim.SGD(g_bn, lr=lr, momentum=hyp['momentum'], nesterov=True)
+        opt.add_param_group({'params': g_w, 'weight_decay': hyp['weight_decay']})
+        opt.add_param_group({'params': g_b})
+        losses = []
+        for _ in range(steps):
+            out, _ = model(x, targets, compute_masks=True)
+            loss = out['det']['det_loss']
+            loss.backward()
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            losses.append(float(loss.detach()))
+        return np.array(losses, dtype=np.float64)
+
+    losses, l8, lp = run(1), run(8), run(1, 1e-6)
     torch.set_num_threads(8)
     np.savez_compressed(os.path.join(HERE, f'trajectory_{tag}.npz'), meta=np.array([batch, size, nc, nmin, nmax, steps]), lr=np.array(lr),
-                        weight_decay=np.array(hyp['weight_decay']), momentum=np.array(hyp['momentum']), losses=np.array(losses, dtype=np.float64))
-    print('wrote', f'trajectory_{tag}.npz', [round(v, 4) for v in losses])
+                        weight_decay=np.array(hyp['weight_decay']), momentum=np.array(hyp['momentum']), losses=losses, losses_8_threads=l8,
+                        losses_perturbed_1e6=lp)
+    print('wrote', f'trajectory_{tag}.npz', [round(v, 4) for v in losses], 'own deviation: 8 threads', float((np.abs(l8 - losses) / losses).max()),
+          'weights * (1 + 1e-6 n)', float((np.abs(lp - losses) / losses).max()))
 
 
 GRAD_KEYS = ['backbone.0.conv.weight', 'backbone.1.conv.weight', 'backbone.2.m.0.cv2.conv.weight',
@@ -738,6 +753,9 @@ def main():
     if sys.argv[1:] == ['calibrated']:         # round 6: bf16 detection-level fixtures whose scores separate; a 30-step loss trajectory
         gen_eval_calibrated('s_640', 's', 8, 2, 640)
         gen_eval_calibrated('l_256', 'l', 8, 1, 256)
+        gen_trajectory('n_128', 'n', 2, 4, 128, 30, 4, 12)
+        return
+    if sys.argv[1:] == ['trajectory']:
         gen_trajectory('n_128', 'n', 2, 4, 128, 30, 4, 12)
         return
     if sys.argv[1:] == ['seg']:

@@ -565,13 +565,13 @@ def test_nms_per_image_with_max_det_beyond_the_lds_kept_list(max_det):
     N = 16384
     preds = torch.zeros((2, N, 13))
     preds[0, :, 0:2] = torch.rand((N, 2), generator=g) * 6000           # sparse: nearly every box survives
-    preds[1, :, 0:2] = torch.rand((N, 2), generator=g) * 500            # dense
+    preds[1, :, 0:2] = torch.rand((N, 2), generator=g) * 120            # dense: a short kept list in the same launch
     preds[:, :, 2:4] = 8 + torch.rand((2, N, 2), generator=g) * 24
     preds[:, :, 4] = 0.2 + torch.rand((2, N), generator=g) * 0.8
     preds[0, ::13, 4] = preds[0, 5, 4]                                  # ties: lower row first
     preds[:, :, 5:] = torch.rand((2, N, 8), generator=g)
     nk = _check_nms(preds, 8, 0.15, 0.45, max_det)
-    assert nk[0] == min(max_det, nk[0]) and nk[0] > 4096 and nk[1] < nk[0]
+    assert nk[0] > 4096 and nk[1] < 4096
     if max_det == 20000:
         assert nk[0] < max_det                                           # every survivor returned, not a truncated list
 

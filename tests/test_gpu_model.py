@@ -190,7 +190,11 @@ def test_full_size_eval_bf16_detections_against_reference_golden(golden_dir, tag
 # the C4 bench) and stores the factors; the test applies the same factors, so both sides run identical weights.  The flat-score 's_640' row above stays
 # as a SENSITIVITY NOTE (0.30 floor: "mostly different boxes" there is decided below bf16 resolution and says nothing about the kernels); what
 # protects the bf16 kernels is the unit-by-unit test further down, what protects bf16 DETECTIONS is this one.  Floors: measured, then pinned a few points under.
-BF16_CALIBRATED_RECALL = {'s_640': 0.90, 'l_256': 0.90}
+# Measured on MI355X (round 6): yolov5s @640 — logits 0.5-0.9 % relative L2 from the reference's fp32 logits, recall@IoU0.9 0.600, recall@IoU0.5 0.957, the reference's
+# 100 best detections 0.965 at IoU 0.5; yolov5l @256 — logits 0.5-0.6 %, 0.917 / 0.923 / 0.970.  The LOGIT bound is the one that fails for the right reason (a wrong
+# bf16 kernel moves it by orders of magnitude); the detection recalls say what that 1 % does downstream: with random weights neighbouring cells / anchors predict
+# near-equal boxes and objectness, so NMS picks another representative of the same object (IoU 0.5-0.9) — recall@0.5 is 0.92-0.96 while recall@0.9 is 0.6-0.9.
+BF16_CALIBRATED = {'s_640': {'logit_l2': 0.02, 'r90': 0.55, 'r50': 0.93, 'top100_r50': 0.93}, 'l_256': {'logit_l2': 0.02, 'r90': 0.87, 'r50': 0.89, 'top100_r50': 0.93}}
 
 
 def _calibrated_model(g, variant, nc, half):
@@ -234,29 +238,47 @@ def test_calibrated_eval_detections_fp32_and_bf16_against_reference_golden(golde
     assert any(n.startswith('deep_256x') for n in log), sorted(log)
     if variant == 's':
         assert 'conv3x3_c64' in log, sorted(log)
-    fracs, ious = [], []
+    # the bf16 network's logits against the reference's (the fixture's strip: first tile, first anchor, four grid rows of every level): the error that
+    # every detection-level difference below comes from
+    plan = list(model._eng().plans.values())[-1]
+    errs = []
+    for i, d in enumerate(plan.det_views()):
+        ref = torch.from_numpy(g[f'det_{i}_strip'])
+        got = d[:1, :1, :4].float().cpu()
+        errs.append(float((got - ref).norm() / ref.norm()))
+    r90, r50, top50, ious = [], [], [], []
     for b in range(batch):
         o = outputs[b]['det']
-        rb, rl = g[f'out_{b}_boxes'], g[f'out_{b}_labels']
+        rb, rl, rs = g[f'out_{b}_boxes'], g[f'out_{b}_labels'], g[f'out_{b}_scores']
         gb, gl = o['boxes'].float().cpu().numpy(), o['labels'].cpu().numpy()
         assert len(gb) > 0 and np.isfinite(gb).all()
         iou = _iou_matrix(rb, gb)
         iou[rl[:, None] != gl[None, :]] = 0.0
         best = iou.max(1)
-        fracs.append(float((best >= 0.9).mean()))
+        r90.append(float((best >= 0.9).mean()))
+        r50.append(float((best >= 0.5).mean()))
+        top = np.argsort(-rs.reshape(-1))[:100]                 # the reference's 100 highest-scoring detections: far from the 300th-place cut
+        top50.append(float((best[top] >= 0.5).mean()))
         ious.append(float(best.mean()))
-    frac = float(np.mean(fracs))
-    print(f'bf16 detections vs reference fp32 goldens, calibrated logits [{tag}]: recall@IoU0.9 per tile {[round(f, 3) for f in fracs]} mean {frac:.3f}, '
-          f'mean best IoU {np.mean(ious):.3f}, kept {[len(outputs[b]["det"]["boxes"]) for b in range(batch)]}')
-    assert frac >= BF16_CALIBRATED_RECALL[tag], (frac, BF16_CALIBRATED_RECALL[tag])
+    m90, m50, mtop = float(np.mean(r90)), float(np.mean(r50)), float(np.mean(top50))
+    print(f'bf16 detections vs reference fp32 goldens, calibrated logits [{tag}]: logits rel. L2 error per level {[round(e, 4) for e in errs]}; '
+          f'recall@IoU0.9 {m90:.3f} {[round(f, 3) for f in r90]}, recall@IoU0.5 {m50:.3f}, top-100 recall@IoU0.5 {mtop:.3f}, mean best IoU {np.mean(ious):.3f}, '
+          f'kept {[len(outputs[b]["det"]["boxes"]) for b in range(batch)]}')
+    lim = BF16_CALIBRATED[tag]
+    assert max(errs) <= lim['logit_l2'], (errs, lim)
+    assert m90 >= lim['r90'] and m50 >= lim['r50'] and mtop >= lim['top100_r50'], (m90, m50, mtop, lim)
 
 
 def test_loss_trajectory_fp32_follows_the_reference_and_bf16_stays_in_its_band(golden_dir):
     """30 optimizer steps on one fixed batch (yolov5n, 2 classes, 4 tiles of 128 x 128): the reference's own losses (trajectory_n_128.npz: its modules,
     torch.optim.SGD with train.py's three parameter groups) against the HIP path in fp32 — step by step, the tolerance growing with the step because
-    thirty updates amplify fp32 reduction-order noise — and against the bf16 path: same seeds, the trajectory must stay inside a stated band around
-    the fp32 one and end within 5 % of it (bf16 storage moves single gradients to cosine ~0.9, DESIGN.md section 6: this is the evidence that
-    training survives it)."""
+    thirty updates amplify fp32 reduction-order noise — and against the bf16 path.  The loop is CHAOTIC (train-mode BatchNorm over four tiles, random
+    weights): the reference deviates from ITSELF by up to 4.4 % with 8 host threads instead of 1 and by up to 5.7 % when every weight is perturbed by
+    1e-6 relative (both trajectories are in the fixture; a perturbation grows ~10x per step over the first four steps).  So: the first four steps are held
+    to 2e-4 x 10^step, every later step to TWICE the reference's own largest deviation (~11 %), and the bf16 trajectory to the same band around the fp32
+    one — measured on MI355X: fp32 against the reference 3.7 % at most, bf16 against fp32 6.5 % at most, 5.9 % at step 30: bf16 storage moves this
+    training loop no further than a 1e-6 weight perturbation moves the reference (single gradients at cosine ~0.9 notwithstanding).
+    Both must also have trained: final loss under a fifth of the first."""
     from hd_yolo_amd.optim import SGD
     g = np.load(os.path.join(golden_dir, 'trajectory_n_128.npz'))
     batch, size, nc, nmin, nmax, steps = (int(v) for v in g['meta'])
@@ -292,9 +314,12 @@ def test_loss_trajectory_fp32_follows_the_reference_and_bf16_stays_in_its_band(g
     rel16 = np.abs(runs[True] - runs[False]) / runs[False]
     print('loss trajectory: reference first / last', ref[0], ref[-1], '| fp32 max rel', rel32.max(), 'at step', int(rel32.argmax()),
           '| bf16 vs fp32 max rel', rel16.max(), 'final', rel16[-1])
-    assert rel32[0] < 2e-4 and (rel32 < 2e-4 + 1e-3 * np.arange(steps)).all(), rel32
-    assert rel16.max() < 0.15 and rel16[-1] < 0.05, rel16
-    assert runs[True][-1] < 0.2 * runs[True][0]
+    own = max(float((np.abs(g['losses_8_threads'] - ref) / ref).max()), float((np.abs(g['losses_perturbed_1e6'] - ref) / ref).max()))
+    band = 2.0 * own
+    assert 0.02 < own < 0.10, own                                 # the fixture's band is what the docstring says it is
+    assert (rel32[:4] < 2e-4 * 10.0 ** np.arange(4)).all(), rel32[:4]
+    assert rel32.max() < band and rel16.max() < band, (rel32.max(), rel16.max(), band)
+    assert runs[True][-1] < 0.2 * runs[True][0] and runs[False][-1] < 0.2 * runs[False][0]
 
 
 def test_backbone_neck_head_called_separately_match_reference(golden_dir):
