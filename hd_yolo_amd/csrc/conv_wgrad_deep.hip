@@ -284,7 +284,10 @@ inline void deep_plan(int K, int Q, long long P, int* ktiles, int* qtiles, int* 
 
 bool deep_ok(int N, int Hin, int Win, int Ho, int Wo, int C, int K, int R, int S, int stride, int ldx, int lddy, int dtype) {
     if (hdy_opt(HDY_OPT_NO_WGRAD_DEEP) || dtype != HDY_BF16) return false;
-    if (C % 64 != 0 || K % 128 != 0 || K < 256 || ldx % 8 != 0 || lddy % 8 != 0) return false;
+    // K: whole 64-channel sub-tiles (the loader's d_col[] test and the slab store's k < K test cover a last, partly filled 256-row tile); round 6: 192 and
+    // up (yolov5m's 192-wide layers: K = 192 fills three quarters of one tile), before that K % 128 == 0 && K >= 256
+    const int kmin = hdy_opt(HDY_OPT_WGRAD_DEEP_KMIN);
+    if (C % 64 != 0 || K % 64 != 0 || K < kmin || ldx % 8 != 0 || lddy % 8 != 0) return false;
     // measured on yolov5s (B = 64): the multi-tap layers 158 -> 85 us (256x512 3x3/s2 @40x40), 158 -> 82 (128x256 @80x80), 96 -> 58 (256x256 s2); the
     // 1x1 layers at 20x20 / 40x40 lose (20 -> 28 us, 35 -> 39 us: a 256 x 256 tile leaves them 4-8 tiles, i.e. 32-64 pixel splits of 7-25 stages,
     // and twice the slab bytes): multi-tap layers only

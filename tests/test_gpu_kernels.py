@@ -90,6 +90,22 @@ CONV_CASES = [
     (5, 128, 128, 64, 64, 3, 1, 1),
     (2, 176, 256, 64, 48, 3, 1, 1),
     (2, 208, 256, 64, 64, 3, 1, 1),
+    # yolov5m's widths (round 6; yolov5m.yaml:5-6, yolov5.py:127 make_divisible(c * 0.75, 8)): 48 / 96 / 192 / 384 — rows that are not multiples of 128
+    # bytes, k-blocks that straddle taps (C % 64 != 0), column tiles that are partly empty (K = 96 on a 128-wide tile, K = 192 on two)
+    (2, 32, 32, 48, 48, 3, 1, 1),        # the first C3's bottleneck 3x3
+    (2, 32, 32, 48, 48, 1, 1, 0),
+    (2, 32, 32, 48, 96, 3, 2, 1),        # backbone.1
+    (2, 24, 24, 96, 96, 3, 1, 1),
+    (2, 24, 24, 96, 96, 1, 1, 0),
+    (2, 24, 24, 96, 192, 3, 2, 1),       # backbone.3
+    (2, 20, 20, 192, 192, 3, 1, 1),
+    (2, 20, 20, 192, 192, 1, 1, 0),
+    (2, 24, 24, 192, 192, 3, 2, 1),      # neck downsample: the deep-pipelined weight gradient from K = 192 (round 6)
+    (2, 20, 20, 192, 384, 3, 2, 1),      # backbone.5
+    (1, 20, 20, 384, 384, 3, 1, 1),
+    (2, 20, 20, 384, 192, 1, 1, 0),      # neck lateral
+    (1, 20, 20, 384, 768, 3, 2, 1),      # backbone.7
+    (1, 20, 20, 768, 384, 1, 1, 0),
 ]
 
 
@@ -106,8 +122,10 @@ def expected_dispatch(case):
         fwd, dgrad = 'conv3x3s2_c32', 'dgrad3x3s2_k64c32'
     if R == 3 and stride == 2 and C == 64 and K == 128 and H % 8 == 0 and W % 32 == 0:
         fwd, dgrad = 'conv3x3s2_c64', 'dgrad3x3s2_k128c64'
-    if R == 3 and stride == 1 and C % 32 == 0 and K % 32 == 0 and C <= 256 and K <= 256:
-        wgrad = 'wgrad3x3'
+    if R == 3 and stride == 1 and C % 32 == 0 and K % 32 == 0 and C <= 256 and K <= 256 and (C % 64 == 0 or C == 32) and (K % 64 == 0 or K == 32):
+        wgrad = 'wgrad3x3'                 # (several 32-wide blocks per split — 96 x 96 — measured slower than the generic kernel: conv_wgrad3x3.hip w3_plan)
+    if R == 3 and stride == 2 and C % 64 == 0 and K % 64 == 0 and K >= 192 and N * (H // 2) * (W // 2) >= 8192:
+        wgrad = 'wgrad_deep'
     return fwd, dgrad, wgrad
 
 
