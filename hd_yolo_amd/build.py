@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(CSRC, 'build')
 LIB = os.path.join(OUT, 'libhdyolo_hip.so')
-SOURCES = ['api.hip', 'conv_igemm.hip', 'conv3x3.hip', 'conv3x3s2.hip', 'conv_deep.hip', 'conv_stem.hip', 'conv_wgrad.hip', 'conv_wgrad3x3.hip', 'conv_wgrad_deep.hip', 'conv_dgrad_s2.hip', 'conv1x1_bwd.hip', 'bn_act.hip', 'pool.hip', 'detect.hip', 'loss.hip', 'roi.hip', 'seg.hip', 'optim.hip', 'exec.hip']
+SOURCES = ['api.hip', 'conv_igemm.hip', 'conv3x3.hip', 'conv3x3_c128.hip', 'conv3x3s2.hip', 'conv_deep.hip', 'conv_stem.hip', 'conv_wgrad.hip', 'conv_wgrad3x3.hip', 'conv_wgrad_deep.hip', 'conv_dgrad_s2.hip', 'conv1x1_bwd.hip', 'bn_act.hip', 'pool.hip', 'detect.hip', 'loss.hip', 'roi.hip', 'seg.hip', 'optim.hip', 'exec.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-ffp-contract=off', '-Wall', '-Wno-unused-function',
          '-I' + CSRC, '-I' + os.path.join(os.path.dirname(HERE), 'include')]
 

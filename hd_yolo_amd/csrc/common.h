@@ -43,6 +43,7 @@ enum HdyOption {
     HDY_OPT_WGRAD_TILE,        // HDY_WGRAD_TILE: dW tile of the generic weight-gradient kernel per workgroup: 0 (default) 128 x 128 where K and T*C allow, 64 = 64 x 64 (four times the pixel range per workgroup at the same grid: a quarter of the split slabs, twice the operand fetches)
     HDY_OPT_SPPF_NO_KEYS,      // HDY_SPPF_NO_KEYS: SPPF forward with the float-compare kernels instead of the order-preserving 16-bit keys (A/B)
     HDY_OPT_WGRAD_DEEP_KMIN,   // HDY_WGRAD_DEEP_KMIN: fewest output channels (a multiple of 64) the deep-pipelined multi-tap weight gradient takes (default 192; 256 = rounds 3-5)
+    HDY_OPT_NO_CONV3X3_C128,   // HDY_NO_CONV3X3_C128: filter-resident 3x3 kernel for 128 input channels off (deep-pipelined / generic kernel instead)
     HDY_OPT_COUNT
 };
 int hdy_opt(int id);

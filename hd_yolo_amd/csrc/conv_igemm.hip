@@ -871,6 +871,7 @@ int hdy_conv_igemm_launch(ConvArgs a, int dtype, int out_f32, hipStream_t st) {
     if (a.ncls <= 1 && a.nstat == 0) {
         if (hdy_conv_stem_try(a, dtype, out_f32, st, &rc)) return rc;         // patch-resident 6x6/s2 stem
         if (hdy_conv3x3_c64_try(a, dtype, out_f32, st, &rc)) return rc;      // filter-resident 3x3 kernel when the shape qualifies
+        if (hdy_conv3x3_c128_try(a, dtype, out_f32, st, &rc)) return rc;     // ... its 128-input-channel form (round 6)
         if (hdy_conv3x3s2_c32_try(a, dtype, out_f32, st, &rc)) return rc;    // patch-resident 3x3 / stride 2 kernel (32 input channels)
         if (hdy_conv_deep_try(a, dtype, out_f32, st, &rc)) return rc;        // deep-pipelined 256-row kernel (C % 64 == 0, K >= 128)
         // the slab count the caller sized its statistics buffer with must be the generic kernel's from here on

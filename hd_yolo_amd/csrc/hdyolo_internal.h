@@ -94,6 +94,8 @@ int hdy_wgrad_stem_launch(const WgradArgs& a, int grid, hipStream_t st);
 int hdy_conv_igemm_slabs(long long M, int K, int taps);
 int hdy_conv3x3_c64_try(const ConvArgs& a, int dtype, int out_f32, hipStream_t st, int* rc);
 int hdy_conv3x3_c64_slabs(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dtype);
+int hdy_conv3x3_c128_try(const ConvArgs& a, int dtype, int out_f32, hipStream_t st, int* rc);
+int hdy_conv3x3_c128_slabs(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dtype);
 int hdy_conv_stem_try(const ConvArgs& a, int dtype, int out_f32, hipStream_t st, int* rc);
 int hdy_conv_stem_slabs(int N, int H, int W, int K, int dtype);
 int hdy_conv_igemm_launch(ConvArgs a, int dtype, int out_f32, hipStream_t st);

@@ -223,3 +223,21 @@ def test_program_words_follow_the_record_list(lib):
     assert w1 == [op_f, 19, 0x10, 8, 0x20, 8, 8] + [0] * 8 + [f32(1e-3), f32(0.03)] + [0x30] * 4 + [ops.EXEC_JOIN, 1, tb + 9]
     with pytest.raises(_lib.HdyError, match='cannot be listed'):
         ops.Program([('hdy_scale_inplace', (1, 2, 3), ())])              # one argument short
+
+
+def test_c128_swizzle_is_conflict_free():
+    """conv3x3_c128.hip keeps its patch as 256-byte pixel rows (all 64 LDS banks once per row), so the 16 lanes of every ds_read_b128 lane group
+    (MI355X_MICROARCH.md, LDS table: {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32) must read 16 DIFFERENT 16-byte chunks.  Lane (fr, fq) of
+    a fragment reads patch column (fr & 7) + s (s = 0, 1, 2: the filter column) and logical chunk ks * 4 + fq; the kernel XORs the chunk with
+    (column & 7) << 1.  Restated here so that a change of the key or of the lane -> pixel map cannot go unnoticed on a box without a GPU."""
+    groups = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)), list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32))]
+    groups += [[l + 32 for l in g] for g in groups]
+    for s in range(3):
+        for ks in range(4):
+            for g in groups:
+                chunks = set()
+                for lane in g:
+                    fr, fq = lane & 15, lane >> 4
+                    col = (fr & 7) + s
+                    chunks.add((ks * 4 + fq) ^ ((col & 7) << 1))
+                assert len(chunks) == 16, (s, ks, g, sorted(chunks))

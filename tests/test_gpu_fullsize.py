@@ -236,10 +236,10 @@ def test_bench_config_step_fast_kernels_against_all_generic_kernels():
     implicit GEMM, generic weight gradient, three-launch BatchNorm backward).  Same weights, tiles and targets: the loss must agree within 1e-3
     for both, the detection convs' gradients point the same way (cosine > 0.999), and — against the same step in fp32 arithmetic — the specialised
     kernels are as close to the truth as the generic ones at every quantile of the per-parameter cosines."""
-    off = ['HDY_NO_CONV3X3', 'HDY_NO_CONV3X3S2', 'HDY_NO_DGRAD_S2', 'HDY_NO_STEM_KERNEL', 'HDY_NO_STEM_WGRAD', 'HDY_NO_WGRAD3X3', 'HDY_NO_DEEP']
+    off = ['HDY_NO_CONV3X3', 'HDY_NO_CONV3X3_C128', 'HDY_NO_CONV3X3S2', 'HDY_NO_DGRAD_S2', 'HDY_NO_STEM_KERNEL', 'HDY_NO_STEM_WGRAD', 'HDY_NO_WGRAD3X3', 'HDY_NO_DEEP']
     loss_f, g_f, log_f = _c2_step([])
     loss_g, g_g, log_g = _c2_step(off)
-    fast = {'conv3x3_c64', 'conv3x3_c32', 'conv3x3s2_c32', 'conv3x3s2_c64', 'dgrad3x3s2_k64c32', 'dgrad3x3s2_k128c64', 'conv_stem', 'wgrad3x3', 'wgrad_stem_fused', 'conv1x1_bwd_64', 'deep_256x128'}
+    fast = {'conv3x3_c64', 'conv3x3_c32', 'conv3x3_c128', 'conv3x3s2_c32', 'conv3x3s2_c64', 'dgrad3x3s2_k64c32', 'dgrad3x3s2_k128c64', 'conv_stem', 'wgrad3x3', 'wgrad_stem_fused', 'conv1x1_bwd_64', 'deep_256x128'}
     assert fast <= log_f, f'specialised kernels that did not run in the bench step: {sorted(fast - log_f)}'
     assert not (log_g & (fast | {'deep_256x256', 'conv1x1_bwd_32', 'conv1x1_bwd_128', 'wgrad_stem'})), sorted(log_g)
     assert np.isfinite(loss_f) and abs(loss_f - loss_g) < 1e-3 * abs(loss_g), (loss_f, loss_g)

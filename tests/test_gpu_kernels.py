@@ -90,6 +90,13 @@ CONV_CASES = [
     (5, 128, 128, 64, 64, 3, 1, 1),
     (2, 176, 256, 64, 48, 3, 1, 1),
     (2, 208, 256, 64, 64, 3, 1, 1),
+    # the filter-resident 3x3 kernel for 128 input channels (round 6, conv3x3_c128.hip): 8 x 8 pixel items, the two channel halves on neighbouring workgroups
+    (2, 40, 40, 128, 128, 3, 1, 1),      # yolov5s' bottleneck shape: 50 items per half on 100 workgroups
+    (3, 24, 40, 128, 128, 3, 1, 1),      # 45 tiles: streams with one and with two items
+    (1, 8, 8, 128, 128, 3, 1, 1),        # a single tile: every patch pixel on the border
+    (2, 16, 24, 128, 64, 3, 1, 1),       # one channel half
+    (2, 16, 16, 128, 104, 3, 1, 1),      # ragged second half (K = 64 + 40)
+    (9, 64, 64, 128, 128, 3, 1, 1),      # 576 tiles on 256 streams: three items on some, two on others
     # yolov5m's widths (round 6; yolov5m.yaml:5-6, yolov5.py:127 make_divisible(c * 0.75, 8)): 48 / 96 / 192 / 384 — rows that are not multiples of 128
     # bytes, k-blocks that straddle taps (C % 64 != 0), column tiles that are partly empty (K = 96 on a 128-wide tile, K = 192 on two)
     (2, 32, 32, 48, 48, 3, 1, 1),        # the first C3's bottleneck 3x3
@@ -118,6 +125,10 @@ def expected_dispatch(case):
         fwd = 'conv3x3_c%d' % C
         if K in (32, 64) and C <= 64:
             dgrad = 'conv3x3_c%d' % K
+    if R == 3 and stride == 1 and pad == 1 and C == 128 and K <= 128 and H % 8 == 0 and W % 8 == 0:
+        fwd = 'conv3x3_c128'
+    if R == 3 and stride == 1 and pad == 1 and K == 128 and C <= 128 and C % 8 == 0 and H % 8 == 0 and W % 8 == 0:
+        dgrad = 'conv3x3_c128'             # the data gradient is the same convolution with the roles of C and K swapped
     if R == 3 and stride == 2 and C == 32 and K == 64 and H % 16 == 0 and W % 64 == 0:
         fwd, dgrad = 'conv3x3s2_c32', 'dgrad3x3s2_k64c32'
     if R == 3 and stride == 2 and C == 64 and K == 128 and H % 8 == 0 and W % 32 == 0:
@@ -900,6 +911,8 @@ AB_CASES = [
     ('HDY_NO_CONV3X3', 'conv3x3_c64', 'dgrad', 8, 128, 128, 64, 64, 1),
     ('HDY_NO_DGRAD_S2', 'dgrad3x3s2_k128c64', 'dgrad', 6, 256, 256, 64, 128, 2),   # 1536 dy tiles of 4x16 on 512 workgroups
     ('HDY_NO_CONV3X3S2', 'conv3x3s2_c64', 'fwd', 6, 256, 256, 64, 128, 2),         # 1536 tiles of 4x16 outputs on 256 eight-wave workgroups
+    ('HDY_NO_CONV3X3_C128', 'conv3x3_c128', 'fwd', 5, 128, 128, 128, 128, 1),      # 1280 tiles of 8x8 on 256 streams x 2 channel halves (round 6)
+    ('HDY_NO_CONV3X3_C128', 'conv3x3_c128', 'dgrad', 5, 128, 128, 128, 128, 1),
 ]
 
 
@@ -963,11 +976,13 @@ def test_specialised_kernel_agrees_with_generic_beyond_one_grid(case):
 
 
 WGRAD_DEEP_CASES = [
-    # N, H, W, C, K, R, stride, pad — shapes of the deep-pipelined weight gradient (C % 64 == 0, K % 128 == 0, K >= 256, >= 8192 output pixels)
+    # N, H, W, C, K, R, stride, pad — shapes of the deep-pipelined weight gradient (C % 64 == 0, K % 64 == 0, K >= 192, >= 8192 output pixels)
     (4, 96, 96, 128, 256, 3, 2, 1),      # 3x3 / stride 2: Q = 1152 = 4.5 column tiles, taps that leave the image
     (4, 96, 96, 64, 256, 3, 2, 1),       # C = 64: one tap per 64-column sub-tile, Q = 576
     (12, 53, 53, 64, 384, 3, 2, 1),      # K = 1.5 row tiles; 27 x 27 output pixels per image (8748 in all): the last stage of the last split is ragged
     (2, 72, 72, 64, 256, 5, 1, 2),       # 25 taps (Q = 1600), stride 1 (3x3 / stride 1 belongs to the patch-resident kernel)
+    (4, 96, 96, 192, 192, 3, 2, 1),      # round 6: K = 192 = three quarters of one 256-row tile (yolov5m's neck downsample), three channel blocks per tap
+    (4, 96, 96, 64, 320, 3, 2, 1),       # K = 1.25 row tiles: the second one a quarter full
 ]
 
 
