@@ -355,9 +355,11 @@ def main():
         tex = torch.tensor([mine], device=device, dtype=torch.float64)
         dist.all_reduce(tex, op=dist.ReduceOp.MAX)
         exposed_ms = tex.item()
-    # second block of K steps, same fences: the steady-state number beside the headline (never instead of it)
+    # second block of K steps, same fences: the steady-state number beside the headline (never instead of it).  HDY_BENCH_SECOND_BLOCK=0 (the
+    # profiling scripts, which count kernels per step over warm-up + K steps) skips it.
+    second = os.environ.get('HDY_BENCH_SECOND_BLOCK', '1') != '0'
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(args.steps if second else 0):
         step()
     fence()
     dt2 = time.perf_counter() - t0
@@ -388,8 +390,9 @@ def main():
                        'allreduce_calls_per_step': (round(net.reducer.calls / max(nsteps_run[0], 1), 2) if (world > 1 or force_dist) else 0),
                        'param_checksum_spread_over_ranks': param_spread},
             'final_loss': round(final_loss, 4), 'prewarm_s': round(prewarm_s, 3), 'prewarm_steps': prewarm_steps,
-            'steady_state': {'ms_per_step': round(dt2 / args.steps * 1e3, 3), 'value': round(tiles / dt2, 2),
-                             'what': f'a second block of {args.steps} timed steps right after the headline block (same barrier + synchronize on both sides)'},
+            'steady_state': ({'ms_per_step': round(dt2 / args.steps * 1e3, 3), 'value': round(tiles / dt2, 2),
+                              'what': f'a second block of {args.steps} timed steps right after the headline block (same barrier + synchronize on both sides)'}
+                             if second else None),
         }
         import hd_yolo_amd
         # self-diagnosis of an N > 1 run: where a scaling loss would come from.  rank_step_ms_min / max: the fastest and the slowest rank's own clock

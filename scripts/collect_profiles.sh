@@ -3,10 +3,11 @@
 #   gpurun --timeout 1100 -- 'bash scripts/collect_profiles.sh r04'
 # Each counter set is its own run; programs are started directly after `--` (no shell hop between rocprofv3 and python).
 set -o pipefail
-R=${1:-r05}
+R=${1:-r06}
 OUT=gpurun_out/prof_$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+export HDY_BENCH_SECOND_BLOCK=0   # (round 6: bench.py times a second block of K steps by default; the per-step divisions here count warm-up + K)
 export HDY_BENCH_PREWARM_S=0      # the profiled runs count kernels per step: no untimed pre-warm steps in the trace (bench.py)
 rocprofv3 --kernel-trace --stats -d $OUT/bench -o bench --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-infer > $OUT/bench.log 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT/roof -o roof --output-format csv -- python3 scripts/roofline_kernel.py > $OUT/roof.log 2>&1
@@ -18,6 +19,9 @@ rocprofv3 --kernel-trace --stats -d $OUT/infer -o infer --output-format csv -- p
 rocprofv3 --kernel-trace --stats -d $OUT/hnet -o hnet --output-format csv -- python3 scripts/bench_hnet.py s 16 1280 4 > $OUT/hnet.log 2>&1
 bash scripts/step_profile.sh $R > /dev/null 2>&1 && cp gpurun_out/step_$R/kernel_stats.txt $OUT/step_kernel_stats.txt
 python3 scripts/layer_bench.py > $OUT/layer_table.txt 2>&1
+python3 scripts/layer_bench.py 32 640 m > $OUT/layer_table_m_b32.txt 2>&1
+python3 scripts/layer_bench.py 128 1024 l eval > $OUT/layer_table_l_eval.txt 2>&1
+bash scripts/step_profile_variant.sh ${R}m m 32 640 > /dev/null 2>&1 && cp gpurun_out/step_${R}m/kernel_stats.txt $OUT/step_m_kernel_stats.txt
 for v in "m 32 640" "l 16 640" "m6 16 1280"; do set -- $v; HDY_BENCH_PREWARM_S=1 python3 bench.py --variant $1 --batch $2 --size $3 --steps 10 --warmup 3 --no-cpu-baseline --no-infer --no-roofline 2>/dev/null | tail -1 | cut -c1-420 >> $OUT/variants.log; done
 python3 scripts/bench_mask.py s 16 1280 4 2>/dev/null | tail -1 >> $OUT/variants.log
 python3 scripts/bench_latency.py 2>/dev/null | tail -3 >> $OUT/variants.log

@@ -2,7 +2,7 @@
 # Copy the summaries that scripts/collect_profiles.sh left under gpurun_out/prof_<round>/ into profiles/<round>_* (the tracked, judged copies):
 #   bash scripts/publish_profiles.sh r04
 set -e
-R=${1:-r05}
+R=${1:-r06}
 O=gpurun_out/prof_$R
 grep "^{" $O/bench.log | tail -1 > profiles/${R}_bench.json
 cp $O/bench/bench_kernel_stats.csv profiles/${R}_bench_kernel_stats.csv
@@ -19,6 +19,6 @@ for k in ('fetch', 'write'):
 PY
 grep "^{" $O/infer.log | tail -1 > profiles/${R}_infer.json; cp $O/infer/infer_kernel_stats.csv profiles/${R}_infer_kernel_stats.csv
 grep "^{" $O/hnet.log | tail -1 > profiles/${R}_hnet.json; cp $O/hnet/hnet_kernel_stats.csv profiles/${R}_hnet_kernel_stats.csv
-for f in layer_table.txt step_kernel_stats.txt trace_gaps.txt trace_idle.txt variants.log step_traffic.json layers_pmc_table.txt seg_kernels.txt; do cp $O/$f profiles/${R}_$f; done
+for f in layer_table.txt layer_table_m_b32.txt layer_table_l_eval.txt step_m_kernel_stats.txt step_kernel_stats.txt trace_gaps.txt trace_idle.txt variants.log step_traffic.json layers_pmc_table.txt seg_kernels.txt; do cp $O/$f profiles/${R}_$f; done
 { echo "# PYTHONPATH=. python scripts/probes/dgrad_walk.py (B = 64, the yolov5s bench shapes; deep pipeline with HDY_DEEP_WALK=1 | generic kernel's walk)"; cat $O/dgrad_walk.txt; } > profiles/${R}_dgrad_walk.txt
 ls -la profiles/${R}_* | wc -l

@@ -6,6 +6,7 @@ TAG=${1:-a}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/step_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+export HDY_BENCH_SECOND_BLOCK=0   # (round 6: bench.py times a second block of K steps by default; the per-step divisions here count warm-up + K)
 export HDY_BENCH_PREWARM_S=0      # the profiled runs count kernels per step: no untimed pre-warm steps in the trace (bench.py)
 rocprofv3 --kernel-trace --stats -d $OUT/p -o p --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-infer --no-roofline --no-cpu-baseline > $OUT/bench.log 2>&1
 tail -1 $OUT/bench.log | cut -c1-160

@@ -5,7 +5,7 @@ TAG=${1:-m}; V=${2:-m}; B=${3:-32}; S=${4:-640}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/step_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-HDY_BENCH_PREWARM_S=0 rocprofv3 --kernel-trace --stats -d $OUT/p -o p --output-format csv -- python3 bench.py --variant $V --batch $B --size $S --steps 10 --warmup 3 --no-infer --no-roofline --no-cpu-baseline > $OUT/bench.log 2>&1
+HDY_BENCH_SECOND_BLOCK=0 HDY_BENCH_PREWARM_S=0 rocprofv3 --kernel-trace --stats -d $OUT/p -o p --output-format csv -- python3 bench.py --variant $V --batch $B --size $S --steps 10 --warmup 3 --no-infer --no-roofline --no-cpu-baseline > $OUT/bench.log 2>&1
 tail -1 $OUT/bench.log | cut -c1-160
 python3 - $OUT <<'PY'
 import csv, sys, glob
