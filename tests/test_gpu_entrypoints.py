@@ -142,6 +142,14 @@ def test_bench_py_single_rank_over_rccl():
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][-1])
     assert line['config']['backend'] == 'nccl' and line['config']['world_size'] == 1 and line['value'] > 0
     assert line['config'].get('allreduce_calls_per_step', 0) >= 1, line['config']          # the bucketed all-reduce really went through RCCL
+    # the self-diagnosis an N > 1 line carries (round 6): how long the main stream stood waiting for the collectives in front of the optimizer (one rank:
+    # nothing on the wire, so next to nothing), the fastest / slowest rank's own clock, and the hardware queues the HIP runtime was started with
+    c = line['config']
+    assert {'allreduce_exposed_ms', 'rank_step_ms_min', 'rank_step_ms_max', 'hw_queues', 'hw_queues_in_time'} <= set(c), sorted(c)
+    print('allreduce_exposed_ms', c['allreduce_exposed_ms'], 'rank step ms', c['rank_step_ms_min'], c['rank_step_ms_max'], 'queues', c['hw_queues'])
+    assert c['allreduce_exposed_ms'] is not None and 0.0 <= c['allreduce_exposed_ms'] <= 0.3, c['allreduce_exposed_ms']
+    assert c['rank_step_ms_min'] <= c['rank_step_ms_max'] == line['ms_per_step'] and c['hw_queues'] >= 8 and c['hw_queues_in_time'] is True
+    assert line['steady_state'] and line['steady_state']['ms_per_step'] > 0 and line['prewarm_steps'] == 0
 
 
 def _bench_line(env_extra, *flags):
