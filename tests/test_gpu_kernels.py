@@ -212,6 +212,45 @@ def conv_case(case, dtype):
     return log_fwd, log_dgrad, log_wgrad
 
 
+RES_CASES = [
+    # (N, H, W, C, K, R, expected kernel family, options): the eval-mode Bottleneck shortcut — y = SiLU(scale * conv + shift) + res (layers.py:96) — in every conv kernel's epilogue
+    (2, 16, 32, 64, 64, 3, 'conv3x3_c64', {}),
+    (2, 24, 40, 128, 128, 3, 'conv3x3_c128', {}),
+    (2, 16, 16, 128, 104, 3, 'conv3x3_c128', {}),                                      # ragged second channel half
+    (3, 40, 40, 128, 128, 3, 'deep_256x128', {'HDY_NO_CONV3X3_C128': 1, 'HDY_DEEP_MIN_TILES': 1}),
+    (3, 40, 40, 256, 256, 3, 'deep_256x256', {'HDY_DEEP_MIN_TILES': 1, 'HDY_DEEP_BN': 256}),
+    (2, 20, 20, 96, 96, 3, 'igemm_128x128x2', {}),
+    (2, 20, 20, 48, 48, 1, 'igemm_128x64x2', {}),
+]
+
+
+@pytest.mark.parametrize('case', RES_CASES, ids=[f'{c[6]}-{c[3]}x{c[4]}k{c[5]}' for c in RES_CASES])
+def test_conv_eval_epilogue_with_residual(case):
+    """The residual operand of the eval-mode convolution epilogue (a pitched slice of a wider buffer, like the plan's) on each kernel family, bf16, against
+    torch fp32: out = SiLU(scale * conv(x, w) + shift) + res, rounded once."""
+    from contextlib import ExitStack
+    N, H, W, C, K, R, want, opts = case
+    dt, pad = torch.bfloat16, R // 2
+    x = q(rnd((N, C, H, W), 31), dt)
+    w = rnd((K, C, R, R), 32, (3.0 / (C * R * R)) ** 0.5)
+    res = q(rnd((N, K, H, W), 33), dt)
+    sc, sh = rnd((K,), 34).abs() + 0.5, rnd((K,), 35)
+    xd = to_dev_nhwc(x, dt)
+    resd = to_dev_nhwc(res, dt, ld=K + 24, off=16)
+    with ExitStack() as es:
+        for k, v in opts.items():
+            es.enter_context(_lib.option(k, v))
+        wp = ops.pack_alloc(K, C, R, R, 1, pad, ops.PACK_FWD, dt, DEV)
+        y = torch.zeros((N, H, W, K), dtype=dt, device=DEV)
+        _lib.dispatch_log(reset=True)
+        ops.run([ops.rec_pack(w.to(DEV), None, 1, pad, ops.PACK_FWD, wp),
+                 ops.rec_conv_fwd(xd, wp, y, K, R, R, 1, pad, scale=sc.to(DEV), shift=sh.to(DEV), act=ops.ACT_SILU, res=resd)])
+        log = _lib.dispatch_log(reset=True)
+    assert want in log, log
+    ref = F.silu(F.conv2d(x, q(w, dt), None, 1, pad) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) + res
+    assert_close(from_dev_nhwc(y), ref, TOL[dt] * 2, f'{want} epilogue with residual')
+
+
 DEEP_CASES = [
     # N, H, W, C, K, R, stride, pad — shapes of the deep-pipelined kernel (C % 64 == 0, K >= 128), small enough for a CPU reference
     (2, 20, 20, 128, 128, 3, 1, 1),      # 4 row tiles, the last one 32 rows; every tile has border pixels
