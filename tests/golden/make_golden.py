@@ -755,6 +755,10 @@ def main():
         gen_eval_calibrated('l_256', 'l', 8, 1, 256)
         gen_trajectory('n_128', 'n', 2, 4, 128, 30, 4, 12)
         return
+    if sys.argv[1:] == ['sizes']:              # round 6: BASELINE configs[2] / [3] at their own tile geometry (per-GPU batch cut to what a CPU finishes in a minute)
+        gen_train('m_640', 'm', 8, 2, 640, 50, 400)
+        gen_eval_calibrated('l_1024', 'l', 8, 1, 1024)
+        return
     if sys.argv[1:] == ['trajectory']:
         gen_trajectory('n_128', 'n', 2, 4, 128, 30, 4, 12)
         return

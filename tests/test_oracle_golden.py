@@ -121,7 +121,7 @@ def ragged(targets, tag):
     return targets
 
 
-@pytest.mark.parametrize('tag,v', [('n_64', 'n'), ('s_128', 's'), ('n6_128', 'n6'), ('n_64_ragged', 'n'), ('c1_640', 'n'), ('m_128', 'm')])
+@pytest.mark.parametrize('tag,v', [('n_64', 'n'), ('s_128', 's'), ('n6_128', 'n6'), ('n_64_ragged', 'n'), ('c1_640', 'n'), ('m_128', 'm'), ('m_640', 'm')])
 def test_train_loss_and_grads(golden_dir, tag, v):
     g = load(golden_dir, f'train_{tag}.npz')
     batch, size, nc, nmin, nmax = (int(t) for t in g['meta'])
@@ -132,9 +132,17 @@ def test_train_loss_and_grads(golden_dir, tag, v):
             t.requires_grad_(True)
     x = synth.synth_images(batch, size, seed=11)
     targets = ragged(synth.synth_targets(batch, size, nc, nmin=nmin, nmax=nmax, seed=5), tag)
-    loss, items, _ = net.train_forward(sd, x, targets)
-    loss.backward()
-    # (the full-size golden was made with ONE torch thread: colliding matches are then resolved in target order, see make_golden.gen_train)
+    # the full-size goldens were made with ONE torch thread (colliding matches are then resolved in target order, see make_golden.gen_train); the deeper
+    # yolov5m at 640 x 640 also needs the oracle on one thread: with 8 its early-layer gradients move by 1.6e-3 of their maximum (fp32 reduction order through
+    # ~80 train-mode BatchNorm layers), with 1 they agree with the reference to 1.2e-5
+    threads = torch.get_num_threads()
+    if tag == 'm_640':
+        torch.set_num_threads(1)
+    try:
+        loss, items, _ = net.train_forward(sd, x, targets)
+        loss.backward()
+    finally:
+        torch.set_num_threads(threads)
     rtol = 1e-5 if size < 640 else 1e-4          # full size: fp32 reduction order over ~10^6 elements differs with the thread count (2e-5)
     close(loss, g['loss'], rtol=rtol)
     for k in ('box', 'obj', 'cls'):
