@@ -95,7 +95,7 @@ def test_c4_yolov5l_batch128_1024_inference():
         _, outs = model(x)
         torch.cuda.synchronize()
         log = set(_lib.dispatch_log(reset=True))
-        assert {'deep_256x256', 'deep_256x128', 'conv_stem'} <= log, sorted(log)
+        assert {'deep_256x256', 'deep_256x128', 'conv_stem', 'conv3x3_c64', 'conv3x3_c128'} <= log, sorted(log)      # (conv3x3_c128: the nine 128 -> 128 3x3 layers at 128 x 128, round 6)
         assert len(outs) == B
         n = [len(o['det']['boxes']) for o in outs]
         assert min(n) > 0 and max(n) <= int(head.nms_params['max_det']), (min(n), max(n))
