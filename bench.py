@@ -23,6 +23,10 @@ Extra objects on the line:
   infer         BASELINE configs[3] (yolov5l, batch 128, 1024x1024 inference): tiles/s, decode and NMS microseconds per tile.
   cpu_baseline  the CPU oracle (oracle/ref_net.py, a torch-fp32 port of the reference path) doing the same training step on
                 a bounded sample (a few 640x640 tiles) on this host's cores.
+  steady_state  a SECOND block of K timed steps right after the headline block (same fences): what the step costs once clocks and caches are warm.
+                `value` / `ms_per_step` are always the first block — W warm-up steps, then exactly K timed steps, no pre-warm (HDY_BENCH_PREWARM_S opts in).
+  config        also carries the self-diagnosis of an N > 1 run: allreduce_exposed_ms (main stream waiting for the collectives in front of the
+                optimizer), rank_step_ms_min / max, hw_queues / hw_queues_in_time, allreduce_expected against allreduce_calls_per_step / _mb_per_step.
 """
 import argparse
 import json
@@ -337,7 +341,7 @@ def main():
     for _ in range(args.steps):
         loss = step()
     fence()
-    dt_rank = dt = time.perf_counter() - t0
+    dt = time.perf_counter() - t0
     dt_min = dt
     if dp_on:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
