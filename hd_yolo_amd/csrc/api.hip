@@ -34,7 +34,7 @@ const OptDef g_opt_def[HDY_OPT_COUNT] = {
     {"HDY_NO_DGRAD_S2", 0, false}, {"HDY_TILE_INTERLEAVE", 1, false}, {"HDY_NO_BIG_TILES", 0, true}, {"HDY_NO_STEM_KERNEL", 0, true},
     {"HDY_WGRAD_BLOCKS", 512, false}, {"HDY_NO_STEM_WGRAD", 0, true}, {"HDY_NO_WGRAD3X3", 0, true}, 
     {"HDY_LOSS_GRID", 2048, false}, {"HDY_NO_DEEP", 0, true}, {"HDY_NO_WGRAD_S2", 0, true}, {"HDY_NO_WGRAD_DEEP", 0, true}, {"HDY_DEEP_BN", 0, false}, {"HDY_DEEP_DEBUG", 0, false}, {"HDY_DEEP_ALL", 1, false}, {"HDY_DEEP_MIN_TILES", 160, false}, {"HDY_DEEP_WALK", 2, false}, {"HDY_NO_BN_REDUCE4", 0, true},
-    {"HDY_WGRAD_TILE", 0, false}, {"HDY_SPPF_NO_KEYS", 0, true}, {"HDY_WGRAD_DEEP_KMIN", 192, false}, {"HDY_NO_CONV3X3_C128", 0, true},
+    {"HDY_WGRAD_TILE", 0, false}, {"HDY_SPPF_NO_KEYS", 0, true}, {"HDY_WGRAD_DEEP_KMIN", 192, false}, {"HDY_NO_CONV3X3_C128", 0, true}, {"HDY_NO_F1X1_96", 0, true},
 };
 std::atomic<int> g_opt[HDY_OPT_COUNT];
 std::once_flag g_opt_once;

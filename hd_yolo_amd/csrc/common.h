@@ -44,6 +44,7 @@ enum HdyOption {
     HDY_OPT_SPPF_NO_KEYS,      // HDY_SPPF_NO_KEYS: SPPF forward with the float-compare kernels instead of the order-preserving 16-bit keys (A/B)
     HDY_OPT_WGRAD_DEEP_KMIN,   // HDY_WGRAD_DEEP_KMIN: fewest output channels (a multiple of 64) the deep-pipelined multi-tap weight gradient takes (default 192; 256 = rounds 3-5)
     HDY_OPT_NO_CONV3X3_C128,   // HDY_NO_CONV3X3_C128: filter-resident 3x3 kernel for 128 input channels off (deep-pipelined / generic kernel instead)
+    HDY_OPT_NO_F1X1_96,        // HDY_NO_F1X1_96: fused 1x1 backward instance for 96 channels off (three launches instead; A/B)
     HDY_OPT_COUNT
 };
 int hdy_opt(int id);

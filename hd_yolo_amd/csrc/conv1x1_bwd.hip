@@ -86,11 +86,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_kernel(const FusedArgs p) 
     constexpr int SUB = BM * 128;                                 // bytes of a [128 rows][128 B] sub-tile
     constexpr int D_SZ = NSK * SUB, X_SZ = NSC * SUB, WSUB = CT * 128;
     constexpr int NCH = KT / 8;                                   // 16-byte chunks per dy row
-    constexpr int RPP = 256 / NCH, NPASS = BM / RPP;              // elementwise phase: rows per pass, passes
+    constexpr bool POW2 = (NCH & (NCH - 1)) == 0;                 // round 6: KT = CT = 96 (yolov5m) — 12 chunks per row: 192 of the 256 threads own a (row, chunk)
+    constexpr int RPP = POW2 ? 256 / NCH : 16, NPASS = BM / RPP;  // elementwise phase: rows per pass, passes
+    constexpr int NACT = NCH * RPP;                               // threads that take part in the elementwise and the store phases
     constexpr int MT = BM / 32;                                   // dgrad: 16-pixel tiles per wave (wave = BM/2 pixels x CT/2 channels)
     constexpr int NT = CT / 32;                                   //        16-channel tiles per wave
     constexpr int MTW = KT / 32, NTW = CT / 32;                   // wgrad: 16x16 tiles per wave (wave = KT/2 x CT/2)
-    static_assert(BM * CT * 2 <= D_SZ, "dx staging must fit the D tile");
+    constexpr int ROWB_L = POW2 ? CT * 2 : 256;                   // staging row pitch (a 192-byte row is padded: the row key XORs 8-byte slots up to 31)
+    static_assert(BM * ROWB_L <= D_SZ, "dx staging must fit the D tile");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const sD = smem;
@@ -122,7 +125,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_kernel(const FusedArgs p) 
     }
 
     // ---- elementwise phase mapping: a thread owns ONE 8-channel vector (its coefficients stay in registers) and NPASS rows
-    const int ch = tid & (NCH - 1), r0 = tid / NCH;
+    const bool ew = tid < NACT;                                   // (all 256 when NCH is a power of two)
+    const int ch = POW2 ? (tid & (NCH - 1)) : (ew ? tid % NCH : 0), r0 = POW2 ? tid / NCH : (ew ? tid / NCH : 0);
     const int c0 = ch * 8;
     // the 48 per-channel coefficients of a thread's vector are re-read from LDS at the start of every tile instead of living in
     // registers across the MFMA phase (where the 128-wide instance would spill)
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_kernel(const FusedArgs p) 
 #pragma unroll
         for (int j = 0; j < NPASS; ++j) {
             const int m = t * BM + r0 + j * RPP;
-            if (m < p.M) {
+            if (m < p.M && ew) {
                 gq[j] = *(const i32x4*)(dzc + (size_t)m * lddzc);
                 vq[j] = *(const i32x4*)(y + (size_t)m * p.ldy + c0);
             } else {
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_kernel(const FusedArgs p) 
                 o.h[2 * q] = (bf16_t)(live ? d.x : 0.0f);
                 o.h[2 * q + 1] = (bf16_t)(live ? d.y : 0.0f);
             }
-            *(i32x4*)(sD + (ch >> 3) * SUB + toff(row, ch & 7)) = o.i;
+            if (ew) *(i32x4*)(sD + (ch >> 3) * SUB + toff(row, ch & 7)) = o.i;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's share of the x tile has landed
         __syncthreads();
@@ -295,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_kernel(const FusedArgs p) 
         // rows of the 32-channel instance (two rows per 128 bytes: bit 0 of the row already selects the bank half).  An odd key swaps the two 8-byte
         // halves of a 16-byte chunk, which the reader undoes in registers.
         if (p.do_dgrad) {
-            constexpr int ROWB = CT * 2, CPR = ROWB / 16, RPI = 256 / CPR;
+            constexpr int ROWB = ROWB_L, CPR = CT * 2 / 16, RPI = POW2 ? 256 / CPR : 16;      // (CT = 96: 12 chunks x 16 rows = 192 storing threads)
 #ifdef HDY_F1X1_OLDKEY                                                  // A/B build (scripts/build_variant.sh ... -DHDY_F1X1_OLDKEY): round 2's key
             auto skey = [](int row) { return row & ((2 * CPR - 1) & 14); };
 #else
@@ -312,7 +316,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_kernel(const FusedArgs p) 
                 }
             }
             __syncthreads();
-            const int cc = tid % CPR, rr = tid / CPR;
+            const bool stq = POW2 || tid < CPR * RPI;
+            const int cc = stq ? tid % CPR : 0, rr = stq ? tid / CPR : 0;
             bf16_t* const dx = (bf16_t*)p.dx;
             const bf16_t* st_y = nullptr;
             int st_ldy = 0, st_act = 0;
@@ -350,14 +355,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_kernel(const FusedArgs p) 
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
                     const int m = t * BM + rr + it * RPI;
-                    arows[it] = m < p.M ? *(const i32x4*)(dx + (size_t)m * p.lddx + cc * 8) : i32x4{0, 0, 0, 0};
+                    arows[it] = (m < p.M && stq) ? *(const i32x4*)(dx + (size_t)m * p.lddx + cc * 8) : i32x4{0, 0, 0, 0};
                 }
             }
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int row = rr + it * RPI;
                 const int m = t * BM + row;
-                if (m >= p.M) break;
+                if (m >= p.M || !stq) break;
                 V16 v, yv;
                 yv.i = STATS_OK ? yrows[it] : i32x4{0, 0, 0, 0};
                 {
@@ -435,7 +440,7 @@ int fused_launch(const FusedArgs& a, int grid, hipStream_t st) {
     attr_once.run([&] {
         (void)hipFuncSetAttribute((const void*)conv1x1_bwd_kernel<KT, CT, BM, NXB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     });
-    hdy_note_dispatch(KT == 32 ? "conv1x1_bwd_32" : (KT == 64 ? "conv1x1_bwd_64" : "conv1x1_bwd_128"));
+    hdy_note_dispatch(KT == 32 ? "conv1x1_bwd_32" : (KT == 64 ? "conv1x1_bwd_64" : (KT == 96 ? "conv1x1_bwd_96" : "conv1x1_bwd_128")));
     hipLaunchKernelGGL((conv1x1_bwd_kernel<KT, CT, BM, NXB>), dim3(grid), dim3(256), smem, st, a);
     HDY_LAUNCH_CHECK("conv1x1_bwd");
     return HDY_OK;
@@ -443,7 +448,7 @@ int fused_launch(const FusedArgs& a, int grid, hipStream_t st) {
 
 // 128-wide: 64-pixel tiles, so that two workgroups fit a CU's LDS.  (64-pixel tiles / four workgroups per CU for the 32- and 64-wide instances were
 // measured in round 3 and are gone: 64<>64 @160x160 265 -> 288 us, 32<>32 207 -> 228 us)
-inline int tile_rows(int K) { return K == 128 ? 64 : 128; }
+inline int tile_rows(int K) { return K >= 96 ? 64 : 128; }
 
 }  // namespace
 
@@ -454,7 +459,7 @@ extern "C" {
 
 // 1 when hdy_conv1x1_bwd_fused has a kernel for this (C, K, dtype)
 int hdy_conv1x1_bwd_fused_ok(int C, int K, int dtype) {
-    return dtype == HDY_BF16 && C == K && (K == 32 || K == 64 || K == 128) ? 1 : 0;
+    return dtype == HDY_BF16 && C == K && (K == 32 || K == 64 || K == 128 || (K == 96 && !hdy_opt(HDY_OPT_NO_F1X1_96))) ? 1 : 0;
 }
 
 // workgroups (= fp32 weight-gradient slabs) the fused kernel uses for M pixels
@@ -534,6 +539,7 @@ static int fused_impl(const void* dz_a, int lddz_a, const void* dz_b, int lddz_b
     int rc;
     if (K == 32) rc = fused_launch<32, 32, 128, 2>(a, grid, st);
     else if (K == 64) rc = fused_launch<64, 64, 128, 2>(a, grid, st);
+    else if (K == 96) rc = fused_launch<96, 96, 64, 2>(a, grid, st);          // round 6: yolov5m's 96-wide 1x1 units (two 64-channel sub-tiles per row, the second half full)
     else rc = fused_launch<128, 128, 64, 1>(a, grid, st);
     if (rc || !grad_a) return rc;
     rc = hdy_wgrad_reduce_launch(a.partial, grid, (size_t)K * C, K_a, C, 0, C, 1, 1, grad_a, accumulate_w, st);

@@ -661,7 +661,10 @@ def test_errors_are_loud():
                                           (128, 128 * 4 + 77, True, False), (128, 128 * 150 + 5, False, True), (64, 128 * 180, True, False),
                                           # more than 512 tiles: workgroups walk 2-3 tiles (requests in flight across tiles), partial last tile
                                           (64, (7, 18839), True, True), (32, (5, 17921), False, False), (64, (4, 19200), False, False),
-                                          (32, (10, 19210), True, True), (128, (7, 10057), True, True)])
+                                          (32, (10, 19210), True, True), (128, (7, 10057), True, True),
+                                          # round 6: the 96-channel instance (yolov5m: 12 chunks per row, 192 of 256 threads in the element-wise and store phases)
+                                          (96, 64 * 3 + 37, False, False), (96, 64 * 5 + 1, True, True), (96, 50, False, True), (96, 64 * 150 + 5, False, True),
+                                          (96, (7, 10057), True, True), (96, (4, 19200), False, False)])
 def test_fused_1x1_backward_matches_reference_and_the_three_launch_path(K, M, pair, acc):
     """hdy_conv1x1_bwd_fused (BatchNorm/SiLU backward apply + wgrad + dgrad in one pass) against (a) plain torch fp32 on the bf16-rounded
     operands and (b) the three-launch path (hdy_bn_act_bwd -> dy, hdy_conv_wgrad, hdy_conv_dgrad) it replaces: same dy bits, so dx / dW
