@@ -5,11 +5,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 from hd_yolo_amd import synth, bench_util
 from metayolo.models.yolo import Model
-m = Model(synth.make_cfg('s', 8), synth.make_hyp())
+V = sys.argv[1] if len(sys.argv) > 1 else 's'
+BB = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+m = Model(synth.make_cfg(V, 8), synth.make_hyp())
 m.load_state_dict(synth.synth_state_dict(synth.shapes_of(m), seed=0), strict=False)
 m = m.to('cuda:0').train(); m.half()
-x = synth.synth_images(64, 640, seed=0).to('cuda:0')
-t = synth.synth_targets(64, 640, 8, seed=1)
+x = synth.synth_images(BB, 640, seed=0).to('cuda:0')
+t = synth.synth_targets(BB, 640, 8, seed=1)
 for tt in t:
     for a in tt['anns']['det']:
         a['boxes'], a['labels'] = a['boxes'].cuda(), a['labels'].cuda()
